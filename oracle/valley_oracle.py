@@ -1,0 +1,378 @@
+"""CPU oracle for Valley's visual-token hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain fp32 PyTorch ops on the CPU, the arithmetic the reference executes on
+its hot path, so that the HIP path can be checked against it.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; nothing under
+``valley_amd/`` does, and the product path fails loudly when the HIP library is missing.
+
+What it restates (citations are into /root/reference unless they start with ``hf:``, which means
+the installed third-party ``transformers`` 5.15.0 under
+/usr/local/lib/python3.10/dist-packages/transformers/models/ — the reference pins
+``transformers @ git+...@cae78c46`` in pyproject.toml:19 and does not vendor it):
+
+* CLIP ViT-L/14 tower to ``hidden_states[select_layer]``
+  - embeddings: hf:clip/modeling_clip.py:203-218 (patch conv, CLS concat, position add)
+  - pre_layrnorm + encoder layers: hf:clip/modeling_clip.py:641-647, 353-383
+  - attention (non-causal, fp32 softmax, scale hd^-0.5): hf:clip/modeling_clip.py:258-277, 302-334
+  - MLP with quick_gelu x*sigmoid(1.702x): hf:clip/modeling_clip.py:338-350
+  - called from valley/model/valley_model.py:172-183 (per clip, hidden_states[-2], CLS kept)
+* mm_projector + temporal pooling + CLS pick: valley/model/valley_model.py:187-193, 206-215,
+  v2 importance pooling :113-121, v3 transformer-delta :123-133
+* visual-token splice with the reference's error behaviour: valley/model/valley_model.py:195-247
+* Llama decoder (RMSNorm / RoPE rotate-half / causal+padding softmax attention / SwiGLU):
+  hf:llama/modeling_llama.py:51-67 (RMSNorm), 73-124 + 127-157 (RoPE), 160-173 (MLP),
+  191-213 (eager attention), 217-289 (attention block), 292-332 (decoder layer)
+  called from valley/model/valley_model.py:249-254; lm_head :304-305
+* manual prefill + KV decode loop and sampling rule: valley/serve/model_worker.py:371-394
+
+Pinning: tests/test_oracle_golden.py checks every function here against fixtures under
+tests/golden/ that tools/gen_goldens.py captured in the authoring container by importing the
+reference itself (valley.model.valley_model, with stub modules for its absent I/O dependencies)
+on top of the installed transformers, fed with valley_amd.weights' deterministic tensors.  The
+reference has no tests or golden vectors of its own, so those captured outputs are
+the anchor; tolerance fp32 vs fp32 is 2e-5 max-abs.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------
+# configs
+# --------------------------------------------------------------------------------------------
+@dataclass
+class VisionCfg:
+    hidden: int = 1024
+    heads: int = 16
+    intermediate: int = 4096
+    layers: int = 24
+    image_size: int = 224
+    patch: int = 14
+    eps: float = 1e-5
+
+
+@dataclass
+class LlamaCfg:
+    hidden: int = 4096
+    heads: int = 32
+    intermediate: int = 11008
+    layers: int = 32
+    vocab: int = 32006
+    eps: float = 1e-5           # 1e-5 Llama-2, 1e-6 LLaMA-1/Vicuna
+    rope_theta: float = 10000.0
+
+
+@dataclass
+class TokenIds:
+    """The six ids the entry points bind onto vision_tower.config
+    (valley/inference/run_valley.py:13-18)."""
+    im_patch_token: int
+    vi_frame_token: int
+    im_start_token: int
+    im_end_token: int
+    vi_start_token: int
+    vi_end_token: int
+
+
+def _t(w: Dict, k: str) -> torch.Tensor:
+    v = w[k]
+    if not isinstance(v, torch.Tensor):
+        v = torch.from_numpy(v)
+    return v.float()
+
+
+# --------------------------------------------------------------------------------------------
+# CLIP vision tower
+# --------------------------------------------------------------------------------------------
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    """hf:activations.py QuickGELUActivation: x * sigmoid(1.702 x)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def clip_embeddings(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, prefix: str = "") -> torch.Tensor:
+    """hf:clip/modeling_clip.py:203-218.  pixels [F,3,H,W] -> [F, 1+P, D]."""
+    pw = _t(w, prefix + "embeddings.patch_embedding.weight")
+    x = F.conv2d(pixels.float(), pw, bias=None, stride=cfg.patch)          # [F, D, g, g]
+    x = x.flatten(2).transpose(1, 2)                                        # [F, P, D]
+    cls = _t(w, prefix + "embeddings.class_embedding").expand(x.shape[0], 1, -1)
+    x = torch.cat([cls, x], dim=1)
+    return x + _t(w, prefix + "embeddings.position_embedding.weight")[None]
+
+
+def clip_attention(x: torch.Tensor, w: Dict, p: str, heads: int) -> torch.Tensor:
+    """hf:clip/modeling_clip.py:302-334 with eager_attention_forward :258-277 (no mask)."""
+    Fn, N, D = x.shape
+    hd = D // heads
+    q = F.linear(x, _t(w, p + "q_proj.weight"), _t(w, p + "q_proj.bias")).view(Fn, N, heads, hd).transpose(1, 2)
+    k = F.linear(x, _t(w, p + "k_proj.weight"), _t(w, p + "k_proj.bias")).view(Fn, N, heads, hd).transpose(1, 2)
+    v = F.linear(x, _t(w, p + "v_proj.weight"), _t(w, p + "v_proj.bias")).view(Fn, N, heads, hd).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)
+    a = torch.softmax(s, dim=-1, dtype=torch.float32)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(Fn, N, D)
+    return F.linear(o, _t(w, p + "out_proj.weight"), _t(w, p + "out_proj.bias"))
+
+
+def clip_layer(x: torch.Tensor, w: Dict, p: str, cfg: VisionCfg) -> torch.Tensor:
+    """hf:clip/modeling_clip.py:353-383 (pre-LN encoder layer)."""
+    h = F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm1.weight"), _t(w, p + "layer_norm1.bias"), cfg.eps)
+    x = x + clip_attention(h, w, p + "self_attn.", cfg.heads)
+    h = F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm2.weight"), _t(w, p + "layer_norm2.bias"), cfg.eps)
+    h = F.linear(h, _t(w, p + "mlp.fc1.weight"), _t(w, p + "mlp.fc1.bias"))
+    h = quick_gelu(h)
+    h = F.linear(h, _t(w, p + "mlp.fc2.weight"), _t(w, p + "mlp.fc2.bias"))
+    return x + h
+
+
+def clip_hidden_states(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, n_layers: Optional[int] = None,
+                       prefix: str = "") -> List[torch.Tensor]:
+    """All encoder hidden states, HF convention: [0] = pre_layrnorm(embeddings),
+    [i] = output of layer i (hf:clip/modeling_clip.py:641-647)."""
+    x = clip_embeddings(pixels, w, cfg, prefix)
+    x = F.layer_norm(x, (cfg.hidden,), _t(w, prefix + "pre_layrnorm.weight"), _t(w, prefix + "pre_layrnorm.bias"), cfg.eps)
+    hs = [x]
+    L = cfg.layers if n_layers is None else n_layers
+    for i in range(L):
+        x = clip_layer(x, w, prefix + f"encoder.layers.{i}.", cfg)
+        hs.append(x)
+    return hs
+
+
+def vit_select(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, select_layer: int = -2, prefix: str = "") -> torch.Tensor:
+    """valley_model.py:180-183: hidden_states[select_layer][:, :] (CLS kept).  Only the layers that
+    contribute are evaluated: hidden_states has cfg.layers+1 entries, so index -2 is the output of
+    layer cfg.layers-1 and the last layer / post_layernorm never run."""
+    idx = select_layer if select_layer >= 0 else cfg.layers + 1 + select_layer
+    return clip_hidden_states(pixels, w, cfg, n_layers=idx, prefix=prefix)[idx]
+
+
+# --------------------------------------------------------------------------------------------
+# projector + temporal pooling
+# --------------------------------------------------------------------------------------------
+def mm_project(feats: torch.Tensor, w: Dict) -> torch.Tensor:
+    """valley_model.py:54-55,190: Linear(mm_hidden -> H) + bias on every token."""
+    return F.linear(feats, _t(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias"))
+
+
+def sinusoid_position_matrix(seq_len: int, d: int, n: float = 10000.0) -> torch.Tensor:
+    """valley_model.py:104-111 (vectorised; same values)."""
+    k = torch.arange(seq_len, dtype=torch.float32)[:, None]
+    i = torch.arange(d // 2, dtype=torch.float32)[None, :]
+    den = torch.pow(torch.tensor(n), 2 * i / d)
+    P = torch.zeros(seq_len, d)
+    P[:, 0::2] = torch.sin(k / den)
+    P[:, 1::2] = torch.cos(k / den)
+    return P
+
+
+def pool_clip(proj: torch.Tensor, method: str, w: Optional[Dict] = None, nhead: int = 8) -> Tuple[torch.Tensor, torch.Tensor]:
+    """valley_model.py:206-215 on one clip.  proj [T, 1+P, H] (already projected).
+    Returns (pooled patch tokens [P, H], per-frame CLS tokens [T, H])."""
+    patches = proj[:, 1:, :]
+    if method == "mean":
+        pooled = patches.mean(dim=0)
+    elif method == "max":
+        pooled = patches.max(dim=0)[0]
+    elif method == "temporal_importance":
+        # valley_model.py:113-121
+        flat = torch.flatten(patches, start_dim=1)                          # [T, P*H]
+        score = torch.softmax(F.linear(flat, _t(w, "model.pooling_layer.weight"), _t(w, "model.pooling_layer.bias")), dim=0)
+        pooled = (score.unsqueeze(2) * patches).sum(dim=0)
+    elif method == "temporal_transformer":
+        # valley_model.py:123-133 : nn.TransformerEncoderLayer(d_model=H, nhead=8, batch_first=True),
+        # torch defaults: dim_feedforward 2048, relu, post-LN (norm_first False), eps 1e-5.
+        x = patches.permute(1, 0, 2)                                        # [P, T, H]
+        T = x.shape[1]
+        pos = _t(w, "model.position_matrix")[:T][None]
+        delta = torch_encoder_layer(x + pos, w, "model.transformer_delta_encoder.layers.0.", nhead)[:, -1, :]
+        pooled = delta + x.mean(dim=1)
+    else:
+        raise ValueError(method)
+    return pooled, proj[:, 0, :]
+
+
+def torch_encoder_layer(x: torch.Tensor, w: Dict, p: str, nhead: int) -> torch.Tensor:
+    """torch.nn.TransformerEncoderLayer forward (post-LN, ReLU FFN), eval mode."""
+    B, T, H = x.shape
+    hd = H // nhead
+    qkv = F.linear(x, _t(w, p + "self_attn.in_proj_weight"), _t(w, p + "self_attn.in_proj_bias"))
+    q, k, v = qkv.chunk(3, dim=-1)
+    q = q.view(B, T, nhead, hd).transpose(1, 2)
+    k = k.view(B, T, nhead, hd).transpose(1, 2)
+    v = v.view(B, T, nhead, hd).transpose(1, 2)
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, T, H)
+    o = F.linear(o, _t(w, p + "self_attn.out_proj.weight"), _t(w, p + "self_attn.out_proj.bias"))
+    x = F.layer_norm(x + o, (H,), _t(w, p + "norm1.weight"), _t(w, p + "norm1.bias"), 1e-5)
+    f = F.linear(F.relu(F.linear(x, _t(w, p + "linear1.weight"), _t(w, p + "linear1.bias"))),
+                 _t(w, p + "linear2.weight"), _t(w, p + "linear2.bias"))
+    return F.layer_norm(x + f, (H,), _t(w, p + "norm2.weight"), _t(w, p + "norm2.bias"), 1e-5)
+
+
+# --------------------------------------------------------------------------------------------
+# visual-token splice (integer index logic + row copies)
+# --------------------------------------------------------------------------------------------
+def splice_visual_tokens(input_ids: torch.Tensor, inputs_embeds: torch.Tensor,
+                         image_features: Sequence[torch.Tensor], tok: TokenIds, method: str = "mean",
+                         w: Optional[Dict] = None) -> torch.Tensor:
+    """valley_model.py:195-247, statement for statement.
+
+    image_features: per multimodal sample, projected features [T_i, 1+P, H].  ``cur_image_idx``
+    advances only on samples that contain <im_patch> (:198-202,246).  Raises ValueError exactly where
+    the reference does (:219-220, :226-227); any failure in the <vi_start> block is swallowed and
+    the image-only splice kept (:231-244).
+    """
+    new_embeds = []
+    cur_image_idx = 0
+    for ids, emb in zip(input_ids, inputs_embeds):
+        if (ids == tok.im_patch_token).sum() == 0:
+            new_embeds.append(emb)                       # + 0*dummy.sum() is a numeric no-op (:200)
+            continue
+        feats = image_features[cur_image_idx]
+        pooled, cls = pool_clip(feats, method, w)
+        P = pooled.shape[0]
+        if (ids == tok.im_start_token).sum() != (ids == tok.im_end_token).sum():
+            raise ValueError("The number of im_start_token and im_end_token should be the same")
+        cur = emb.clone()
+        for pos in torch.where(ids == tok.im_start_token)[0]:
+            pos = int(pos)
+            # reference indexes ids[pos+P+1] unguarded: IndexError if the prompt is too short
+            if ids[pos + P + 1] != tok.im_end_token:
+                raise ValueError("Seems that the image is cut.")
+            cur = torch.cat((cur[:pos + 1], pooled, cur[pos + P + 1:]), dim=0)
+        try:
+            if (ids == tok.vi_start_token).sum() != (ids == tok.vi_end_token).sum():
+                raise ValueError("The number of vi_start_token and vi_end_token should be the same")
+            T = cls.shape[0]
+            assert (ids == tok.vi_frame_token).sum() == T
+            vid = cur.clone()
+            for pos in torch.where(ids == tok.vi_start_token)[0]:
+                pos = int(pos)
+                if ids[pos + T + 1] != tok.vi_end_token:
+                    raise ValueError("Seems that the image is cut.")
+                vid = torch.cat((vid[:pos + 1], cls, vid[pos + T + 1:]), dim=0)
+        except Exception:                                # bare except in the reference (:243)
+            vid = cur.clone()
+        new_embeds.append(vid)
+        cur_image_idx += 1
+    return torch.stack(new_embeds, dim=0)
+
+
+# --------------------------------------------------------------------------------------------
+# Llama decoder
+# --------------------------------------------------------------------------------------------
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """hf:llama/modeling_llama.py:61-66."""
+    var = x.float().pow(2).mean(-1, keepdim=True)
+    return weight * (x.float() * torch.rsqrt(var + eps))
+
+
+def rope_cos_sin(positions: torch.Tensor, head_dim: int, theta: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """hf:llama/modeling_llama.py:95-124: inv_freq = theta^(-2i/d); emb = cat(freqs, freqs)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = positions.float()[..., None] * inv                               # [..., d/2]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """hf:llama/modeling_llama.py:127-131."""
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """hf:llama/modeling_llama.py:134-157, x [B,h,S,d], cos/sin [B,S,d]."""
+    return x * cos[:, None] + rotate_half(x) * sin[:, None]
+
+
+def build_additive_mask(attention_mask: Optional[torch.Tensor], B: int, q_len: int, kv_len: int) -> torch.Tensor:
+    """causal AND padding as an additive fp32 mask [B,1,q,kv] (hf masking_utils semantics:
+    key j visible to query i iff j <= i + past and attention_mask[b, j] == 1)."""
+    past = kv_len - q_len
+    i = torch.arange(q_len)[:, None] + past
+    j = torch.arange(kv_len)[None, :]
+    allowed = (j <= i)[None, None].expand(B, 1, q_len, kv_len)
+    if attention_mask is not None:
+        allowed = allowed & attention_mask[:, None, None, :kv_len].bool()
+    return torch.where(allowed, 0.0, torch.finfo(torch.float32).min)
+
+
+def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
+                past: Optional[Tuple[torch.Tensor, torch.Tensor]]):
+    """hf:llama/modeling_llama.py:292-332 + 217-289."""
+    B, S, H = x.shape
+    hd = H // cfg.heads
+    h = rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps)
+    q = F.linear(h, _t(w, p + "self_attn.q_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
+    k = F.linear(h, _t(w, p + "self_attn.k_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
+    v = F.linear(h, _t(w, p + "self_attn.v_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
+    q = apply_rope(q, cos, sin)
+    k = apply_rope(k, cos, sin)
+    if past is not None:
+        k = torch.cat([past[0], k], dim=2)
+        v = torch.cat([past[1], v], dim=2)
+    s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5) + mask
+    a = torch.softmax(s, dim=-1, dtype=torch.float32)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, S, H)
+    x = x + F.linear(o, _t(w, p + "self_attn.o_proj.weight"))
+    h = rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps)
+    g = F.linear(h, _t(w, p + "mlp.gate_proj.weight"))
+    u = F.linear(h, _t(w, p + "mlp.up_proj.weight"))
+    x = x + F.linear(F.silu(g) * u, _t(w, p + "mlp.down_proj.weight"))
+    return x, (k, v)
+
+
+def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,
+                  attention_mask: Optional[torch.Tensor] = None,
+                  past: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None,
+                  n_layers: Optional[int] = None):
+    """hf:llama/modeling_llama.py:372-417: positions = arange(S) + past_len (independent of the
+    padding mask), final RMSNorm.  Returns (hidden [B,S,H], new past)."""
+    B, S, H = inputs_embeds.shape
+    past_len = 0 if past is None else past[0][0].shape[2]
+    pos = (torch.arange(S) + past_len)[None].expand(B, S)
+    cos, sin = rope_cos_sin(pos, H // cfg.heads, cfg.rope_theta)
+    mask = build_additive_mask(attention_mask, B, S, past_len + S)
+    x = inputs_embeds.float()
+    new_past = []
+    L = cfg.layers if n_layers is None else n_layers
+    for i in range(L):
+        x, kv = llama_layer(x, w, f"model.layers.{i}.", cfg, cos, sin, mask, None if past is None else past[i])
+        new_past.append(kv)
+    return rms_norm(x, _t(w, "model.norm.weight"), cfg.eps), new_past
+
+
+# --------------------------------------------------------------------------------------------
+# whole path
+# --------------------------------------------------------------------------------------------
+def valley_forward(input_ids: torch.Tensor, images, w: Dict, vw: Dict, lcfg: LlamaCfg, vcfg: VisionCfg,
+                   tok: TokenIds, attention_mask: Optional[torch.Tensor] = None, past=None,
+                   select_layer: int = -2, method: str = "mean", vprefix: str = ""):
+    """ValleyLlamaForCausalLM.forward (valley_model.py:272-330) without the loss.
+    images: [B,T,3,H,W] tensor or list of [T_i,3,H,W] (valley_model.py:168-184)."""
+    emb = F.embedding(input_ids, _t(w, "model.embed_tokens.weight"))
+    if images is not None and input_ids.shape[1] != 1:
+        feats = [mm_project(vit_select(clip, vw, vcfg, select_layer, vprefix), w) for clip in images]
+        emb = splice_visual_tokens(input_ids, emb, feats, tok, method, w)
+    hidden, new_past = llama_forward(emb, w, lcfg, attention_mask, past)
+    logits = F.linear(hidden, _t(w, "lm_head.weight"))
+    return logits, new_past, emb
+
+
+def greedy_decode(input_ids: torch.Tensor, images, w, vw, lcfg, vcfg, tok, steps: int, **kw):
+    """valley/serve/model_worker.py:371-394 with temperature < 1e-4 (argmax):
+    prefill once, then feed one token at a time with the growing KV cache and an all-ones mask."""
+    logits, past, _ = valley_forward(input_ids, images, w, vw, lcfg, vcfg, tok, **kw)
+    out_tokens, out_logits = [], []
+    for _ in range(steps):
+        last = logits[:, -1, :]
+        out_logits.append(last)
+        token = last.argmax(dim=-1)
+        out_tokens.append(token)
+        logits, past, _ = valley_forward(token[:, None], None, w, vw, lcfg, vcfg, tok, past=past)
+    return torch.stack(out_tokens, 1), torch.stack(out_logits, 1)
