@@ -1,0 +1,129 @@
+/*
+ * valley_hip.h — C ABI of libvalley_hip.so, the MI355X (gfx950) kernels behind Valley's
+ * visual-token hot path.
+ *
+ * The reference (RupertLuo/Valley) has no FFI/plugin layer: its hot path is Python calling
+ * HuggingFace modules (valley/model/valley_model.py:163-254, 292-305).  This header is the boundary
+ * a maintainer binds instead of those module calls (ctypes stub in INTEGRATION.md;
+ * valley_amd/lib.py is that binding).  Each entry point cites the reference / third-party
+ * call it replaces.  "hf:" = transformers/models/… (the un-vendored dependency pinned at
+ * pyproject.toml:19).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in practice);
+ *     nothing is allocated, freed or retained; no global state; thread-safe per distinct stream.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised.
+ *   - bf16 = raw uint16_t storage; the residual stream and norm parameters are fp32.
+ *   - row-major everywhere; leading dimensions are in ELEMENTS.
+ *   - return 0 on success, -22 (EINVAL) for unsupported shapes/alignments,
+ *     -(1000+hipError_t) if a launch failed.  vly_last_error() gives a thread-local message.
+ */
+#ifndef VALLEY_HIP_H
+#define VALLEY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLY_ABI_VERSION 1
+
+/* epilogues of vly_gemm_bf16 */
+#define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
+#define VLY_EPI_QUICK_GELU  1   /* C = q(A W^T + bias), q(x) = x*sigmoid(1.702x)  hf:activations.py  */
+#define VLY_EPI_SWIGLU      2   /* W rows interleaved (gate_j, up_j): C[:, j] = silu(g_j) * u_j,
+                                   C is N/2 wide                     hf:llama/modeling_llama.py:171 */
+/* output dtypes */
+#define VLY_OUT_BF16 0
+#define VLY_OUT_F32  1
+
+/* pooling modes of vly_pool_tokens (valley/model/valley_model.py:206-209) */
+#define VLY_POOL_MEAN 0
+#define VLY_POOL_MAX  1
+
+int         vly_abi_version(void);
+const char *vly_last_error(void);
+
+/* GEMM with fused epilogue:  C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) + residual[M,N]
+ *   A, W bf16; bias fp32 or NULL; residual fp32 or NULL (ldr); C bf16 or fp32 (out_dtype).
+ *   W is an nn.Linear weight as stored ([out,in] row-major) — no transpose is ever materialised.
+ *   Requires K % 64 == 0, lda/ldw % 8 == 0, N % 4 == 0 (N % 8 for SWIGLU), 16-byte aligned bases.
+ *   Replaces every nn.Linear / Conv2d-as-GEMM on the path: CLIP patch embedding
+ *   (hf:clip/modeling_clip.py:148-154,209), q/k/v/out_proj (:293-296), fc1/fc2 (:343-344),
+ *   mm_projector (valley_model.py:54-55,190), Llama q/k/v/o (hf:llama/modeling_llama.py:230-241),
+ *   gate/up/down (:166-168), lm_head (valley_model.py:264,305).
+ *   tile_hint: 0 = auto, 1 = 256x256, 2 = 128x128, 3 = 256x128 (tuning / tests). */
+int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
+                  int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+                  int epilogue, int out_dtype, int tile_hint, void *stream);
+
+/* LayerNorm over the last dim of an fp32 [M,D] tensor -> bf16 (GEMM input) and optionally fp32.
+ *   hf:clip/modeling_clip.py:605,642 (pre_layrnorm), :363,368 (layer_norm1/2).  D % 256 == 0, D <= 8192. */
+int vly_layernorm(const float *x, const float *gamma, const float *beta, void *y_bf16, float *y_f32,
+                  int M, int D, float eps, void *stream);
+
+/* RMSNorm (fp32 statistics) of fp32 [M,D] -> bf16.  hf:llama/modeling_llama.py:61-66.  Same D limits. */
+int vly_rmsnorm(const float *x, const float *gamma, void *y_bf16, int M, int D, float eps, void *stream);
+
+/* im2col for the 14x14/stride-14 patch conv: images bf16 [F,3,224,224] -> patches bf16 [F*256, 640]
+ *   (k = c*196 + ky*14 + kx, columns 588..639 zero) so that Conv2d becomes vly_gemm_bf16 with the
+ *   zero-padded [1024,640] weight.  hf:clip/modeling_clip.py:209-210. */
+int vly_patchify(const void *images_bf16, void *patches_bf16, int F, void *stream);
+
+/* CLS concat + position add + pre_layrnorm: patch_out fp32 [F*256,1024] (the patch GEMM's fp32
+ *   output) -> residual stream fp32 [F*257,1024].  hf:clip/modeling_clip.py:212-217 then :642. */
+int vly_vit_embed_ln(const float *patch_out_f32, const float *cls, const float *pos,
+                     const float *gamma, const float *beta, float *h_f32, int F, float eps, void *stream);
+
+/* ViT self-attention, non-causal, no mask, 16 heads x 64, N = 257 tokens per frame:
+ *   qkv bf16 [F*257, 3072] (q | k | v, biases already added) -> out bf16 [F*257, 1024].
+ *   softmax in fp32, scale 64^-0.5.  hf:clip/modeling_clip.py:258-277, 317-330. */
+int vly_vit_attention(const void *qkv_bf16, void *out_bf16, int F, void *stream);
+
+/* Temporal pooling + per-frame CLS pick for B clips of T frames:
+ *   feats fp32 [B,T,257,W] -> out bf16 [B, 256+T, W]; rows 0..255 = mean/max over T of patch
+ *   tokens, rows 256.. = CLS token of each frame.  valley/model/valley_model.py:206-215. */
+int vly_pool_tokens(const float *feats_f32, void *out_bf16, int B, int T, int W, int mode, void *stream);
+
+/* Token-embedding gather + visual-token splice -> fp32 residual stream:
+ *   row_map int32 [R]: v >= 0 -> embed_table[v];  v < 0 -> visual[-v-1].
+ *   embed_table bf16 [V,H], visual bf16 [NV,H], out fp32 [R,H].
+ *   valley/model/valley_model.py:160 and the row copies of :228,:242 (the integer index logic and
+ *   its ValueErrors stay on the host, valley_amd/splice.py). */
+int vly_embed_splice(const int32_t *row_map, const void *embed_bf16, const void *visual_bf16,
+                     float *out_f32, int R, int H, void *stream);
+
+/* RoPE (rotate-half) on q and k of a fused qkv buffer + KV-cache append:
+ *   qkv bf16 [B*S, 3*heads*128]; q rotated in place; rotated k and v written to
+ *   kcache/vcache bf16 [B, heads, ctx_max, 128] at positions past_len..past_len+S-1.
+ *   position of row s = past_len + s (independent of padding).  cos/sin: fp32 tables
+ *   [ctx_max, 64] indexed by absolute position (built by the host exactly as
+ *   hf:llama/modeling_llama.py:95-124).  Rotation :127-157, KV append :261-262 (legacy tuple cat
+ *   at the pinned commit). */
+int vly_rope_kv(void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
+                const float *sin_table, int B, int S, int heads, int past_len, int ctx_max, void *stream);
+
+/* Causal self-attention over the KV cache, head_dim 128:
+ *   q from qkv bf16 [B*S, 3*heads*128] (first third), K/V from the caches, kv_len = past_len+S.
+ *   key_valid uint8 [B, kv_len] or NULL (1 = attend; the padding half of HF's additive mask).
+ *   out bf16 [B*S, heads*128].  Works for S == 1 (decode) too.
+ *   hf:llama/modeling_llama.py:191-213, mask = causal AND padding (:386-397 / masking_utils). */
+int vly_llama_attention(const void *qkv_bf16, const void *kcache_bf16, const void *vcache_bf16,
+                        const uint8_t *key_valid, void *out_bf16, int B, int S, int heads,
+                        int past_len, int ctx_max, void *stream);
+
+/* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
+ *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
+ *   serve/model_worker.py:380-387 (one-token forward). */
+int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
+                  int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+                  int epilogue, int out_dtype, void *stream);
+
+/* argmax over the last dim of fp32 [M,N] -> int32 [M].  serve/model_worker.py:389-391. */
+int vly_argmax(const float *x, int32_t *idx, int M, int N, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALLEY_HIP_H */

@@ -1,0 +1,264 @@
+"""GPU unit parity: every HIP kernel (through the C ABI) vs a plain fp32 PyTorch statement of the
+same op on the same seeded inputs.  Tolerances are written per test: bf16 storage gives ~2^-8
+relative error per rounding; fp32-output paths are held to tighter bounds."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def relerr(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+def maxabs(got, ref):
+    return float((got.float().cpu() - ref.float().cpu()).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (1028, 1024, 1024), (64, 512, 64), (513, 4096, 640)])
+def test_gemm_plain(M, N, K, tile):
+    from valley_amd import ops
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.05, dtype=torch.bfloat16)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm_mfma(a.to(dev()), w.to(dev()), out_dtype=torch.float32, tile_hint=tile)
+    torch.cuda.synchronize()
+    # fp32 accumulation of exact bf16 products: only summation-order noise
+    assert maxabs(out, ref) < 2e-4 * math.sqrt(K), (maxabs(out, ref))
+    out16 = ops.gemm_mfma(a.to(dev()), w.to(dev()), tile_hint=tile)
+    assert relerr(out16, ref) < 4e-3
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_epilogues(tile):
+    from valley_amd import ops
+    M, N, K = 771, 1024, 256
+    a = rnd((M, K), 3, dtype=torch.bfloat16)
+    w = rnd((N, K), 4, 0.05, dtype=torch.bfloat16)
+    bias = rnd((N,), 5, 0.5)
+    res = rnd((M, N), 6)
+    base = a.float() @ w.float().t() + bias
+    d = dev()
+    # bias + residual, fp32 out (the residual-stream update)
+    out = ops.gemm_mfma(a.to(d), w.to(d), bias.to(d), res.to(d), out_dtype=torch.float32, tile_hint=tile)
+    assert maxabs(out, base + res) < 5e-3
+    # quick_gelu
+    out = ops.gemm_mfma(a.to(d), w.to(d), bias.to(d), epilogue=ops.EPI_QUICK_GELU, tile_hint=tile)
+    ref = base * torch.sigmoid(1.702 * base)
+    assert relerr(out, ref) < 4e-3
+    # swiglu on interleaved rows
+    out = ops.gemm_mfma(a.to(d), w.to(d), epilogue=ops.EPI_SWIGLU, tile_hint=tile)
+    nb = a.float() @ w.float().t()
+    ref = torch.nn.functional.silu(nb[:, 0::2]) * nb[:, 1::2]
+    assert out.shape == (M, N // 2)
+    assert relerr(out, ref) < 4e-3
+
+
+def test_gemm_strided_a_and_asymmetric():
+    """A with a row stride (a slice of a wider buffer) and a weight with one hot row/col: catches
+    transposed fragments that symmetric data would hide."""
+    from valley_amd import ops
+    d = dev()
+    big = rnd((200, 512), 7, dtype=torch.bfloat16).to(d)
+    a = big[:, 128:384]
+    w = torch.zeros((128, 256), dtype=torch.bfloat16)
+    w[3, 17] = 1.0
+    w[100, 255] = 2.0
+    out = ops.gemm_mfma(a, w.to(d), out_dtype=torch.float32)
+    ref = a.float().cpu() @ w.float().t()
+    assert maxabs(out, ref) == 0.0
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 8])
+def test_gemv(M):
+    from valley_amd import ops
+    N, K = 1000, 1024
+    d = dev()
+    a = rnd((M, K), 8, dtype=torch.bfloat16)
+    w = rnd((N, K), 9, 0.05, dtype=torch.bfloat16)
+    bias = rnd((N,), 10, 0.5)
+    res = rnd((M, N), 11)
+    base = a.float() @ w.float().t()
+    out = ops.gemv(a.to(d), w.to(d), bias.to(d), res.to(d), out_dtype=torch.float32)
+    assert maxabs(out, base + bias + res) < 2e-3
+    out = ops.gemv(a.to(d), w.to(d), epilogue=ops.EPI_SWIGLU)
+    ref = torch.nn.functional.silu(base[:, 0::2]) * base[:, 1::2]
+    assert relerr(out, ref) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [1024, 4096, 5120, 256])
+def test_norms(D):
+    from valley_amd import ops
+    d = dev()
+    x = rnd((37, D), 12, 2.0) + 0.3
+    g = rnd((D,), 13, 0.1) + 1.0
+    b = rnd((D,), 14, 0.1)
+    y16, y32 = ops.layernorm(x.to(d), g.to(d), b.to(d), 1e-5, want_f32=True)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
+    assert maxabs(y32, ref) < 2e-5
+    assert maxabs(y16, ref.to(torch.bfloat16)) <= 0.04   # at most one bf16 ulp at |x| < 8
+    y = ops.rmsnorm(x.to(d), g.to(d), 1e-6)
+    ref = g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert relerr(y, ref) < 3e-3
+
+
+def test_patchify_matches_conv():
+    from valley_amd import ops
+    d = dev()
+    F = 3
+    img = rnd((F, 3, 224, 224), 15, dtype=torch.bfloat16)
+    wt = rnd((1024, 3, 14, 14), 16, 0.02, dtype=torch.bfloat16)
+    cols = ops.patchify(img.to(d))
+    ref_cols = torch.nn.functional.unfold(img.float(), kernel_size=14, stride=14).transpose(1, 2).reshape(F * 256, 588)
+    assert maxabs(cols[:, :588], ref_cols) == 0.0
+    assert float(cols[:, 588:].float().abs().max()) == 0.0
+    wpad = torch.zeros((1024, 640), dtype=torch.bfloat16)
+    wpad[:, :588] = wt.reshape(1024, 588)
+    out = ops.gemm_mfma(cols, wpad.to(d), out_dtype=torch.float32)
+    ref = torch.nn.functional.conv2d(img.float(), wt.float(), stride=14).flatten(2).transpose(1, 2).reshape(F * 256, 1024)
+    assert maxabs(out, ref) < 2e-3
+
+
+def test_vit_embed_ln():
+    from valley_amd import ops
+    d = dev()
+    F = 2
+    po = rnd((F * 256, 1024), 17)
+    cls, pos = rnd((1024,), 18), rnd((257, 1024), 19, 0.1)
+    g, b = rnd((1024,), 20, 0.1) + 1.0, rnd((1024,), 21, 0.1)
+    out = ops.vit_embed_ln(po.to(d), cls.to(d), pos.to(d), g.to(d), b.to(d), F, 1e-5)
+    emb = torch.cat([cls.expand(F, 1, 1024), po.view(F, 256, 1024)], 1) + pos[None]
+    ref = torch.nn.functional.layer_norm(emb, (1024,), g, b, 1e-5).view(F * 257, 1024)
+    assert maxabs(out, ref) < 2e-5
+
+
+def test_vit_attention():
+    from valley_amd import ops
+    d = dev()
+    F = 3
+    qkv = rnd((F * 257, 3072), 22, 1.0, dtype=torch.bfloat16)
+    qkv[5, :64] *= 6.0            # one spiky query row
+    out = ops.vit_attention(qkv.to(d), F)
+    x = qkv.float().view(F, 257, 3, 16, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    a = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (a @ v).transpose(1, 2).reshape(F * 257, 1024)
+    assert maxabs(out, ref) < 2.5e-2
+    assert relerr(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pool_tokens(mode):
+    from valley_amd import ops
+    d = dev()
+    B, T, W = 2, 5, 1024
+    f = rnd((B, T, 257, W), 23)
+    out = ops.pool_tokens(f.to(d).view(-1, W), B, T, mode)
+    pooled = f[:, :, 1:].mean(1) if mode == 0 else f[:, :, 1:].max(1)[0]
+    ref = torch.cat([pooled, f[:, :, 0]], dim=1)
+    assert maxabs(out, ref.to(torch.bfloat16)) <= 0.02
+    assert relerr(out, ref) < 3e-3
+
+
+def test_embed_splice():
+    from valley_amd import ops
+    d = dev()
+    V, H, NV = 50, 256, 7
+    emb = rnd((V, H), 24, dtype=torch.bfloat16)
+    vis = rnd((NV, H), 25, dtype=torch.bfloat16)
+    rmap = torch.tensor([0, 49, -1, -7, 3, -2, 10], dtype=torch.int32)
+    out = ops.embed_splice(rmap.to(d), emb.to(d), vis.to(d))
+    ref = torch.stack([emb[v].float() if v >= 0 else vis[-v - 1].float() for v in rmap.tolist()])
+    assert maxabs(out, ref) == 0.0
+
+
+def _rope_tables(n, theta=10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    ang = torch.arange(n, dtype=torch.float32)[:, None] * inv[None]
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+def _ref_attention(q, k, v, past, key_valid):
+    """q [B,h,S,128], k/v [B,h,kv,128] fp32; causal + validity; fp32 softmax."""
+    B, h, S, _ = q.shape
+    kv = k.shape[2]
+    s = q @ k.transpose(-1, -2) * (128 ** -0.5)
+    i = torch.arange(S)[:, None] + past
+    j = torch.arange(kv)[None]
+    allowed = (j <= i)[None, None].expand(B, 1, S, kv)
+    if key_valid is not None:
+        allowed = allowed & key_valid[:, None, None, :].bool()
+    s = torch.where(allowed, s, torch.tensor(-1e30))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("B,S,past,heads,pad", [(2, 75, 0, 2, 9), (1, 336, 0, 3, 0), (2, 1, 130, 2, 5), (1, 40, 100, 2, 0)])
+def test_rope_kv_and_llama_attention(B, S, past, heads, pad):
+    from valley_amd import ops
+    d = dev()
+    Hq = heads * 128
+    ctx_max = 512
+    cos, sin = _rope_tables(ctx_max)
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    if past:
+        kc[:, :, :past] = rnd((B, heads, past, 128), 30, dtype=torch.bfloat16)
+        vc[:, :, :past] = rnd((B, heads, past, 128), 31, dtype=torch.bfloat16)
+    qkv = rnd((B * S, 3 * Hq), 32, dtype=torch.bfloat16)
+    kcd, vcd, qd = kc.to(d), vc.to(d), qkv.to(d).clone()
+    ops.rope_kv(qd, kcd, vcd, cos.to(d), sin.to(d), B, S, heads, past)
+    # reference rope
+    x = qkv.float().view(B, S, 3, heads, 128)
+    pos = torch.arange(S) + past
+    c = torch.cat([cos[pos], cos[pos]], -1)[None, :, None]
+    sn = torch.cat([sin[pos], sin[pos]], -1)[None, :, None]
+
+    def rot(t):
+        return torch.cat([-t[..., 64:], t[..., :64]], -1)
+    qr = x[:, :, 0] * c + rot(x[:, :, 0]) * sn
+    kr = x[:, :, 1] * c + rot(x[:, :, 1]) * sn
+    assert maxabs(qd.view(B, S, 3, heads, 128)[:, :, 0], qr.to(torch.bfloat16)) <= 0.04
+    assert maxabs(kcd[:, :, past:past + S], kr.transpose(1, 2).to(torch.bfloat16)) <= 0.04
+    assert maxabs(vcd[:, :, past:past + S], x[:, :, 2].transpose(1, 2)) == 0.0
+    assert float(kcd[:, :, past + S:].float().abs().max()) == 0.0
+
+    kv = past + S
+    valid = torch.ones((B, kv), dtype=torch.uint8)
+    if pad:
+        valid[0, :pad] = 0                      # left padding on sample 0
+    out = ops.llama_attention(qd, kcd, vcd, valid.to(d) if pad else None, B, S, heads, past)
+    qf = qd.float().cpu().view(B, S, 3, heads, 128)[:, :, 0].transpose(1, 2)
+    ref = _ref_attention(qf, kcd[:, :, :kv].float().cpu(), vcd[:, :, :kv].float().cpu(), past, valid if pad else None)
+    ref = ref.transpose(1, 2).reshape(B * S, Hq)
+    got = out.float().cpu()
+    rows = torch.ones(B * S, dtype=torch.bool)
+    if pad and past == 0:
+        rows[:pad] = False                      # fully-masked (padded) query rows are don't-care
+    assert maxabs(got[rows], ref[rows]) < 2.5e-2
+    assert relerr(got[rows], ref[rows]) < 6e-3
+
+
+def test_argmax():
+    from valley_amd import ops
+    x = rnd((5, 32006), 40)
+    x[2, 31999] = 50.0
+    x[3, 7] = 60.0
+    x[3, 9] = 60.0
+    got = ops.argmax(x.to(dev())).cpu()
+    assert got.tolist() == x.argmax(-1).tolist()

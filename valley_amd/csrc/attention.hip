@@ -1,0 +1,339 @@
+// Attention kernels for gfx950 (MFMA 16x16x32 bf16, fp32 softmax).
+//
+// Both kernels compute S^T = K Q^T with the K fragment as the MFMA "A" operand, so a lane holds,
+// for ONE query row q = lane&15, the scores of keys kv = 16t + 4*(lane>>4) + r: the softmax row
+// reduction is in-register plus two xor-shuffles (16, 32), and the probabilities are already in the
+// B-operand position of the second product O^T = V^T P^T (the k-slot order of a lane's 8 values is
+// chosen to match, so P never crosses lanes).  V is transposed while it is staged into LDS
+// (d-major rows, stride = 16*odd bytes mod 256 so the 8-byte fragment reads are conflict-free);
+// K keeps its row-major image with the 16-byte-chunk XOR swizzle.
+//
+//   vit_attention   : one workgroup per (frame, head); all 257 keys/values of the head live in
+//                     LDS (70.7 KB -> 2 workgroups per CU), no online softmax needed.
+//                     flop/frame/layer = 4*257*257*64*16 = 0.271 GFLOP.
+//   llama_attention : flash-style over KV-cache tiles of 64 keys with online softmax, causal +
+//                     key-validity mask, head_dim 128; also serves decode (S = 1).
+#include "common.hpp"
+#include "../../include/valley_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+VLY_DEVICE uint32_t sel16(const u32x4& a, const u32x4& b, int dd) {   // element dd (0..15) of 16 bf16 in (a,b)
+    const uint32_t w = dd < 8 ? a[dd >> 1] : b[(dd - 8) >> 1];
+    return (dd & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ViT attention
+// ---------------------------------------------------------------------------------------------
+constexpr int VN = 257;            // tokens
+constexpr int VNT = 17;            // 16-key tiles (272 padded keys)
+constexpr int VNC = 9;             // 32-key chunks for P·V (288 padded keys)
+constexpr int VLD = 3072;          // qkv row stride (elements)
+constexpr int VT_STRIDE = 296;     // V^T row stride in elements (592 B = 2*256 + 16*5)
+constexpr int VK_BYTES = VNT * 16 * 128;
+
+__global__ void __launch_bounds__(256) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2];
+    char* sK = smem;
+    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
+    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
+
+    // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7 ------------------------------------
+    for (int s = tid; s < VNT * 16 * 8; s += 256) {
+        const int row = s >> 3, c = s & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
+        *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+    // ---- V^T: [64 d][288 kv]; wave w transposes d = 16w..16w+15, lane <-> key pair ---------------
+#pragma unroll
+    for (int pg = 0; pg < 3; ++pg) {
+        const int p = pg * 64 + lane;
+        if (p < VNC * 16) {
+            const int kv0 = 2 * p, kv1 = kv0 + 1;
+            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
+            if (kv0 < VN) {
+                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + wave * 16;
+                a0 = *(const u32x4*)r0;
+                a1 = *(const u32x4*)(r0 + 8);
+            }
+            if (kv1 < VN) {
+                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + wave * 16;
+                b0 = *(const u32x4*)r1;
+                b1 = *(const u32x4*)(r1 + 8);
+            }
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
+                *(uint32_t*)(sVt + (wave * 16 + dd) * VT_STRIDE + kv0) = w;
+            }
+        }
+    }
+    __syncthreads();
+
+    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
+    for (int qt = wave; qt < VNT; qt += 4) {
+        const int q = qt * 16 + l15;
+        const int qc = min(q, VN - 1);
+        bf16x8 qf[2];
+        qf[0] = *(const bf16x8*)(base + (size_t)qc * VLD + g * 8);
+        qf[1] = *(const bf16x8*)(base + (size_t)qc * VLD + 32 + g * 8);
+
+        f32x4 s[VNT];
+#pragma unroll
+        for (int t = 0; t < VNT; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                acc = mfma16(kf, qf[kk], acc);
+            }
+            s[t] = acc * sc;
+        }
+        // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
+
+        float m = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(s[t][r] - m);
+                s[t][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < VNC; ++c) {
+            u32x4 pk;
+            pk[0] = pack_bf16x2(s[2 * c][0], s[2 * c][1]);
+            pk[1] = pack_bf16x2(s[2 * c][2], s[2 * c][3]);
+            if (2 * c + 1 < VNT) {
+                pk[2] = pack_bf16x2(s[2 * c + 1][0], s[2 * c + 1][1]);
+                pk[3] = pack_bf16x2(s[2 * c + 1][2], s[2 * c + 1][3]);
+            } else {
+                pk[2] = 0u;
+                pk[3] = 0u;
+            }
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 32 * c + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + 16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
+            }
+        }
+        if (q < VN) {
+            const float inv = 1.f / l;
+            uint16_t* op = out + ((size_t)f * VN + q) * 1024 + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+                pk[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+                *(u32x2*)(op + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
+// grid = (ceil(S/64), heads, B); 4 waves x 16 query rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int LK_BYTES = 64 * 256;          // K tile: 64 keys x 128 d, 256-byte rows, chunk ^= row & 15
+constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row stride 144 B = 16*9
+
+__global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
+                                                         const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
+                                                         uint16_t* __restrict__ out, int S, int heads, int past, int ctx_max) {
+    __shared__ __attribute__((aligned(16))) char smem[LK_BYTES + 128 * LVT_STRIDE * 2];
+    char* sK = smem;
+    uint16_t* sVt = (uint16_t*)(smem + LK_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int Hq = heads * 128;
+    const int kv_len = past + S;
+
+    const int q = qb * 64 + wave * 16 + l15;             // query row inside this call
+    const int qc = min(q, S - 1);
+    const int qpos = past + q;                            // absolute position: keys <= qpos are visible
+    const uint16_t* qp = qkv + ((size_t)b * S + qc) * 3 * Hq + h * 128;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 32 + g * 8);
+
+    const uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_len : nullptr;
+
+    const int q_last = min(qb * 64 + 63, S - 1);
+    const int kv_end = min(past + q_last + 1, kv_len);
+    const int ntiles = (kv_end + 63) >> 6;
+
+    const float sc = 0.08838834764831845f * LOG2E;        // 128^-0.5 * log2(e)
+    float m = NEG_BIG, l = 0.f;
+    f32x4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int kv0 = kt * 64;
+        __syncthreads();                                  // previous tile fully consumed
+        // ---- stage K tile (row-major, swizzled) ---------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = i * 256 + tid, row = s >> 4, c = s & 15;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (kv0 + row < kv_len) v = *(const u32x4*)(kbase + (size_t)(kv0 + row) * 128 + c * 8);
+            *(u32x4*)(sK + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+        }
+        // ---- stage V^T tile: thread <-> (key pair p, group of 16 d) -----------------------------
+        {
+            const int p = tid & 31, dg = tid >> 5;
+            const int r0 = kv0 + 2 * p, r1 = r0 + 1;
+            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
+            if (r0 < kv_len) {
+                const uint16_t* x = vbase + (size_t)r0 * 128 + dg * 16;
+                a0 = *(const u32x4*)x;
+                a1 = *(const u32x4*)(x + 8);
+            }
+            if (r1 < kv_len) {
+                const uint16_t* x = vbase + (size_t)r1 * 128 + dg * 16;
+                b0 = *(const u32x4*)x;
+                b1 = *(const u32x4*)(x + 8);
+            }
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
+                *(uint32_t*)(sVt + (dg * 16 + dd) * LVT_STRIDE + 2 * p) = w;
+            }
+        }
+        // key validity of this tile as a 64-bit wave mask (lane <-> key kv0 + lane)
+        const int kvl = kv0 + lane;
+        const bool ok = kvl < kv_len && (!kvld || kvld[kvl] != 0);
+        const unsigned long long vmask = __ballot(ok);
+        __syncthreads();
+
+        // ---- S^T tile ---------------------------------------------------------------------------
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 256 + (((kk * 4 + g) ^ l15) << 4));
+                acc = mfma16(kf, qf[kk], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kl = t * 16 + 4 * g + r;
+                const bool vis = ((vmask >> kl) & 1ull) && (kv0 + kl <= qpos);
+                s[t][r] = vis ? acc[r] * sc : NEG_BIG;
+            }
+        }
+        // ---- online softmax ------------------------------------------------------------------------
+        float rm = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rm = fmaxf(rm, s[t][r]);
+        rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
+        rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
+        const float mn = fmaxf(m, rm);
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(s[t][r] - mn);
+                s[t][r] = p;
+                ps += p;
+            }
+        l = l * alpha + ps;                                // per-lane partial; the 4 g-lanes share alpha
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+        // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 pk;
+            pk[0] = pack_bf16x2(s[2 * c][0], s[2 * c][1]);
+            pk[1] = pack_bf16x2(s[2 * c][2], s[2 * c][3]);
+            pk[2] = pack_bf16x2(s[2 * c + 1][0], s[2 * c + 1][1]);
+            pk[3] = pack_bf16x2(s[2 * c + 1][2], s[2 * c + 1][3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * LVT_STRIDE + 32 * c + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + 16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
+            }
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q < S) {
+        const float inv = 1.f / l;
+        uint16_t* op = out + ((size_t)b * S + q) * Hq + h * 128 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+            pk[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+            *(u32x2*)(op + dt * 16) = pk;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
+    if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
+    hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    return vly_check_launch("vly_vit_attention");
+}
+
+extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const void* vcache, const uint8_t* key_valid,
+                                   void* out, int B, int S, int heads, int past_len, int ctx_max, void* stream) {
+    if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || past_len + S > ctx_max || B > 65535 || heads > 65535 ||
+        ((uintptr_t)qkv & 15) || ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) || ((uintptr_t)out & 7)) {
+        vly_set_error("vly_llama_attention: bad args B=%d S=%d heads=%d past=%d ctx_max=%d", B, S, heads, past_len, ctx_max);
+        return -22;
+    }
+    hipLaunchKernelGGL(llama_attn_kernel, dim3((S + 63) / 64, heads, B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
+                       S, heads, past_len, ctx_max);
+    return vly_check_launch("vly_llama_attention");
+}

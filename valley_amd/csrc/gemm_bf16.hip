@@ -1,0 +1,219 @@
+// bf16 GEMM with fused epilogues for gfx950:  C[M,N] = epi(A[M,K] · W[N,K]^T + bias) + residual.
+//
+// Both operands are K-contiguous (activations row-major, nn.Linear weights as stored), so one
+// staging routine serves both.  Structure (MI355X_MICROARCH / cdna_hip_programming §5):
+//   * tile BM x BN x 64, waves laid out (BM/WM) x (BN/WN), each wave owns WM x WN of C as
+//     (WM/16) x (WN/16) MFMA 16x16x32 fragments held in registers for the whole K loop;
+//   * global -> LDS by `global_load_lds_dwordx4` (no VGPR round trip): the LDS image is
+//     lane-linear [row][8 x 16B], so the bank swizzle chunk ^= (row & 7) is applied to the
+//     per-lane SOURCE address and again on the ds_read_b128 (rule 21: both sides or neither);
+//   * two LDS stages, one barrier per K tile: the loads of tile t+1 are in flight while the
+//     MFMAs of tile t run;
+//   * operands are fed to the MFMA swapped (W fragment as the "A" operand), so every lane ends
+//     up holding 4 consecutive n for one m: bias/residual are float4 loads and C is written as
+//     8-byte (bf16) or 16-byte (fp32) pieces along the row;
+//   * block id -> tile mapping gives each XCD (private 4 MiB L2) a contiguous run of tiles.
+// Algorithmic work: 2*M*N*K flop per launch; HBM traffic floor (M*K + N*K)*2 + M*N*out bytes.
+#include "common.hpp"
+#include "../../include/valley_hip.h"
+
+namespace {
+
+constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 chunks of 16 B
+
+template <int BM, int BN, int WM, int WN, int EPI, int OUT>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+            const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
+            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_n) {
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int NT = NW * 64;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;      // glds passes per tile
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // ---- XCD-aware tile assignment (bijective for any grid size) ---------------------------
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int m0 = (swz / tiles_n) * BM, n0 = (swz % tiles_n) * BN;
+
+    // ---- per-thread staging sources (element offsets; the K offset is added per tile) -------
+    uint32_t offA[PA], offW[PW];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+        const int gr = min(m0 + row, M - 1);
+        offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+        const int gr = min(n0 + row, N - 1);
+        offW[p] = (uint32_t)gr * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sW = sA + A_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+#pragma unroll
+        for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+    };
+
+    // ---- wave position and fragment read offsets --------------------------------------------
+    const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+    // row & 7 == l15 & 7 for every fragment row (all bases are multiples of 16)
+    const int rdA = (wm0 + l15) * 128, rdW = (wn0 + l15) * 128;
+    const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                                  // tile kt landed; buffer (kt+1)&1 is free
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* sA = smem + (kt & 1) * STAGE;
+        const char* sW = sA + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw = kk ? sw1 : sw0;
+            bf16x8 af[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + rdA + i * 2048 + sw);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(sW + rdW + j * 2048 + sw);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g ----------------------
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm0 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn0 + j * 16 + g * 4;
+            if (n >= N) continue;
+            f32x4 v = acc[i][j];
+            if (bias) {
+                const f32x4 b = *(const f32x4*)(bias + n);
+                v += b;
+            }
+            if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+            }
+            if constexpr (EPI == VLY_EPI_SWIGLU) {
+                const float o0 = v[0] / (1.f + __expf(-v[0])) * v[1];
+                const float o1 = v[2] / (1.f + __expf(-v[2])) * v[3];
+                const size_t o = (size_t)m * ldc + (n >> 1);
+                if constexpr (OUT == VLY_OUT_BF16) {
+                    *(uint32_t*)((uint16_t*)Cv + o) = pack_bf16x2(o0, o1);
+                } else {
+                    *(float2*)((float*)Cv + o) = make_float2(o0, o1);
+                }
+            } else {
+                if (R) {
+                    const f32x4 rr = *(const f32x4*)(R + (size_t)m * ldr + n);
+                    v += rr;
+                }
+                const size_t o = (size_t)m * ldc + n;
+                if constexpr (OUT == VLY_OUT_BF16) {
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(v[0], v[1]);
+                    pk[1] = pack_bf16x2(v[2], v[3]);
+                    *(u32x2*)((uint16_t*)Cv + o) = pk;
+                } else {
+                    *(f32x4*)((float*)Cv + o) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_tile(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
+                int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    dim3 grid(tm * tn), block(NT);
+#define VLY_GEMM_LAUNCH(E, O)                                                                         \
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O>), grid, block, 0, st, (const uint16_t*)A,   \
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tn)
+    if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
+    else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    else {
+        vly_set_error("vly_gemm_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
+        return -22;
+    }
+#undef VLY_GEMM_LAUNCH
+    return vly_check_launch("vly_gemm_bf16");
+}
+
+}  // namespace
+
+// Tile choice: 256x256 (8 waves, 1 block/CU) has the best inner-loop efficiency but needs enough
+// tiles to fill 256 CUs; 128x128 (4 waves, 2 blocks/CU) quantises better on small problems.
+static int pick_tile(int M, int N) {
+    auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    // modelled time = waves-of-blocks * per-tile work / relative efficiency
+    auto cost = [&](int bm, int bn, int per_cu, double eff) {
+        const long t = tiles(bm, bn);
+        const long slots = 256L * per_cu;
+        const long rounds = (t + slots - 1) / slots;
+        return (double)rounds * per_cu * bm * bn / eff;
+    };
+    const double c256 = cost(256, 256, 1, 1.0);
+    const double c128 = cost(128, 128, 2, 0.72);
+    const double c2x1 = cost(256, 128, 1, 0.88);
+    if (c256 <= c128 && c256 <= c2x1) return 1;
+    return c2x1 <= c128 ? 3 : 2;
+}
+
+extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C,
+                             int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue,
+                             int out_dtype, int tile_hint, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16: empty problem"); return -22; }
+    if (K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
+        ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) ||
+        (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15))) {
+        vly_set_error("vly_gemm_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",
+                      M, N, K, lda, ldw, ldc, ldr);
+        return -22;
+    }
+    if ((size_t)M * lda >= (1ull << 32) || (size_t)N * ldw >= (1ull << 32)) {
+        vly_set_error("vly_gemm_bf16: operand exceeds 2^32 elements");
+        return -22;
+    }
+    if (epilogue == VLY_EPI_SWIGLU && residual) { vly_set_error("vly_gemm_bf16: SWIGLU takes no residual"); return -22; }
+    hipStream_t st = (hipStream_t)stream;
+    const int t = tile_hint ? tile_hint : pick_tile(M, N);
+    switch (t) {
+        case 1: return launch_tile<256, 256, 128, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        case 2: return launch_tile<128, 128, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        case 3: return launch_tile<256, 128, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
+    }
+}

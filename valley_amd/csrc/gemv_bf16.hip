@@ -1,0 +1,113 @@
+// Weight-streaming GEMV for decode: C[M<=8, N] = epi(A[M,K] · W[N,K]^T + bias) + residual.
+// HBM-bound by construction: every wave owns two consecutive weight rows and streams them once with
+// 16-byte loads (no LDS round trip — the operand is not shared between waves,
+// cdna_hip_programming §5 "GEMV / M <= 16"); the few activation rows stay L1/L2 resident.
+// Algorithmic bytes per launch = N*K*2 (weights) — activations and outputs are negligible.
+#include "common.hpp"
+#include "../../include/valley_hip.h"
+
+namespace {
+
+VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s = fmaf(__uint_as_float(w[i] << 16), __uint_as_float(a[i] << 16), s);
+        s = fmaf(__uint_as_float(w[i] & 0xffff0000u), __uint_as_float(a[i] & 0xffff0000u), s);
+    }
+    return s;
+}
+
+template <int MR, int EPI, int OUT>
+__global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                   const float* __restrict__ bias, const float* __restrict__ R,
+                                                   void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (n0 >= N) return;
+    const uint16_t* w0 = W + (size_t)n0 * ldw;
+    const uint16_t* w1 = W + (size_t)min(n0 + 1, N - 1) * ldw;
+    float acc0[MR], acc1[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+    const int nch = K >> 3;
+#pragma unroll 4
+    for (int c = lane; c < nch; c += 64) {
+        const u32x4 x0 = __builtin_nontemporal_load((const u32x4*)(w0 + 8 * c));
+        const u32x4 x1 = __builtin_nontemporal_load((const u32x4*)(w1 + 8 * c));
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const u32x4 a = *(const u32x4*)(A + (size_t)min(m, M - 1) * lda + 8 * c);
+            acc0[m] += dot8(x0, a);
+            acc1[m] += dot8(x1, a);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
+    if (lane != 0) return;
+    const bool has1 = n0 + 1 < N;
+    const float b0 = bias ? bias[n0] : 0.f, b1 = (bias && has1) ? bias[n0 + 1] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        if (m >= M) break;
+        float v0 = acc0[m] + b0, v1 = acc1[m] + b1;
+        if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+            v0 = v0 / (1.f + __expf(-1.702f * v0));
+            v1 = v1 / (1.f + __expf(-1.702f * v1));
+        }
+        if constexpr (EPI == VLY_EPI_SWIGLU) {
+            const float o = v0 / (1.f + __expf(-v0)) * v1;
+            const size_t off = (size_t)m * ldc + (n0 >> 1);
+            if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f32_to_bf16(o);
+            else ((float*)Cv)[off] = o;
+        } else {
+            if (R) {
+                v0 += R[(size_t)m * ldr + n0];
+                if (has1) v1 += R[(size_t)m * ldr + n0 + 1];
+            }
+            const size_t off = (size_t)m * ldc + n0;
+            if constexpr (OUT == VLY_OUT_BF16) {
+                ((uint16_t*)Cv)[off] = f32_to_bf16(v0);
+                if (has1) ((uint16_t*)Cv)[off + 1] = f32_to_bf16(v1);
+            } else {
+                ((float*)Cv)[off] = v0;
+                if (has1) ((float*)Cv)[off + 1] = v1;
+            }
+        }
+    }
+}
+
+template <int MR>
+int launch_mr(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
+              int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
+    dim3 grid((N + 7) / 8), block(256);
+#define VLY_GEMV(E, O)                                                                                     \
+    hipLaunchKernelGGL((gemv_kernel<MR, E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, \
+                       bias, R, C, M, N, K, lda, ldw, ldc, ldr)
+    if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMV(VLY_EPI_NONE, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMV(VLY_EPI_NONE, VLY_OUT_F32);
+    else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMV(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMV(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    else {
+        vly_set_error("vly_gemv_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
+        return -22;
+    }
+#undef VLY_GEMV
+    return vly_check_launch("vly_gemv_bf16");
+}
+
+}  // namespace
+
+extern "C" int vly_gemv_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C, int M,
+                             int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, void* stream) {
+    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 8 || lda % 8 || ldw % 8 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||
+        (epilogue == VLY_EPI_SWIGLU && (N % 2 || residual))) {
+        vly_set_error("vly_gemv_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d", M, N, K, lda, ldw);
+        return -22;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 1) return launch_mr<1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+    if (M == 2) return launch_mr<2>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+    if (M <= 4) return launch_mr<4>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+    return launch_mr<8>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+}

@@ -1,0 +1,347 @@
+// HBM-bound row kernels of the hot path: LayerNorm / RMSNorm, patch im2col, ViT embedding
+// assembly, temporal pooling, embedding gather + visual splice, RoPE + KV-cache append, argmax.
+// All are one-wave-per-row (or per contiguous run) with 16-byte accesses; the roofline that bounds
+// them is HBM bandwidth, algorithmic bytes = bytes read + bytes written stated per kernel.
+#include "common.hpp"
+#include "../../include/valley_hip.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;           // 4 waves, one row each
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm: fp32 [M,D] -> bf16 (and optionally fp32).  One wave per row, the row is
+// read once into registers (NV float4 per lane), statistics in fp32 (two-pass variance on the
+// register copy, like torch), written as 8-byte bf16x4.  bytes/row = 4D read + 2D (+4D) written.
+// ---------------------------------------------------------------------------------------------
+template <int NV, bool RMS>
+__global__ void __launch_bounds__(256) norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, uint16_t* __restrict__ y16,
+                                                   float* __restrict__ y32, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = (const float4*)(x + (size_t)row * D);
+    const int nvec = D >> 2;                 // float4 per row; lane handles v = lane + 64*i
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        else s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if constexpr (RMS) {
+        rstd = rsqrtf(s / (float)D + eps);
+    } else {
+        mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += a * a + b * b + cc * cc + d * d;
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)D + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= nvec) continue;
+        const float4 gm = ((const float4*)gamma)[c];
+        float4 o;
+        if constexpr (RMS) {
+            // hf: weight * (x * rsqrt(var + eps))
+            o.x = gm.x * (v[i].x * rstd); o.y = gm.y * (v[i].y * rstd);
+            o.z = gm.z * (v[i].z * rstd); o.w = gm.w * (v[i].w * rstd);
+        } else {
+            const float4 bt = ((const float4*)beta)[c];
+            o.x = (v[i].x - mean) * rstd * gm.x + bt.x; o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+            o.z = (v[i].z - mean) * rstd * gm.z + bt.z; o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        }
+        if (y16) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(o.x, o.y);
+            pk[1] = pack_bf16x2(o.z, o.w);
+            *(u32x2*)(y16 + (size_t)row * D + 4 * c) = pk;
+        }
+        if (y32) ((float4*)(y32 + (size_t)row * D))[c] = o;
+    }
+}
+
+template <bool RMS>
+int launch_norm(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int M, int D, float eps,
+                hipStream_t st, const char* name) {
+    if (M <= 0 || D <= 0 || D % 4 || D > 8192 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) ||
+        (beta && ((uintptr_t)beta & 15)) || ((uintptr_t)y16 & 7) || ((uintptr_t)y32 & 15)) {
+        vly_set_error("%s: unsupported shape/alignment M=%d D=%d", name, M, D);
+        return -22;
+    }
+    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+    const int nv = (D / 4 + 63) / 64;
+#define VLY_NORM(NV) hipLaunchKernelGGL((norm_kernel<NV, RMS>), grid, block, 0, st, x, gamma, beta, (uint16_t*)y16, y32, M, D, eps)
+    if (nv <= 4) VLY_NORM(4);
+    else if (nv <= 8) VLY_NORM(8);
+    else if (nv <= 16) VLY_NORM(16);
+    else if (nv <= 20) VLY_NORM(20);
+    else VLY_NORM(32);
+#undef VLY_NORM
+    return vly_check_launch(name);
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col for Conv2d(3->1024, k=14, s=14): images bf16 [F,3,224,224] -> [F*256, 640].
+// One wave per output row (patch): 640 columns = 10 per lane.  Column k = c*196 + ky*14 + kx.
+// bytes/frame = 301,056 read + 327,680 written.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) patchify_kernel(const uint16_t* __restrict__ img, uint16_t* __restrict__ out, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int f = row >> 8, p = row & 255, py = p >> 4, px = p & 15;
+    const uint16_t* base = img + (size_t)f * 3 * 224 * 224 + (size_t)(py * 14) * 224 + px * 14;
+    uint16_t* o = out + (size_t)row * 640;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int k = lane + 64 * i;
+        uint16_t v = 0;
+        if (k < 588) {
+            const int c = k / 196, r = k - c * 196, ky = r / 14, kx = r - ky * 14;
+            v = base[(size_t)c * 224 * 224 + ky * 224 + kx];
+        }
+        o[k] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ViT embedding assembly + pre_layrnorm: row t of frame f = (t == 0 ? cls : patch_out[f*256+t-1], fp32)
+// + pos[t], then LayerNorm -> fp32 residual stream.  One wave per row, D = 1024 (4 float4/lane).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vit_embed_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ h, int rows, float eps) {
+    constexpr int D = 1024;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int f = row / 257, t = row - f * 257;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        float4 e;
+        if (t == 0) {
+            e = ((const float4*)cls)[c];
+        } else {
+            e = ((const float4*)(patch_out + ((size_t)(f * 256 + t - 1)) * D))[c];
+        }
+        const float4 pp = ((const float4*)(pos + (size_t)t * D))[c];
+        e.x += pp.x; e.y += pp.y; e.z += pp.z; e.w += pp.w;
+        v[i] = e;
+        s += e.x + e.y + e.z + e.w;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += a * a + b * b + c * c + d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        const float4 gm = ((const float4*)gamma)[c], bt = ((const float4*)beta)[c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gm.x + bt.x; o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[i].z - mean) * rstd * gm.z + bt.z; o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        ((float4*)(h + (size_t)row * D))[c] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Temporal pooling: feats fp32 [B,T,257,W] -> out bf16 [B,256+T,W].
+// Thread per 4 columns of one output row; rows < 256 reduce over T, rows >= 256 copy a CLS row.
+// bytes/clip = 4*T*257*W read + 2*(256+T)*W written.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pool_kernel(const float* __restrict__ feats, uint16_t* __restrict__ out, int B, int T, int W, int mode) {
+    const int wv = W >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * (256 + T) * wv;
+    if (idx >= total) return;
+    const int c = (int)(idx % wv);
+    const long rr = idx / wv;
+    const int r = (int)(rr % (256 + T)), b = (int)(rr / (256 + T));
+    const float* fb = feats + (size_t)b * T * 257 * W;
+    float4 o;
+    if (r < 256) {
+        o = ((const float4*)(fb + (size_t)(1 + r) * W))[c];
+        for (int t = 1; t < T; ++t) {
+            const float4 a = ((const float4*)(fb + ((size_t)t * 257 + 1 + r) * W))[c];
+            if (mode == VLY_POOL_MAX) { o.x = fmaxf(o.x, a.x); o.y = fmaxf(o.y, a.y); o.z = fmaxf(o.z, a.z); o.w = fmaxf(o.w, a.w); }
+            else { o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+        }
+        if (mode == VLY_POOL_MEAN) { const float inv = 1.f / (float)T; o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv; }
+    } else {
+        o = ((const float4*)(fb + (size_t)(r - 256) * 257 * W))[c];
+    }
+    u32x2 pk;
+    pk[0] = pack_bf16x2(o.x, o.y);
+    pk[1] = pack_bf16x2(o.z, o.w);
+    *(u32x2*)(out + ((size_t)b * (256 + T) + r) * W + 4 * c) = pk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding gather + visual splice: out[r,:] = (map[r] >= 0 ? embed[map[r]] : visual[-map[r]-1]).
+// One wave per row, 16-byte bf16x8 reads, fp32 writes.  bytes/row = 2H read + 4H written.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) embed_splice_kernel(const int32_t* __restrict__ map, const uint16_t* __restrict__ embed,
+                                                           const uint16_t* __restrict__ visual, float* __restrict__ out, int R, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int v = map[row];
+    const uint16_t* src = v >= 0 ? embed + (size_t)v * H : visual + (size_t)(-v - 1) * H;
+    float* o = out + (size_t)row * H;
+    for (int c = lane; c < (H >> 3); c += 64) {
+        const u32x4 pk = *(const u32x4*)(src + 8 * c);
+        float4 a, b;
+        a.x = __uint_as_float(pk[0] << 16); a.y = __uint_as_float(pk[0] & 0xffff0000u);
+        a.z = __uint_as_float(pk[1] << 16); a.w = __uint_as_float(pk[1] & 0xffff0000u);
+        b.x = __uint_as_float(pk[2] << 16); b.y = __uint_as_float(pk[2] & 0xffff0000u);
+        b.z = __uint_as_float(pk[3] << 16); b.w = __uint_as_float(pk[3] & 0xffff0000u);
+        ((float4*)o)[2 * c] = a;
+        ((float4*)o)[2 * c + 1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE (rotate-half) on q,k + KV-cache append.  One wave per (row, head): lane i handles the
+// pair (d = i, d = i + 64) of head_dim 128.  cos/sin come from fp32 tables [ctx_max, 64] the host
+// builds exactly as hf does (inv_freq = theta^(-2i/128), angle = pos * inv_freq, fp32).
+// q' = q*cos + rot(q)*sin with rot(q)[d<64] = -q[d+64], rot(q)[d>=64] = q[d-64].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                      int B, int S, int heads, int past, int ctx_max) {
+    const int lane = threadIdx.x & 63;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (b*S + s)*heads + h
+    if (unit >= (long)B * S * heads) return;
+    const int h = (int)(unit % heads);
+    const long rs = unit / heads;
+    const int s = (int)(rs % S), b = (int)(rs / S);
+    const int Hq = heads * 128;
+    const int pos = past + s;
+    const float cs = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
+    uint16_t* q = qkv + (size_t)rs * 3 * Hq + h * 128;
+    uint16_t* k = q + Hq;
+    const uint16_t* v = q + 2 * Hq;
+    const float q1 = bf16_to_f32(q[lane]), q2 = bf16_to_f32(q[lane + 64]);
+    q[lane] = f32_to_bf16(q1 * cs - q2 * sn);
+    q[lane + 64] = f32_to_bf16(q2 * cs + q1 * sn);
+    const float k1 = bf16_to_f32(k[lane]), k2 = bf16_to_f32(k[lane + 64]);
+    const size_t co = (((size_t)b * heads + h) * ctx_max + pos) * 128;
+    kc[co + lane] = f32_to_bf16(k1 * cs - k2 * sn);
+    kc[co + lane + 64] = f32_to_bf16(k2 * cs + k1 * sn);
+    vc[co + lane] = v[lane];
+    vc[co + lane + 64] = v[lane + 64];
+}
+
+// argmax over rows of fp32 [M,N]; first maximal index (torch.argmax tie rule on CPU).
+__global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const float* r = x + (size_t)blockIdx.x * N;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = r[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        idx[blockIdx.x] = bi;
+    }
+}
+
+}  // namespace
+
+extern "C" int vly_layernorm(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                             int M, int D, float eps, void* stream) {
+    if (!beta) { vly_set_error("vly_layernorm: beta is required"); return -22; }
+    return launch_norm<false>(x, gamma, beta, y_bf16, y_f32, M, D, eps, (hipStream_t)stream, "vly_layernorm");
+}
+
+extern "C" int vly_rmsnorm(const float* x, const float* gamma, void* y_bf16, int M, int D, float eps, void* stream) {
+    return launch_norm<true>(x, gamma, nullptr, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_rmsnorm");
+}
+
+extern "C" int vly_patchify(const void* images, void* patches, int F, void* stream) {
+    if (F <= 0) { vly_set_error("vly_patchify: F=%d", F); return -22; }
+    const int rows = F * 256;
+    hipLaunchKernelGGL(patchify_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)images,
+                       (uint16_t*)patches, rows);
+    return vly_check_launch("vly_patchify");
+}
+
+extern "C" int vly_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                                const float* beta, float* h, int F, float eps, void* stream) {
+    if (F <= 0) { vly_set_error("vly_vit_embed_ln: F=%d", F); return -22; }
+    const int rows = F * 257;
+    hipLaunchKernelGGL(vit_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       patch_out, cls, pos, gamma, beta, h, rows, eps);
+    return vly_check_launch("vly_vit_embed_ln");
+}
+
+extern "C" int vly_pool_tokens(const float* feats, void* out, int B, int T, int W, int mode, void* stream) {
+    if (B <= 0 || T <= 0 || W <= 0 || W % 4 || (mode != VLY_POOL_MEAN && mode != VLY_POOL_MAX)) {
+        vly_set_error("vly_pool_tokens: bad args B=%d T=%d W=%d mode=%d", B, T, W, mode);
+        return -22;
+    }
+    const long total = (long)B * (256 + T) * (W / 4);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feats,
+                       (uint16_t*)out, B, T, W, mode);
+    return vly_check_launch("vly_pool_tokens");
+}
+
+extern "C" int vly_embed_splice(const int32_t* row_map, const void* embed, const void* visual, float* out, int R, int H,
+                                void* stream) {
+    if (R <= 0 || H <= 0 || H % 8) { vly_set_error("vly_embed_splice: bad args R=%d H=%d", R, H); return -22; }
+    hipLaunchKernelGGL(embed_splice_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, row_map,
+                       (const uint16_t*)embed, (const uint16_t*)visual, out, R, H);
+    return vly_check_launch("vly_embed_splice");
+}
+
+extern "C" int vly_rope_kv(void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
+                           int B, int S, int heads, int past_len, int ctx_max, void* stream) {
+    if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || past_len + S > ctx_max) {
+        vly_set_error("vly_rope_kv: bad args B=%d S=%d heads=%d past=%d ctx_max=%d", B, S, heads, past_len, ctx_max);
+        return -22;
+    }
+    const long units = (long)B * S * heads;
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
+                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, B, S, heads, past_len, ctx_max);
+    return vly_check_launch("vly_rope_kv");
+}
+
+extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, void* stream) {
+    if (M <= 0 || N <= 0) { vly_set_error("vly_argmax: bad args"); return -22; }
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, idx, N);
+    return vly_check_launch("vly_argmax");
+}

@@ -1,0 +1,71 @@
+"""ctypes binding of libvalley_hip.so (include/valley_hip.h).
+
+This is the ONLY compute backend of the package: if the library is missing or does not export the
+expected ABI the import fails loudly — there is no PyTorch / CPU fallback path."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_void_p
+
+from . import build as _build
+
+_LIB = None
+
+_P = c_void_p
+_SIGS = {
+    "vly_abi_version": (c_int, []),
+    "vly_last_error": (c_char_p, []),
+    "vly_gemm_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_layernorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "vly_rmsnorm": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
+    "vly_patchify": (c_int, [_P, _P, c_int, _P]),
+    "vly_vit_embed_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_float, _P]),
+    "vly_vit_attention": (c_int, [_P, _P, c_int, _P]),
+    "vly_pool_tokens": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vly_embed_splice": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "vly_rope_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_llama_attention": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_argmax": (c_int, [_P, _P, c_int, c_int, _P]),
+}
+EXPORTS = tuple(_SIGS)
+ABI_VERSION = 1
+
+
+class ValleyHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("VALLEY_HIP_LIB", _build.LIB)
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it is absent or stale."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ValleyHipError(
+            f"{path} not found: build it with `python -m valley_amd.build` (hipcc --offload-arch=gfx950). "
+            "valley_amd has no non-HIP compute path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ValleyHipError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vly_abi_version() != ABI_VERSION:
+        raise ValleyHipError(f"ABI mismatch: library {lib.vly_abi_version()} vs binding {ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().vly_last_error().decode(errors="replace")
+        raise ValleyHipError(f"{what} failed (rc={rc}): {msg}")

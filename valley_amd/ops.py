@@ -1,0 +1,187 @@
+"""Thin typed wrappers: torch device tensors -> raw pointers + the current HIP stream -> C ABI.
+
+PyTorch is plumbing here (allocator, stream, tensor views); all arithmetic happens in
+libvalley_hip.so.  Every wrapper validates dtype/device/contiguity and raises on the library's
+error codes."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+EPI_NONE, EPI_QUICK_GELU, EPI_SWIGLU = 0, 1, 2
+OUT_BF16, OUT_F32 = 0, 1
+POOL_MEAN, POOL_MAX = 0, 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
+    if not t.is_cuda:
+        raise _lib.ValleyHipError(f"{name}: expected a device tensor (valley_amd has no CPU compute path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+
+
+def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra):
+    _chk(a, torch.bfloat16, "a", contiguous=False)
+    _chk(w, torch.bfloat16, "w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    M, K = a.shape
+    N = w.shape[0]
+    No = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, No), dtype=out_dtype, device=a.device)
+    else:
+        assert tuple(out.shape) == (M, No) and out.stride(1) == 1, (out.shape, (M, No))
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    if residual is not None:
+        _chk(residual, torch.float32, "residual", contiguous=False)
+        assert tuple(residual.shape) == (M, N) and residual.stride(1) == 1
+    od = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    fn = getattr(_lib.load(), fn_name)
+    rc = fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
+            out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
+    _lib.check(rc, fn_name)
+    return out
+
+
+def gemm_mfma(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
+    """MFMA tile kernel: out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual."""
+    return _gemm_common("vly_gemm_bf16", a, w, bias, residual, epilogue, out_dtype, out, (tile_hint,))
+
+
+def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None):
+    """Weight-streaming kernel for M <= 8 rows (decode)."""
+    return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
+
+
+def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
+    """Dispatch on M: <= 8 rows stream the weights (HBM-bound), otherwise MFMA tiles."""
+    if a.shape[0] <= 8:
+        return gemv(a, w, bias, residual, epilogue, out_dtype, out)
+    return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_f32: bool = False,
+              out: Optional[torch.Tensor] = None):
+    _chk(x, torch.float32, "x")
+    M, D = x.shape
+    y16 = out if out is not None else torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    y32 = torch.empty_like(x) if want_f32 else None
+    rc = _lib.load().vly_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y16.data_ptr(), _ptr(y32), M, D, eps,
+                                   _stream())
+    _lib.check(rc, "vly_layernorm")
+    return (y16, y32) if want_f32 else y16
+
+
+def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    M, D = x.shape
+    y = out if out is not None else torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    rc = _lib.load().vly_rmsnorm(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), M, D, eps, _stream())
+    _lib.check(rc, "vly_rmsnorm")
+    return y
+
+
+def patchify(images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[F,3,224,224] bf16 -> [F*256, 640] bf16."""
+    _chk(images, torch.bfloat16, "images")
+    F = images.shape[0]
+    assert tuple(images.shape[1:]) == (3, 224, 224), images.shape
+    if out is None:
+        out = torch.empty((F * 256, 640), dtype=torch.bfloat16, device=images.device)
+    rc = _lib.load().vly_patchify(images.data_ptr(), out.data_ptr(), F, _stream())
+    _lib.check(rc, "vly_patchify")
+    return out
+
+
+def vit_embed_ln(patch_out: torch.Tensor, cls, pos, gamma, beta, F: int, eps: float, out=None) -> torch.Tensor:
+    _chk(patch_out, torch.float32, "patch_out")
+    if out is None:
+        out = torch.empty((F * 257, 1024), dtype=torch.float32, device=patch_out.device)
+    rc = _lib.load().vly_vit_embed_ln(patch_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), gamma.data_ptr(),
+                                      beta.data_ptr(), out.data_ptr(), F, eps, _stream())
+    _lib.check(rc, "vly_vit_embed_ln")
+    return out
+
+
+def vit_attention(qkv: torch.Tensor, F: int, out=None) -> torch.Tensor:
+    _chk(qkv, torch.bfloat16, "qkv")
+    assert tuple(qkv.shape) == (F * 257, 3072), qkv.shape
+    if out is None:
+        out = torch.empty((F * 257, 1024), dtype=torch.bfloat16, device=qkv.device)
+    rc = _lib.load().vly_vit_attention(qkv.data_ptr(), out.data_ptr(), F, _stream())
+    _lib.check(rc, "vly_vit_attention")
+    return out
+
+
+def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN) -> torch.Tensor:
+    """feats fp32 [B*T*257, W] -> bf16 [B, 256+T, W]."""
+    _chk(feats, torch.float32, "feats")
+    W = feats.shape[-1]
+    assert feats.numel() == B * T * 257 * W
+    out = torch.empty((B, 256 + T, W), dtype=torch.bfloat16, device=feats.device)
+    rc = _lib.load().vly_pool_tokens(feats.data_ptr(), out.data_ptr(), B, T, W, mode, _stream())
+    _lib.check(rc, "vly_pool_tokens")
+    return out
+
+
+def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[torch.Tensor]) -> torch.Tensor:
+    _chk(row_map, torch.int32, "row_map")
+    _chk(embed, torch.bfloat16, "embed")
+    R, H = row_map.numel(), embed.shape[1]
+    if visual is not None:
+        _chk(visual, torch.bfloat16, "visual")
+    out = torch.empty((R, H), dtype=torch.float32, device=embed.device)
+    rc = _lib.load().vly_embed_splice(row_map.data_ptr(), embed.data_ptr(), _ptr(visual), out.data_ptr(), R, H, _stream())
+    _lib.check(rc, "vly_embed_splice")
+    return out
+
+
+def rope_kv(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+            B: int, S: int, heads: int, past_len: int):
+    _chk(qkv, torch.bfloat16, "qkv")
+    _chk(kcache, torch.bfloat16, "kcache")
+    _chk(vcache, torch.bfloat16, "vcache")
+    ctx_max = kcache.shape[2]
+    assert tuple(kcache.shape) == (B, heads, ctx_max, 128) and vcache.shape == kcache.shape
+    assert cos.shape[0] >= past_len + S and cos.shape[1] == 64 and cos.dtype == torch.float32 and cos.is_contiguous()
+    rc = _lib.load().vly_rope_kv(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                 B, S, heads, past_len, ctx_max, _stream())
+    _lib.check(rc, "vly_rope_kv")
+
+
+def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, key_valid: Optional[torch.Tensor],
+                    B: int, S: int, heads: int, past_len: int, out=None) -> torch.Tensor:
+    _chk(qkv, torch.bfloat16, "qkv")
+    ctx_max = kcache.shape[2]
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        assert tuple(key_valid.shape) == (B, past_len + S)
+    if out is None:
+        out = torch.empty((B * S, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+    rc = _lib.load().vly_llama_attention(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), _ptr(key_valid),
+                                         out.data_ptr(), B, S, heads, past_len, ctx_max, _stream())
+    _lib.check(rc, "vly_llama_attention")
+    return out
+
+
+def argmax(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    M, N = x.shape
+    out = torch.empty((M,), dtype=torch.int32, device=x.device)
+    rc = _lib.load().vly_argmax(x.data_ptr(), out.data_ptr(), M, N, _stream())
+    _lib.check(rc, "vly_argmax")
+    return out
