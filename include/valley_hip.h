@@ -120,6 +120,11 @@ int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, void *stream);
 
+/* fp32 -> bf16 (round-to-nearest-even) over n contiguous elements, n % 8 == 0: the `.to(dtype)`
+ *   between an fp32 tensor and a GEMM input (only used on the `max`-pooling path, where the
+ *   projector has to see every token, valley_model.py:190,209). */
+int vly_cast_f32_bf16(const float *x, void *y_bf16, long n, void *stream);
+
 /* argmax over the last dim of fp32 [M,N] -> int32 [M].  serve/model_worker.py:389-391. */
 int vly_argmax(const float *x, int32_t *idx, int M, int N, void *stream);
 

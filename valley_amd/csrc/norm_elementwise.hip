@@ -254,6 +254,17 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv
     vc[co + lane + 64] = v[lane + 64];
 }
 
+// fp32 -> bf16 cast (round to nearest even), 8 elements per thread.
+__global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+    u32x4 pk;
+    pk[0] = pack_bf16x2(a.x, a.y); pk[1] = pack_bf16x2(a.z, a.w);
+    pk[2] = pack_bf16x2(b.x, b.y); pk[3] = pack_bf16x2(b.z, b.w);
+    ((u32x4*)y)[i] = pk;
+}
+
 // argmax over rows of fp32 [M,N]; first maximal index (torch.argmax tie rule on CPU).
 __global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N) {
     __shared__ float sv[4];
@@ -344,4 +355,11 @@ extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, void* stre
     if (M <= 0 || N <= 0) { vly_set_error("vly_argmax: bad args"); return -22; }
     hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, idx, N);
     return vly_check_launch("vly_argmax");
+}
+
+extern "C" int vly_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
+    if (n <= 0 || n % 8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) { vly_set_error("vly_cast_f32_bf16: bad args n=%ld", n); return -22; }
+    const long n8 = n / 8;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, n8);
+    return vly_check_launch("vly_cast_f32_bf16");
 }

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
 from . import build as _build
 
@@ -28,6 +28,7 @@ _SIGS = {
     "vly_llama_attention": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
 }
 EXPORTS = tuple(_SIGS)
 ABI_VERSION = 1

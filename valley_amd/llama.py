@@ -1,0 +1,167 @@
+"""Llama decoder (prefill + KV-cache decode) on the HIP kernels.
+
+Replaces HF ``LlamaModel.forward`` as called by ``ValleyLlamaModel.forward``
+(valley/model/valley_model.py:249-254 -> hf:llama/modeling_llama.py:347-417) and the ``lm_head``
+(valley_model.py:264,304-305).  Per layer: RMSNorm -> fused q|k|v GEMM -> RoPE + KV append ->
+causal attention -> o_proj GEMM (+residual) -> RMSNorm -> fused gate/up GEMM with SwiGLU epilogue
+-> down_proj GEMM (+residual).  MHA only (7B/13B have no GQA), head_dim 128.
+
+HBM layout: residual stream fp32 [B*S, H]; weights bf16, q/k/v concatenated to [3H, H], gate/up
+row-interleaved to [2I, H] so that the SwiGLU pair sits in one lane; KV cache bf16
+[B, heads, ctx_max, 128] per layer (the legacy HF tuple layout, so ``past[l][0]`` is a plain view).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _dev(t, device, dtype):
+    if not isinstance(t, torch.Tensor):
+        t = torch.from_numpy(np.ascontiguousarray(t))
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+class HipKVCache:
+    """Pre-allocated KV cache.  Supports the legacy indexing the serving loop uses
+    (``past_key_values[0][0].shape[-2]``, serve/model_worker.py:381) and ``get_seq_length()``."""
+
+    def __init__(self, layers: int, batch: int, heads: int, ctx_max: int, device):
+        self.k = [torch.zeros((batch, heads, ctx_max, 128), dtype=torch.bfloat16, device=device) for _ in range(layers)]
+        self.v = [torch.zeros((batch, heads, ctx_max, 128), dtype=torch.bfloat16, device=device) for _ in range(layers)]
+        self.seq_len = 0
+        self.ctx_max = ctx_max
+        self.batch = batch
+        self.key_valid: Optional[torch.Tensor] = None      # uint8 [B, ctx_max] when a padding mask was given
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.seq_len
+
+    def __len__(self):
+        return len(self.k)
+
+    def __bool__(self):                                      # an allocated cache is "truthy" only once filled
+        return self.seq_len > 0
+
+    def __getitem__(self, layer: int):
+        return (self.k[layer][:, :, :self.seq_len], self.v[layer][:, :, :self.seq_len])
+
+    def __iter__(self):
+        for i in range(len(self.k)):
+            yield self[i]
+
+
+class HipLlama:
+    def __init__(self, hidden: int, heads: int, intermediate: int, layers: int, vocab: int, eps: float,
+                 rope_theta: float = 10000.0, max_positions: int = 2048, device="cuda:0"):
+        if hidden != heads * 128:
+            raise ValueError("HIP Llama path requires head_dim == 128 (hidden = heads*128)")
+        if hidden % 64 or intermediate % 64:
+            raise ValueError("hidden and intermediate sizes must be multiples of 64")
+        self.H, self.heads, self.I, self.L, self.V, self.eps = hidden, heads, intermediate, layers, vocab, eps
+        self.Vpad = (vocab + 7) // 8 * 8
+        self.device = torch.device(device)
+        self.max_positions = max_positions
+        # hf:llama/modeling_llama.py:95-124 : inv_freq = theta^(-2i/d), angle = pos * inv_freq, fp32
+        inv = 1.0 / (rope_theta ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+        ang = torch.arange(max_positions, dtype=torch.float32)[:, None] * inv[None]
+        self.cos, self.sin = ang.cos().contiguous().to(self.device), ang.sin().contiguous().to(self.device)
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        self.loaded = False
+        self._ws = {}
+
+    # ---- weights -------------------------------------------------------------------------------
+    @staticmethod
+    def _interleave(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+        I, H = gate.shape
+        return torch.stack([gate, up], dim=1).reshape(2 * I, H).contiguous()
+
+    def load_state_dict(self, sd: Dict) -> "HipLlama":
+        """Reference key names (SURVEY.md §5 weight-loading contract)."""
+        d, bf, f32 = self.device, torch.bfloat16, torch.float32
+        self.embed = _dev(sd["model.embed_tokens.weight"], d, bf)
+        self.layers = []
+        for i in range(self.L):
+            p = f"model.layers.{i}."
+            L = {}
+            L["ln1"] = _dev(sd[p + "input_layernorm.weight"], d, f32)
+            L["ln2"] = _dev(sd[p + "post_attention_layernorm.weight"], d, f32)
+            L["w_qkv"] = torch.cat([_dev(sd[p + f"self_attn.{n}_proj.weight"], d, bf) for n in "qkv"], 0).contiguous()
+            L["w_o"] = _dev(sd[p + "self_attn.o_proj.weight"], d, bf)
+            L["w_gu"] = self._interleave(_dev(sd[p + "mlp.gate_proj.weight"], d, bf), _dev(sd[p + "mlp.up_proj.weight"], d, bf))
+            L["w_down"] = _dev(sd[p + "mlp.down_proj.weight"], d, bf)
+            self.layers.append(L)
+        self.norm = _dev(sd["model.norm.weight"], d, f32)
+        self.lm_head = torch.zeros((self.Vpad, self.H), dtype=bf, device=d)
+        self.lm_head[:self.V] = _dev(sd["lm_head.weight"], d, bf)
+        self.loaded = True
+        return self
+
+    def init_random(self, seed: int = 0, std: float = 0.02) -> "HipLlama":
+        d, bf, f32 = self.device, torch.bfloat16, torch.float32
+        g = torch.Generator(device=d).manual_seed(seed)
+        rn = lambda shape: (torch.randn(shape, generator=g, device=d, dtype=f32) * std).to(bf)  # noqa: E731
+        self.embed = rn((self.V, self.H))
+        self.layers = []
+        for _ in range(self.L):
+            self.layers.append(dict(ln1=torch.ones(self.H, device=d), ln2=torch.ones(self.H, device=d),
+                                    w_qkv=rn((3 * self.H, self.H)), w_o=rn((self.H, self.H)),
+                                    w_gu=rn((2 * self.I, self.H)), w_down=rn((self.H, self.I))))
+        self.norm = torch.ones(self.H, device=d)
+        self.lm_head = torch.zeros((self.Vpad, self.H), dtype=bf, device=d)
+        self.lm_head[:self.V] = rn((self.V, self.H))
+        self.loaded = True
+        return self
+
+    # ---- compute ---------------------------------------------------------------------------------
+    def new_cache(self, batch: int, ctx_max: Optional[int] = None) -> HipKVCache:
+        return HipKVCache(self.L, batch, self.heads, ctx_max or self.max_positions, self.device)
+
+    def _workspace(self, M: int):
+        ws = self._ws.get(M)
+        if ws is None:
+            d, bf = self.device, torch.bfloat16
+            ws = dict(x=torch.empty((M, self.H), dtype=bf, device=d), qkv=torch.empty((M, 3 * self.H), dtype=bf, device=d),
+                      att=torch.empty((M, self.H), dtype=bf, device=d), mlp=torch.empty((M, self.I), dtype=bf, device=d))
+            if len(self._ws) > 6:
+                self._ws.clear()
+            self._ws[M] = ws
+        return ws
+
+    def forward(self, h: torch.Tensor, B: int, S: int, cache: HipKVCache, n_layers: Optional[int] = None) -> torch.Tensor:
+        """h fp32 [B*S, H] (modified in place) -> final-norm hidden bf16 [B*S, H].  Appends S
+        positions to ``cache``; key validity comes from cache.key_valid."""
+        if not self.loaded:
+            raise RuntimeError("Llama engine has no weights")
+        past = cache.seq_len
+        if past + S > cache.ctx_max:
+            raise ValueError(f"KV cache overflow: {past}+{S} > {cache.ctx_max}")
+        if cache.batch != B:
+            raise ValueError("cache batch mismatch")
+        M = B * S
+        ws = self._workspace(M)
+        kv = None
+        if cache.key_valid is not None:
+            kv = cache.key_valid[:, :past + S].contiguous()
+        nl = self.L if n_layers is None else n_layers
+        for li in range(nl):
+            L = self.layers[li]
+            ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
+            ops.gemm(ws["x"], L["w_qkv"], out=ws["qkv"])
+            ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
+            ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
+            ops.gemm(ws["att"], L["w_o"], residual=h, out=h)
+            ops.rmsnorm(h, L["ln2"], self.eps, out=ws["x"])
+            ops.gemm(ws["x"], L["w_gu"], epilogue=ops.EPI_SWIGLU, out=ws["mlp"])
+            ops.gemm(ws["mlp"], L["w_down"], residual=h, out=h)
+        cache.seq_len = past + S
+        return ops.rmsnorm(h, self.norm, self.eps, out=ws["x"])
+
+    def logits(self, x: torch.Tensor) -> torch.Tensor:
+        """x bf16 [M,H] -> fp32 [M,V] (a view of the V-padded GEMM output)."""
+        out = ops.gemm(x, self.lm_head, out_dtype=torch.float32)
+        return out[:, :self.V]

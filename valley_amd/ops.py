@@ -185,3 +185,11 @@ def argmax(x: torch.Tensor) -> torch.Tensor:
     rc = _lib.load().vly_argmax(x.data_ptr(), out.data_ptr(), M, N, _stream())
     _lib.check(rc, "vly_argmax")
     return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    rc = _lib.load().vly_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    _lib.check(rc, "vly_cast_f32_bf16")
+    return y

@@ -1,0 +1,465 @@
+"""Drop-in for ``valley/model/valley_model.py`` (reference lines cited per symbol) on MI355X.
+
+Same names, argument meaning and error behaviour as the reference classes; the arithmetic runs in
+libvalley_hip.so through ``valley_amd.ops``.  Differences that are deliberate and documented in
+DESIGN.md:
+
+* all frames of all clips are encoded in one batch instead of the per-clip loop (:179-184);
+* mean pooling happens BEFORE the projector (mean is linear: mean_T(Wx+b) = W mean_T(x) + b), which
+  cuts the projector GEMM from B*T*257 to B*(256+T) rows; ``max`` pooling keeps the reference
+  order (project all tokens, then max) because max does not commute;
+* the dummy ``zeros(256,1024)`` projection (:192-193) and the ``0 * dummy.sum()`` add (:200) are
+  numeric no-ops and are not executed;
+* logits are returned in fp32 (the reference returns the model dtype).
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .llama import HipKVCache, HipLlama
+from .splice import build_row_map
+from .vision_tower import HipCLIPVisionTower, VisionConfig
+
+try:                                                     # plumbing only: config + output containers
+    from transformers import LlamaConfig
+    from transformers.modeling_outputs import BaseModelOutputWithPast, CausalLMOutputWithPast
+except Exception:                                        # pragma: no cover - transformers is in the image
+    LlamaConfig = None
+
+    class CausalLMOutputWithPast(SimpleNamespace):
+        pass
+
+    class BaseModelOutputWithPast(SimpleNamespace):
+        pass
+
+# valley/util/config.py:1-13
+IGNORE_INDEX = -100
+DEFAULT_PAD_TOKEN = "[PAD]"
+DEFAULT_EOS_TOKEN = "</s>"
+DEFAULT_BOS_TOKEN = "</s>"
+DEFAULT_UNK_TOKEN = "<unk>"
+DEFAULT_IMAGE_TOKEN = "<image>"
+DEFAULT_IMAGE_PATCH_TOKEN = "<im_patch>"
+DEFAULT_IM_START_TOKEN = "<im_start>"
+DEFAULT_IM_END_TOKEN = "<im_end>"
+DEFAULT_VIDEO_TOKEN = "<video>"
+DEFAULT_VIDEO_FRAME_TOKEN = "<vi_frame>"
+DEFAULT_VI_START_TOKEN = "<vi_start>"
+DEFAULT_VI_END_TOKEN = "<vi_end>"
+
+if LlamaConfig is not None:
+    class ValleyConfig(LlamaConfig):                     # valley_model.py:18-19
+        model_type = "valley"
+else:                                                    # pragma: no cover
+    class ValleyConfig(SimpleNamespace):
+        model_type = "valley"
+
+
+def build_vision_tower(config_or_name=None, device="cuda:0", state_dict: Optional[Dict] = None, **kw) -> HipCLIPVisionTower:
+    """Factory named by the north star (absent in the reference snapshot).  Accepts a
+    ``VisionConfig``/HF ``CLIPVisionConfig``-like object, a dict, or a checkpoint directory holding
+    ``config.json`` + safetensors/bin weights (the role of ``CLIPVisionModel.from_pretrained`` at
+    valley_model.py:38,66)."""
+    cfg = VisionConfig(**kw)
+    if isinstance(config_or_name, dict):
+        cfg = VisionConfig(**{**config_or_name, **kw})
+    elif isinstance(config_or_name, str):
+        from .checkpoint import load_clip_checkpoint
+        cfg, state_dict = load_clip_checkpoint(config_or_name)
+    elif config_or_name is not None:
+        fields = ("hidden_size", "num_attention_heads", "intermediate_size", "num_hidden_layers", "image_size",
+                  "patch_size", "layer_norm_eps", "hidden_act")
+        cfg = VisionConfig(**{f: getattr(config_or_name, f) for f in fields if hasattr(config_or_name, f)})
+    tower = HipCLIPVisionTower(cfg, device=device)
+    if state_dict is not None:
+        tower.load_state_dict(state_dict)
+    return tower
+
+
+class HipLinear:
+    """nn.Linear stand-in exposing ``weight`` / ``bias`` (mm_projector, valley_model.py:54-55)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        self.weight, self.bias = weight, bias
+        self.in_features, self.out_features = weight.shape[1], weight.shape[0]
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        shp = x.shape
+        y = ops.gemm(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous(), self.weight, self.bias)
+        return y.view(*shp[:-1], self.out_features)
+
+
+class ValleyLlamaModel:
+    """valley_model.py:21-254."""
+    config_class = ValleyConfig
+
+    def __init__(self, config, device="cuda:0"):
+        self.config = config
+        self.device = torch.device(device)
+        self.training = False
+        self.patch_pooling_method = "mean"                   # :27
+        c = config
+        self.llama = HipLlama(c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers,
+                              c.vocab_size, c.rms_norm_eps, getattr(c, "rope_theta", None) or _rope_theta(c),
+                              getattr(c, "max_position_embeddings", 2048), device=self.device)
+        self.vision_tower: Optional[HipCLIPVisionTower] = None
+        self.mm_projector: Optional[HipLinear] = None
+        if getattr(config, "mm_vision_tower", None):         # :29-38
+            self.vision_tower = build_vision_tower(config.mm_vision_tower, device=self.device)
+        if getattr(config, "use_patch_importance_pooling", False):   # :40-43
+            self.patch_pooling_method = "temporal_importance"
+        if getattr(config, "use_delta_transformer", False):  # :45-52
+            self.patch_pooling_method = "temporal_transformer"
+
+    @property
+    def embed_tokens(self):
+        return SimpleNamespace(weight=self.llama.embed)
+
+    def initialize_vision_modules(self, vision_tower, mm_vision_select_layer, pretrain_mm_mlp_adapter=None,
+                                  use_patch_importance_pooling=False, use_delta_transformer=False):
+        """valley_model.py:59-103."""
+        self.config.mm_vision_tower = vision_tower
+        if self.vision_tower is None:
+            self.vision_tower = vision_tower if isinstance(vision_tower, HipCLIPVisionTower) \
+                else build_vision_tower(vision_tower, device=self.device)
+        vc = self.vision_tower.config
+        num_patches = (vc.image_size // vc.patch_size) ** 2
+        self.config.use_mm_proj = True
+        self.config.use_patch_importance_pooling = use_patch_importance_pooling
+        self.config.use_delta_transformer = use_delta_transformer
+        self.config.mm_hidden_size = vc.hidden_size
+        self.config.mm_vision_select_layer = mm_vision_select_layer
+        if use_patch_importance_pooling:
+            self.patch_pooling_method = "temporal_importance"
+        if use_delta_transformer:
+            self.patch_pooling_method = "temporal_transformer"
+        if self.mm_projector is None:
+            g = torch.Generator(device=self.device).manual_seed(0)
+            w = torch.randn((self.config.hidden_size, vc.hidden_size), generator=g, device=self.device) * vc.hidden_size ** -0.5
+            self.mm_projector = HipLinear(w.to(torch.bfloat16), torch.zeros(self.config.hidden_size, device=self.device))
+        if pretrain_mm_mlp_adapter is not None:
+            sd = torch.load(pretrain_mm_mlp_adapter, map_location="cpu")
+            sd = {k.split(".")[-1]: v for k, v in sd.items()}
+            self.mm_projector = HipLinear(sd["weight"].to(self.device, torch.bfloat16).contiguous(),
+                                          sd["bias"].to(self.device, torch.float32).contiguous())
+        return dict(image_processor=None, image_token_len=num_patches, vision_config=vc)
+
+    # ---- visual tokens -----------------------------------------------------------------------------
+    def encode_clips(self, images) -> (torch.Tensor, List[int]):
+        """images: [B,T,3,224,224] tensor or list of [T_i,3,224,224] (valley_model.py:168-184).
+        Returns (pooled bf16 [sum(256+T_i), W], frames per clip).  W = 1024 for mean pooling (projection
+        comes after), W = H for max pooling (projection first)."""
+        clips = list(images) if isinstance(images, (list, tuple)) else [images[b] for b in range(len(images))]
+        Ts = [int(c.shape[0]) for c in clips]
+        frames = torch.cat([c.to(self.device) for c in clips], 0) if len(clips) > 1 else clips[0].to(self.device)
+        sel = getattr(self.config, "mm_vision_select_layer", -1)
+        feats = self.vision_tower.encode(frames, select_layer=sel)            # fp32 [F,257,1024]
+        method = self.patch_pooling_method
+        if method not in ("mean", "max"):
+            raise NotImplementedError(f"patch_pooling_method={method!r}: the v2/v3 temporal modules are not built yet "
+                                      "(SURVEY.md §8f N4)")
+        W = 1024
+        if method == "max":
+            # max does not commute with the projector: project every token first (reference order)
+            x16 = ops.cast_bf16(feats.view(-1, 1024))
+            feats = ops.gemm(x16, self.mm_projector.weight, self.mm_projector.bias, out_dtype=torch.float32)
+            W = feats.shape[-1]
+            feats = feats.view(-1, 257, W)
+        mode = ops.POOL_MEAN if method == "mean" else ops.POOL_MAX
+        outs, f0 = [], 0
+        if len(set(Ts)) == 1:
+            pooled = ops.pool_tokens(feats.reshape(-1, W), len(Ts), Ts[0], mode).view(-1, W)
+        else:
+            for T in Ts:
+                outs.append(ops.pool_tokens(feats[f0:f0 + T].reshape(-1, W), 1, T, mode).view(-1, W))
+                f0 += T
+            pooled = torch.cat(outs, 0)
+        return pooled, Ts
+
+    def project_pooled(self, pooled: torch.Tensor) -> torch.Tensor:
+        """pooled bf16 [NV, 1024] -> visual tokens bf16 [NV, H] (mm_projector, valley_model.py:190)."""
+        if pooled.shape[-1] == self.config.hidden_size and self.patch_pooling_method == "max":
+            return pooled
+        return ops.gemm(pooled, self.mm_projector.weight, self.mm_projector.bias)
+
+    def embed_inputs(self, input_ids, images=None, visual_tokens: Optional[torch.Tensor] = None,
+                     frames_per_clip: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """Token embedding + visual splice (valley_model.py:160-247) -> fp32 residual stream [B*S, H]."""
+        B, S = input_ids.shape
+        ids_host = input_ids.detach().cpu().numpy()
+        row_map = ids_host.astype(np.int32).reshape(-1)
+        visual = None
+        has_vision = self.vision_tower is not None and (S != 1 or self.training)          # :164
+        if has_vision and (images is not None or visual_tokens is not None):
+            if visual_tokens is None:
+                pooled, frames_per_clip = self.encode_clips(images)
+                visual = self.project_pooled(pooled)
+            else:
+                visual = visual_tokens
+            row_map = build_row_map(ids_host, frames_per_clip, self.vision_tower.config)
+        if row_map.min() < -(0 if visual is None else visual.shape[0]) or row_map.max() >= self.llama.V:
+            raise IndexError("index out of range in self")               # torch embedding's error text
+        return ops.embed_splice(torch.from_numpy(row_map).to(self.device), self.llama.embed, visual)
+
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
+                visual_tokens: Optional[torch.Tensor] = None, frames_per_clip: Optional[Sequence[int]] = None):
+        """valley_model.py:135-254.  ``visual_tokens``/``frames_per_clip`` let a caller that already
+        encoded (e.g. the frame-DP path, valley_amd/parallel.py) skip the tower."""
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not materialised by the HIP path")
+        if inputs_embeds is not None:
+            h = inputs_embeds.to(self.device, torch.float32).reshape(-1, self.config.hidden_size).contiguous().clone()
+            B, S = inputs_embeds.shape[:2]
+        else:
+            B, S = input_ids.shape
+            h = self.embed_inputs(input_ids, images, visual_tokens, frames_per_clip)
+        cache = past_key_values
+        if cache is None or not isinstance(cache, HipKVCache):
+            ctx = max(getattr(self.config, "max_position_embeddings", 2048), S)
+            cache = self.llama.new_cache(B, ctx if use_cache else S)
+        if attention_mask is not None:
+            am = attention_mask.to(self.device)
+            if cache.key_valid is None and bool((am == 0).any()):
+                cache.key_valid = torch.ones((B, cache.ctx_max), dtype=torch.uint8, device=self.device)
+            if cache.key_valid is not None:
+                n = min(am.shape[1], cache.ctx_max)
+                cache.key_valid[:, :n] = am[:, :n].to(torch.uint8)
+        x = self.llama.forward(h, B, S, cache)
+        return BaseModelOutputWithPast(last_hidden_state=x.view(B, S, -1), past_key_values=cache if use_cache else None)
+
+    __call__ = forward
+
+
+def _rope_theta(c) -> float:
+    rp = getattr(c, "rope_parameters", None)
+    if isinstance(rp, dict) and "rope_theta" in rp:
+        return float(rp["rope_theta"])
+    return 10000.0
+
+
+class ValleyLlamaForCausalLM:
+    """valley_model.py:257-439."""
+    config_class = ValleyConfig
+
+    def __init__(self, config, device="cuda:0"):
+        from . import lib
+        lib.load()                                           # fail loudly right here if the HIP library is absent
+        self.config = config
+        self.device = torch.device(device)
+        self.model = ValleyLlamaModel(config, device=device)
+
+    # -- module-ish API ------------------------------------------------------------------------------
+    def get_model(self):                                     # :269
+        return self.model
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    @property
+    def lm_head(self):
+        return SimpleNamespace(weight=self.model.llama.lm_head[:self.model.llama.V])
+
+    def load_state_dict(self, sd: Dict, strict: bool = True):
+        """Reference key names: model.*, lm_head.weight, model.mm_projector.{weight,bias},
+        model.vision_tower.* (valley/model/apply_delta.py:25,30)."""
+        self.model.llama.load_state_dict(sd)
+        if "model.mm_projector.weight" in sd:
+            self.model.mm_projector = HipLinear(_dev(sd["model.mm_projector.weight"], self.device, torch.bfloat16),
+                                                _dev(sd["model.mm_projector.bias"], self.device, torch.float32))
+            self.config.use_mm_proj = True
+        vt = {k[len("model.vision_tower."):]: v for k, v in sd.items() if k.startswith("model.vision_tower.")}
+        if vt:
+            if self.model.vision_tower is None:
+                self.model.vision_tower = build_vision_tower(None, device=self.device)
+            self.model.vision_tower.load_state_dict(vt)
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **kw):
+        """Sharded HF checkpoint directory (config.json + *.safetensors / pytorch_model-*.bin)."""
+        from .checkpoint import load_valley_checkpoint
+        config, sd = load_valley_checkpoint(path, ValleyConfig)
+        config.mm_vision_tower_name = getattr(config, "mm_vision_tower", None)
+        tower_name = getattr(config, "mm_vision_tower", None)
+        if tower_name is not None and not os.path.isdir(str(tower_name)):
+            config.mm_vision_tower = None                    # no hub access: the tower must come from the state dict
+        model = cls(config, device=device)
+        model.load_state_dict(sd)
+        config.mm_vision_tower = tower_name
+        return model
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None, **kw):
+        """valley_model.py:272-330.  Returns CausalLMOutputWithPast(logits fp32 [B,S,V], past_key_values)."""
+        if labels is not None:
+            raise NotImplementedError("training loss (valley_model.py:307-318) is outside the inference hot path")
+        out = self.model.forward(input_ids=input_ids, attention_mask=attention_mask, past_key_values=past_key_values,
+                                 inputs_embeds=inputs_embeds, use_cache=use_cache, output_attentions=output_attentions,
+                                 output_hidden_states=output_hidden_states, images=images, **kw)
+        hidden = out.last_hidden_state                                    # bf16 [B,S,H]
+        B, S, H = hidden.shape
+        logits = self.model.llama.logits(hidden.view(B * S, H)).view(B, S, -1)      # lm_head on ALL positions (:304-305)
+        if return_dict is False:
+            return (logits, out.past_key_values)
+        return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=out.past_key_values,
+                                      hidden_states=None, attentions=None)
+
+    __call__ = forward
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
+        """valley_model.py:332-352 (an EMPTY HipKVCache is falsy, so step 0 keeps the whole prompt — the
+        behaviour the reference had at its pinned transformers)."""
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        if inputs_embeds is not None and past_key_values is None:
+            model_inputs = {"inputs_embeds": inputs_embeds}
+        else:
+            model_inputs = {"input_ids": input_ids}
+        model_inputs.update({"past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"),
+                             "attention_mask": attention_mask, "images": kwargs.get("images", None)})
+        return model_inputs
+
+    @torch.no_grad()
+    def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens: int = 64, do_sample: bool = False,
+                 temperature: float = 1.0, stopping_criteria=None, eos_token_id=None, **kw):
+        """Prefill + per-token KV decode (the loop of serve/model_worker.py:371-394; the reference's CLI
+        path reaches the same through HF ``generate``, valley_model.py:432).  Greedy when not sampling or
+        temperature < 1e-4, else temperature softmax + multinomial."""
+        input_ids = input_ids.to(self.device)
+        B, S = input_ids.shape
+        ctx = min(getattr(self.config, "max_position_embeddings", 2048), S + max_new_tokens)
+        cache = self.model.llama.new_cache(B, max(ctx, S + 1))
+        mask = attention_mask
+        out = self.forward(input_ids=input_ids, images=images, attention_mask=mask, past_key_values=cache, use_cache=True)
+        seq = input_ids
+        for _ in range(max_new_tokens):
+            last = out.logits[:, -1, :].contiguous()
+            if do_sample and temperature >= 1e-4:
+                probs = torch.softmax(last / temperature, dim=-1)
+                token = torch.multinomial(probs, num_samples=1).view(B)
+            else:
+                token = ops.argmax(last).to(torch.long)
+            seq = torch.cat([seq, token[:, None]], dim=1)
+            if eos_token_id is not None and bool((token == eos_token_id).all()):
+                break
+            if stopping_criteria is not None and all(bool(c(seq, None)) for c in stopping_criteria):
+                break
+            if cache.seq_len + 1 > cache.ctx_max:
+                break
+            if mask is not None:
+                mask = torch.cat([mask.to(self.device), torch.ones((B, 1), dtype=mask.dtype, device=self.device)], dim=1)
+            out = self.forward(input_ids=token[:, None], attention_mask=mask, past_key_values=cache, use_cache=True)
+        return seq
+
+    # -- tokenizer / prompt glue -----------------------------------------------------------------------
+    def resize_token_embeddings(self, n: int):
+        ll = self.model.llama
+        if n == ll.V:
+            return
+        H, d = ll.H, self.device
+        emb = torch.zeros((n, H), dtype=torch.bfloat16, device=d)
+        keep = min(n, ll.V)
+        emb[:keep] = ll.embed[:keep]
+        head = torch.zeros(((n + 7) // 8 * 8, H), dtype=torch.bfloat16, device=d)
+        head[:keep] = ll.lm_head[:keep]
+        ll.embed, ll.lm_head, ll.V, ll.Vpad = emb, head, n, head.shape[0]
+        self.config.vocab_size = n
+
+    def initialize_vision_tokenizer(self, tokenizer):
+        """valley_model.py:354-379."""
+        vc = self.get_model().vision_tower.config
+        vc.use_im_start_end = True
+        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_VIDEO_FRAME_TOKEN], special_tokens=True)
+        self.resize_token_embeddings(len(tokenizer))
+        num_new = tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN, DEFAULT_VI_START_TOKEN,
+                                        DEFAULT_VI_END_TOKEN], special_tokens=True)
+        self.resize_token_embeddings(len(tokenizer))
+        vc.im_start_token, vc.im_end_token = tokenizer.convert_tokens_to_ids([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN])
+        vc.vi_start_token, vc.vi_end_token = tokenizer.convert_tokens_to_ids([DEFAULT_VI_START_TOKEN, DEFAULT_VI_END_TOKEN])
+        vc.vi_frame_token = tokenizer.convert_tokens_to_ids(DEFAULT_VIDEO_FRAME_TOKEN)
+        if num_new > 0:
+            ll = self.model.llama
+            ll.embed[ll.V - num_new:ll.V] = ll.embed[:ll.V - num_new].float().mean(0, keepdim=True).to(torch.bfloat16)
+            ll.lm_head[ll.V - num_new:ll.V] = ll.lm_head[:ll.V - num_new].float().mean(0, keepdim=True).to(torch.bfloat16)
+        vc.im_patch_token = tokenizer.convert_tokens_to_ids([DEFAULT_IMAGE_PATCH_TOKEN])[0]
+
+    def build_inputs(self, tokenizer, messages):
+        """valley_model.py:381-402 (including its role spellings and the hard-coded 8 frame tokens)."""
+        prompt = ''
+        for m in messages:
+            if m['role'] == 'system':
+                prompt += m['content'] + '\n\n' + '###'
+            elif m['role'] == 'user':
+                replace_token = DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_PATCH_TOKEN * 256 + DEFAULT_IM_END_TOKEN + \
+                    DEFAULT_VI_START_TOKEN + DEFAULT_VIDEO_FRAME_TOKEN * 8 + DEFAULT_VI_END_TOKEN
+                if '<video>' in m['content'] or '<image>' in m['content']:
+                    message = m['content'].replace('<video>', replace_token)
+                    message = message.replace('<image>', replace_token)
+                    prompt += ' ' + 'Human' + ": " + message + ' \n' + '###'
+            elif m['role'] == 'assistent':
+                prompt += ' ' + 'Assistent' + ": " + m['content'] + ' \n' + '###'
+            else:
+                raise ValueError("Role is only suport \"assistent\", \"human\" and \"system\".")
+        if DEFAULT_IM_START_TOKEN not in prompt:
+            raise ValueError("You need to specify the <video> token in the query")
+        tokenizer.padding_side = 'left'
+        return tokenizer([prompt], padding=True)
+
+    def process_response(self, outputs):
+        """valley_model.py:404-422."""
+        output = []
+        for out in outputs:
+            while True:
+                cur_len = len(out)
+                out = out.strip()
+                for pattern in ['###', 'Assistant:', 'Response:', 'Valley:']:
+                    if out.startswith(pattern):
+                        out = out[len(pattern):].strip()
+                if len(out) == cur_len:
+                    break
+            try:
+                index = out.index('###')
+            except ValueError:
+                out += '###'
+                index = out.index("###")
+            output.append(out[:index].strip())
+        return output
+
+    @torch.no_grad()
+    def completion(self, tokenizer, video, message: list, gen_kwargs: dict, device=None):
+        """valley_model.py:424-439.  ``video`` is a path (decoded by valley_amd.video.load_video) or an
+        already preprocessed [3,T,224,224] tensor."""
+        from .video import KeywordsStoppingCriteria, load_video
+        inputs = self.build_inputs(tokenizer, message)
+        input_ids = torch.as_tensor(inputs.input_ids).to(self.device)
+        images = video if isinstance(video, torch.Tensor) else load_video(video)
+        images = images.permute(1, 0, 2, 3).unsqueeze(0)
+        stopping = KeywordsStoppingCriteria(['###'], tokenizer, input_ids)
+        gk = {k: v for k, v in gen_kwargs.items() if k in ("max_new_tokens", "do_sample", "temperature", "eos_token_id")}
+        output_ids = self.generate(input_ids=input_ids, images=images, stopping_criteria=[stopping], **gk)
+        n_in = input_ids.shape[1]
+        n_diff = (input_ids != output_ids[:, :n_in]).sum().item()
+        if n_diff > 0:
+            print(f'[Warning] {n_diff} output_ids are not the same as the input_ids')
+        outputs = tokenizer.batch_decode(output_ids[:, n_in:], skip_special_tokens=True)
+        return self.process_response(outputs)
+
+
+def _dev(t, device, dtype):
+    if not isinstance(t, torch.Tensor):
+        t = torch.from_numpy(np.ascontiguousarray(t))
+    return t.to(device=device, dtype=dtype).contiguous()

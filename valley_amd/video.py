@@ -1,0 +1,75 @@
+"""Host-side video glue of the entry points (valley/util/data_util.py:40-56, 249-303).
+
+``load_video`` needs ``decord`` to decode containers; this image has none, so the function accepts a
+directory of frames / an ``.npy`` of uint8 frames [N,H,W,3] and otherwise raises.  The sampling and
+normalisation follow the reference: 8 uniformly spaced frames (``np.linspace(0, len-1, 8).astype(int)``,
+:264-265), short side to 256 (bilinear), centre crop 224, /255, CLIP mean/std (:272-273).
+The GPU version of this preprocessing is the "next" row N2 of SURVEY.md §8(f)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class KeywordsStoppingCriteria:
+    """valley/util/data_util.py:40-56."""
+
+    def __init__(self, keywords, tokenizer, input_ids):
+        self.keywords = keywords
+        self.tokenizer = tokenizer
+        self.start_len = None
+        self.input_ids = input_ids
+
+    def __call__(self, output_ids, scores=None, **kwargs) -> bool:
+        if self.start_len is None:
+            self.start_len = self.input_ids.shape[1]
+        else:
+            outputs = self.tokenizer.batch_decode(output_ids[:, self.start_len:], skip_special_tokens=True)[0]
+            for keyword in self.keywords:
+                if keyword in outputs:
+                    return True
+        return False
+
+
+def sample_indices(n_total: int, n: int = 8) -> np.ndarray:
+    return np.linspace(0, n_total - 1, n).astype(np.int_)
+
+
+def preprocess_frames(frames_u8: np.ndarray, scale_size: int = 256, crop: int = 224) -> torch.Tensor:
+    """uint8 [T,H,W,3] -> float32 [3,T,224,224], the tensor layout ``load_video`` returns."""
+    x = torch.from_numpy(np.ascontiguousarray(frames_u8)).permute(0, 3, 1, 2).float()      # [T,3,H,W]
+    _, _, H, W = x.shape
+    if H <= W:
+        nh, nw = scale_size, int(round(W * scale_size / H))
+    else:
+        nh, nw = int(round(H * scale_size / W)), scale_size
+    x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)
+    t, l = int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
+    x = x[:, :, t:t + crop, l:l + crop] / 255.0
+    mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    return ((x - mean) / std).permute(1, 0, 2, 3).contiguous()
+
+
+def load_video(path, fixed_frame_number: int = 8) -> torch.Tensor:
+    if isinstance(path, np.ndarray):
+        frames = path
+    elif str(path).endswith(".npy"):
+        frames = np.load(path)
+    elif os.path.isfile(path):
+        try:
+            import decord
+        except ImportError as e:
+            raise RuntimeError("decoding video containers needs `decord`, which this image does not ship; pass a "
+                               "preprocessed [3,T,224,224] tensor, a uint8 frame array or an .npy file") from e
+        vr = decord.VideoReader(path, num_threads=1, ctx=decord.cpu(0))
+        frames = vr.get_batch(sample_indices(len(vr), fixed_frame_number)).asnumpy()
+        return preprocess_frames(frames)
+    else:
+        raise FileNotFoundError(path)
+    return preprocess_frames(frames[sample_indices(len(frames), fixed_frame_number)])

@@ -1,0 +1,199 @@
+"""CLIP ViT-L/14 frame encoder on the HIP kernels.
+
+Replaces the reference's per-clip ``vision_tower(images[b], output_hidden_states=True)
+.hidden_states[select_layer]`` loop (valley/model/valley_model.py:168-184) and the HuggingFace
+``CLIPVisionModel`` it calls (hf:clip/modeling_clip.py:138-218, 259-383, 594-656).  All frames of
+all clips go through ONE batch (M = F*257 GEMM rows) — the reference's B sequential small-M calls
+are what keeps it off the MFMA roofline.  Only the layers that contribute to
+``hidden_states[select_layer]`` run (23 of 24 for -2; post_layernorm never runs).
+
+Data layout in HBM: residual stream fp32 [F*257, 1024]; GEMM activations bf16; weights bf16 in
+nn.Linear layout with q/k/v fused to [3072,1024]; the 14x14 patch conv as a [1024, 640] GEMM
+weight (K = 588 zero-padded to 640).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class VisionConfig(SimpleNamespace):
+    """The attributes of HF ``CLIPVisionConfig`` the path reads, plus the six token ids the entry
+    points bind here (valley/inference/run_valley.py:13-18, valley_model.py:363-365,379)."""
+
+    def __init__(self, **kw):
+        d = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=24,
+                 image_size=224, patch_size=14, layer_norm_eps=1e-5, hidden_act="quick_gelu", num_channels=3)
+        d.update(kw)
+        super().__init__(**d)
+
+
+def _dev(t, device, dtype):
+    if not isinstance(t, torch.Tensor):
+        t = torch.from_numpy(np.ascontiguousarray(t))
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+class HipCLIPVisionTower:
+    """ViT-L/14-shaped tower.  ``config`` is mutable (token ids are set on it by the callers)."""
+
+    def __init__(self, config: Optional[VisionConfig] = None, device="cuda:0"):
+        self.config = config or VisionConfig()
+        c = self.config
+        if c.hidden_size != 1024 or c.num_attention_heads != 16 or c.image_size != 224 or c.patch_size != 14:
+            # the reference forward hard-codes 1024 / 256 patches too (valley_model.py:192)
+            raise ValueError("the HIP tower supports the ViT-L/14 geometry only (1024 wide, 16 heads, 224/14)")
+        if c.hidden_act != "quick_gelu":
+            raise ValueError("only quick_gelu towers are supported")
+        self.device = torch.device(device)
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        self.loaded = False
+        self._ws = {}
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict, prefix: str = "") -> "HipCLIPVisionTower":
+        """HF CLIPVisionModel key names, flat (transformers 5.x) or with the ``vision_model.`` prefix of
+        the pinned commit."""
+        if prefix == "" and any(k.startswith("vision_model.") for k in sd):
+            prefix = "vision_model."
+        g = lambda k: sd[prefix + k]  # noqa: E731
+        d, bf, f32 = self.device, torch.bfloat16, torch.float32
+        c = self.config
+        wp = _dev(g("embeddings.patch_embedding.weight"), d, bf).reshape(1024, 588)
+        self.w_patch = torch.zeros((1024, 640), dtype=bf, device=d)
+        self.w_patch[:, :588] = wp
+        self.cls = _dev(g("embeddings.class_embedding"), d, f32)
+        self.pos = _dev(g("embeddings.position_embedding.weight"), d, f32)
+        self.pre_g, self.pre_b = _dev(g("pre_layrnorm.weight"), d, f32), _dev(g("pre_layrnorm.bias"), d, f32)
+        self.layers = []
+        for i in range(c.num_hidden_layers):
+            p = f"encoder.layers.{i}."
+            if prefix + p + "layer_norm1.weight" not in sd:
+                break                                           # a tower truncated to the needed layers
+            L = {}
+            L["ln1_g"], L["ln1_b"] = _dev(g(p + "layer_norm1.weight"), d, f32), _dev(g(p + "layer_norm1.bias"), d, f32)
+            L["ln2_g"], L["ln2_b"] = _dev(g(p + "layer_norm2.weight"), d, f32), _dev(g(p + "layer_norm2.bias"), d, f32)
+            L["w_qkv"] = torch.cat([_dev(g(p + f"self_attn.{n}_proj.weight"), d, bf) for n in "qkv"], 0).contiguous()
+            L["b_qkv"] = torch.cat([_dev(g(p + f"self_attn.{n}_proj.bias"), d, f32) for n in "qkv"], 0).contiguous()
+            L["w_o"], L["b_o"] = _dev(g(p + "self_attn.out_proj.weight"), d, bf), _dev(g(p + "self_attn.out_proj.bias"), d, f32)
+            L["w_fc1"], L["b_fc1"] = _dev(g(p + "mlp.fc1.weight"), d, bf), _dev(g(p + "mlp.fc1.bias"), d, f32)
+            L["w_fc2"], L["b_fc2"] = _dev(g(p + "mlp.fc2.weight"), d, bf), _dev(g(p + "mlp.fc2.bias"), d, f32)
+            self.layers.append(L)
+        self.loaded = True
+        return self
+
+    def init_random(self, seed: int = 0, layers: Optional[int] = None) -> "HipCLIPVisionTower":
+        """Random weights generated on the device (bench only; parity tests use valley_amd.weights)."""
+        c = self.config
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        d, bf, f32 = self.device, torch.bfloat16, torch.float32
+        rn = lambda shape, std, dt=bf: (torch.randn(shape, generator=g, device=d, dtype=f32) * std).to(dt)  # noqa: E731
+        H, I = c.hidden_size, c.intermediate_size
+        self.w_patch = torch.zeros((1024, 640), dtype=bf, device=d)
+        self.w_patch[:, :588] = rn((1024, 588), 0.02)
+        self.cls, self.pos = rn((H,), H ** -0.5, f32), rn((257, H), 0.02, f32)
+        self.pre_g, self.pre_b = torch.ones(H, device=d), torch.zeros(H, device=d)
+        nl = c.num_hidden_layers if layers is None else layers
+        in_std = H ** -0.5 * (2 * c.num_hidden_layers) ** -0.5
+        self.layers = []
+        for _ in range(nl):
+            self.layers.append(dict(
+                ln1_g=torch.ones(H, device=d), ln1_b=torch.zeros(H, device=d),
+                ln2_g=torch.ones(H, device=d), ln2_b=torch.zeros(H, device=d),
+                w_qkv=rn((3 * H, H), 0.02), b_qkv=rn((3 * H,), 0.02, f32),
+                w_o=rn((H, H), H ** -0.5), b_o=rn((H,), 0.02, f32),
+                w_fc1=rn((I, H), (2 * H) ** -0.5), b_fc1=rn((I,), 0.02, f32),
+                w_fc2=rn((H, I), in_std * 2), b_fc2=rn((H,), 0.02, f32)))
+        self.loaded = True
+        return self
+
+    # ---- compute ---------------------------------------------------------------------------------
+    def _workspace(self, F: int):
+        ws = self._ws.get(F)
+        if ws is None:
+            d, M, I = self.device, F * 257, self.config.intermediate_size
+            ws = dict(cols=torch.empty((F * 256, 640), dtype=torch.bfloat16, device=d),
+                      patch=torch.empty((F * 256, 1024), dtype=torch.float32, device=d),
+                      x=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
+                      qkv=torch.empty((M, 3072), dtype=torch.bfloat16, device=d),
+                      att=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
+                      mlp=torch.empty((M, I), dtype=torch.bfloat16, device=d))
+            if len(self._ws) > 4:
+                self._ws.clear()
+            self._ws[F] = ws
+        return ws
+
+    def n_layers_for(self, select_layer: int) -> int:
+        n = self.config.num_hidden_layers
+        idx = select_layer if select_layer >= 0 else n + 1 + select_layer
+        if not 0 <= idx <= n:
+            raise IndexError(f"select_layer {select_layer} out of range for {n} layers")
+        return idx
+
+    def embed(self, frames: torch.Tensor, h: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """frames bf16 [F,3,224,224] -> hidden_states[0] = pre_layrnorm(embeddings), fp32 [F*257,1024]."""
+        F = frames.shape[0]
+        ws = self._workspace(F)
+        ops.patchify(frames, out=ws["cols"])
+        ops.gemm_mfma(ws["cols"], self.w_patch, out=ws["patch"])
+        return ops.vit_embed_ln(ws["patch"], self.cls, self.pos, self.pre_g, self.pre_b, F, self.config.layer_norm_eps, out=h)
+
+    def layer_forward(self, h: torch.Tensor, L: Dict[str, torch.Tensor], F: int):
+        """One pre-LN encoder layer, in place on the fp32 residual stream h [F*257,1024]."""
+        ws = self._workspace(F)
+        eps = self.config.layer_norm_eps
+        ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
+        ops.gemm_mfma(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        ops.vit_attention(ws["qkv"], F, out=ws["att"])
+        ops.gemm_mfma(ws["att"], L["w_o"], L["b_o"], residual=h, out=h)
+        ops.layernorm(h, L["ln2_g"], L["ln2_b"], eps, out=ws["x"])
+        ops.gemm_mfma(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
+        ops.gemm_mfma(ws["mlp"], L["w_fc2"], L["b_fc2"], residual=h, out=h)
+
+    def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: int = 256,
+               keep_all: bool = False):
+        """frames [F,3,224,224] (any float dtype, device) -> fp32 [F,257,1024] = hidden_states[select_layer].
+        ``keep_all`` additionally returns every hidden state (slow path for the HF-style call)."""
+        if not self.loaded:
+            raise RuntimeError("vision tower has no weights")
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (3, 224, 224):
+            raise ValueError(f"Input image size ({tuple(frames.shape)}) doesn't match model (3*224*224).")
+        frames = frames.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        nl = self.n_layers_for(select_layer)
+        if nl > len(self.layers):
+            raise RuntimeError(f"need {nl} encoder layers, tower holds {len(self.layers)}")
+        Ftot = frames.shape[0]
+        out = torch.empty((Ftot * 257, 1024), dtype=torch.float32, device=self.device)
+        all_states = [] if keep_all else None
+        for f0 in range(0, Ftot, chunk):
+            F = min(chunk, Ftot - f0)
+            h = out[f0 * 257:(f0 + F) * 257]
+            self.embed(frames[f0:f0 + F], h)
+            states = [h.clone()] if keep_all else None
+            for L in self.layers[:nl]:
+                self.layer_forward(h, L, F)
+                if keep_all:
+                    states.append(h.clone())
+            if keep_all:
+                all_states.append(states)
+        res = out.view(Ftot, 257, 1024)
+        if keep_all:
+            merged = [torch.cat([s[i] for s in all_states], 0).view(Ftot, 257, 1024) for i in range(nl + 1)]
+            return res, merged
+        return res
+
+    # HF-style call used by code written against CLIPVisionModel (valley_model.py:172,180)
+    def __call__(self, pixel_values: torch.Tensor, output_hidden_states: bool = True):
+        last, states = self.encode(pixel_values, select_layer=len(self.layers), keep_all=True)
+        return SimpleNamespace(last_hidden_state=last, hidden_states=tuple(states))
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def to(self, *a, **k):
+        return self
