@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — Valley visual-token hot path on MI355X.
+
+A "step" is ONE pass of the hot path over one batch of synthetic clips resident in HBM:
+    frames [B,T,3,224,224] bf16 -> CLIP ViT-L/14 encode (23 of 24 layers, hidden_states[-2])
+    -> temporal mean pool + per-frame CLS -> (N>1: RCCL all-gather of pooled tokens, 1024-wide)
+    -> mm_projector -> token-embedding gather + visual splice -> Llama prefill over [visual || text]
+    -> lm_head on all positions.
+Default workload = BASELINE.json configs[1] "Valley2-7b: 8 frames x batch 4, ViT-L/14 + Llama-2-7B
+prefill, bf16, 1xMI355X" (S = 320 + T = 328 per SURVEY.md §8d).  `--config c3` runs the 13B case.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): frames shard by whole
+clips (every rank encodes its own B clips: weak scaling), ONE all-gather reassembles the pooled
+visual tokens of all N*B clips on every rank, every rank projects them, then prefills its own B
+sequences on its Llama replica (`--prefill replicated` prefills all N*B on every rank instead, the
+literal reading of configs[3]).
+
+One JSON line on rank 0.  `value` = frames pushed through the WHOLE path per second over all
+ranks; `stages` gives the ViT-encode frames/s and prefill tokens/s measured with HIP events inside
+the same timed steps; `roofline` is for the dominant kernel (the MFMA GEMM instantiation with the
+largest share of time), achieved = algorithmic flop per launch / mean launch duration, both measured
+live with HIP events around every GEMM launch of the timed steps; `cpu_baseline` times the CPU oracle
+(oracle/valley_oracle.py, kind "port") on a bounded sample of the same workload on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (B clips per GPU, T frames, hidden, heads, intermediate, layers, eps, label)
+    "c2": dict(B=4, T=8, H=4096, heads=32, I=11008, L=32, eps=1e-5, label="Valley2-7b: 8 frames x batch 4, ViT-L/14 + Llama-2-7B prefill"),
+    "c3": dict(B=8, T=16, H=5120, heads=40, I=13824, L=40, eps=1e-6, label="Valley-13b-v1: 16 frames x batch 8, ViT-L/14 + Vicuna-13B prefill"),
+    "tiny": dict(B=2, T=4, H=256, heads=2, I=512, L=2, eps=1e-5, label="tiny plumbing config"),
+}
+VOCAB_TEXT = 32000
+PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
+VIT_GFLOP_PER_FRAME = 155.29        # patch 0.308 + 23 x 6.738
+
+
+def prefill_flop(S, H, I, L, V):
+    """S*[L*(8H^2+6HI)+2HV] + L*2*S*(S+1)*H (causal-half attention)."""
+    return S * (L * (8 * H * H + 6 * H * I) + 2 * H * V) + L * 2 * S * (S + 1) * H
+
+
+def cpu_baseline(cfg, threads):
+    """Oracle (kind "port") on a bounded sample: 1 clip x T frames through ViT-L/14 (23 layers) and
+    2 of the L Llama layers at S = 320+T, scaled by L/2; fp32, all host threads."""
+    from oracle import valley_oracle as O
+    torch.set_num_threads(threads)
+    T, H, I, L = cfg["T"], cfg["H"], cfg["I"], cfg["L"]
+    S = 320 + T
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s, std=0.02: torch.randn(*s, generator=g) * std  # noqa: E731
+    vw = {"embeddings.class_embedding": rn(1024), "embeddings.patch_embedding.weight": rn(1024, 3, 14, 14),
+          "embeddings.position_embedding.weight": rn(257, 1024), "pre_layrnorm.weight": torch.ones(1024),
+          "pre_layrnorm.bias": torch.zeros(1024)}
+    for i in range(23):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            vw[p + f"self_attn.{n}.weight"], vw[p + f"self_attn.{n}.bias"] = rn(1024, 1024), rn(1024)
+        for n in ("layer_norm1", "layer_norm2"):
+            vw[p + n + ".weight"], vw[p + n + ".bias"] = torch.ones(1024), torch.zeros(1024)
+        vw[p + "mlp.fc1.weight"], vw[p + "mlp.fc1.bias"] = rn(4096, 1024), rn(4096)
+        vw[p + "mlp.fc2.weight"], vw[p + "mlp.fc2.bias"] = rn(1024, 4096), rn(1024)
+    nl = 2
+    lw = {"model.norm.weight": torch.ones(H)}
+    for i in range(nl):
+        p = f"model.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            lw[p + f"self_attn.{n}.weight"] = rn(H, H)
+        lw[p + "mlp.gate_proj.weight"], lw[p + "mlp.up_proj.weight"], lw[p + "mlp.down_proj.weight"] = rn(I, H), rn(I, H), rn(H, I)
+        lw[p + "input_layernorm.weight"], lw[p + "post_attention_layernorm.weight"] = torch.ones(H), torch.ones(H)
+    px = torch.randn((T, 3, 224, 224), generator=g)
+    emb = rn(1, S, H, std=1.0)
+    vcfg = O.VisionCfg(layers=24)
+    lcfg = O.LlamaCfg(hidden=H, heads=cfg["heads"], intermediate=I, layers=nl, eps=cfg["eps"])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.vit_select(px, vw, vcfg, -2)
+        t_vit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.llama_forward(emb, lw, lcfg, n_layers=nl)
+        t_l = time.perf_counter() - t0
+    t_clip = t_vit + t_l * (L / nl)
+    return {"value": round(T / t_clip, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32: 1 clip x {T} frames ViT-L/14 23 layers ({t_vit:.2f}s) + {nl} of {L} Llama layers "
+                      f"at S={S} ({t_l:.2f}s, scaled x{L // nl}); lm_head excluded",
+            "vit_frames_per_s": round(T / t_vit, 3), "prefill_tokens_per_s": round(S / (t_l * L / nl), 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=list(CONFIGS))
+    ap.add_argument("--prefill", default="sharded", choices=["sharded", "replicated"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (rocprof runs)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from valley_amd import ops, parallel
+    from valley_amd import valley_model as vm
+    from valley_amd import weights as W
+
+    cfg = CONFIGS[args.config]
+    B, T, H, I, L = cfg["B"], cfg["T"], cfg["H"], cfg["I"], cfg["L"]
+    V = VOCAB_TEXT + 6
+    S = 320 + T
+    config = vm.ValleyConfig(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=L,
+                             num_attention_heads=cfg["heads"], num_key_value_heads=cfg["heads"], rms_norm_eps=cfg["eps"],
+                             max_position_embeddings=2048)
+    config.use_mm_proj, config.mm_hidden_size, config.mm_vision_select_layer = True, 1024, -2
+    model = vm.ValleyLlamaForCausalLM(config, device=dev)
+    mm = model.get_model()
+    mm.llama.init_random(seed=0)
+    tower = vm.build_vision_tower(None, device=dev)
+    tower.init_random(seed=0, layers=23)                     # layer 24 never contributes to hidden_states[-2]
+    for k, v in W.SPECIAL_IDS(VOCAB_TEXT).items():
+        setattr(tower.config, k, v)
+    mm.initialize_vision_modules(tower, -2)
+
+    # synthetic inputs, resident in HBM before the timed region
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    frames = torch.randn((B, T, 3, 224, 224), generator=g, device=dev).to(torch.bfloat16)
+    ids = torch.from_numpy(W.synthetic_prompt(7, T, VOCAB_TEXT)).view(1, S)
+    Bp = B * world if args.prefill == "replicated" else B
+    input_ids = ids.repeat(Bp, 1)
+    cache = mm.llama.new_cache(Bp, S)
+    Ts_all = [T] * (B * world)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    stage_events = []
+
+    def step(record):
+        e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
+        if record:
+            e0.record()
+        pooled, _ = mm.encode_clips(frames)                              # ViT encode + temporal pool (local clips)
+        if world > 1:
+            pooled = parallel.all_gather_rows(pooled, [pooled.shape[0]] * world)
+        if record:
+            e1.record()
+        visual = mm.project_pooled(pooled)                               # all N*B clips' tokens, on every rank
+        if args.prefill == "sharded" and world > 1:
+            n = B * (256 + T)
+            visual = visual[rank * n:(rank + 1) * n]
+        cache.seq_len = 0
+        out = model(input_ids=input_ids, past_key_values=cache, use_cache=True, visual_tokens=visual,
+                    frames_per_clip=Ts_all[:Bp])
+        if record:
+            e2.record()
+            stage_events.append((e0, e1, e2))
+        return out
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    rec = None if args.no_kernel_events else []
+    ops.set_recorder(rec)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_recorder(None)
+    assert torch.isfinite(out.logits[:, -1]).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        frames_total = B * T * world
+        vit_ms = sum(a.elapsed_time(b) for a, b, _ in stage_events) / len(stage_events)
+        pre_ms = sum(b.elapsed_time(c) for _, b, c in stage_events) / len(stage_events)
+        vit_fps = B * T / (vit_ms * 1e-3)
+        pre_tps = Bp * S / (pre_ms * 1e-3)
+        vit_tf = vit_fps * VIT_GFLOP_PER_FRAME / 1e3
+        pre_tf = prefill_flop(S, H, I, L, V) * Bp / (pre_ms * 1e-3) / 1e12
+        result = {
+            "metric": "frames/sec ViT-L/14 encode + prefill tokens/sec",
+            "value": round(frames_total / (elapsed / args.steps), 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": cfg["label"] + f", S={S}, end-to-end hot path (encode+pool+project+splice+prefill+lm_head)",
+                       "name": args.config, "clips_per_gpu": B, "frames_per_clip": T, "prefill_batch_per_gpu": Bp,
+                       "seq_len": S, "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},
+            "stages": {"vit_frames_per_s_per_gpu": round(vit_fps, 1), "vit_ms": round(vit_ms, 3),
+                       "vit_TFLOPs": round(vit_tf, 1), "vit_frac_of_bf16_peak": round(vit_tf / PEAK_BF16_TFLOPS, 4),
+                       "prefill_tokens_per_s_per_gpu": round(pre_tps, 1), "prefill_ms": round(pre_ms, 3),
+                       "prefill_TFLOPs": round(pre_tf, 1), "prefill_frac_of_bf16_peak": round(pre_tf / PEAK_BF16_TFLOPS, 4)},
+        }
+        if rec:
+            agg = {}
+            for name, flop, a, b in rec:
+                d = agg.setdefault(name, [0.0, 0.0, 0])
+                d[0] += a.elapsed_time(b) * 1e-3
+                d[1] += flop
+                d[2] += 1
+            dom = max(agg.items(), key=lambda kv: kv[1][0])
+            name, (tsum, fsum, n) = dom
+            ach = fsum / tsum / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                  "launches": n, "avg_launch_us": round(tsum / n * 1e6, 2),
+                                  "avg_flop_per_launch": round(fsum / n / 1e9, 3),
+                                  "share_of_step_time": round(tsum / args.steps / (ms_step * 1e-3), 3),
+                                  "all_gemm_kernels": {k: {"TFLOPs": round(v[1] / v[0] / 1e12, 1), "launches": v[2],
+                                                           "ms_per_step": round(v[0] / args.steps * 1e3, 3)}
+                                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

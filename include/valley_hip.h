@@ -58,6 +58,10 @@ int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);
 
+/* The tile configuration vly_gemm_bf16 picks for (M,N) when tile_hint == 0 (1/2/3 as above); lets a
+ *   caller label launches when it profiles (bench.py's per-kernel roofline). */
+int vly_gemm_tile_for(int M, int N);
+
 /* LayerNorm over the last dim of an fp32 [M,D] tensor -> bf16 (GEMM input) and optionally fp32.
  *   hf:clip/modeling_clip.py:605,642 (pre_layrnorm), :363,368 (layer_norm1/2).  D % 256 == 0, D <= 8192. */
 int vly_layernorm(const float *x, const float *gamma, const float *beta, void *y_bf16, float *y_f32,

@@ -192,6 +192,8 @@ static int pick_tile(int M, int N) {
     return c2x1 <= c128 ? 3 : 2;
 }
 
+extern "C" int vly_gemm_tile_for(int M, int N) { return pick_tile(M, N); }
+
 extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C,
                              int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue,
                              int out_dtype, int tile_hint, void* stream) {

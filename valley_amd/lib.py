@@ -17,6 +17,7 @@ _SIGS = {
     "vly_abi_version": (c_int, []),
     "vly_last_error": (c_char_p, []),
     "vly_gemm_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_gemm_tile_for": (c_int, [c_int, c_int]),
     "vly_layernorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_rmsnorm": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_patchify": (c_int, [_P, _P, c_int, _P]),

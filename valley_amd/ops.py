@@ -16,6 +16,17 @@ OUT_BF16, OUT_F32 = 0, 1
 POOL_MEAN, POOL_MAX = 0, 1
 
 
+# Optional per-launch recorder (bench.py's live per-kernel timing): a list that receives
+# (kernel_label, algorithmic_flops, start_event, end_event) for every MFMA GEMM launch.
+_RECORDER = None
+TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64"}
+
+
+def set_recorder(rec):
+    global _RECORDER
+    _RECORDER = rec
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -50,9 +61,18 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
         _chk(residual, torch.float32, "residual", contiguous=False)
         assert tuple(residual.shape) == (M, N) and residual.stride(1) == 1
     od = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
-    fn = getattr(_lib.load(), fn_name)
+    L = _lib.load()
+    fn = getattr(L, fn_name)
+    rec = _RECORDER if fn_name == "vly_gemm_bf16" else None
+    if rec is not None:
+        tile = extra[0] or L.vly_gemm_tile_for(M, N)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
+    if rec is not None:
+        e1.record()
+        rec.append((f"gemm_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}>", 2.0 * M * N * K, e0, e1))
     _lib.check(rc, fn_name)
     return out
 
