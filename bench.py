@@ -53,7 +53,8 @@ def prefill_flop(S, H, I, L, V):
 
 def cpu_baseline(cfg, threads):
     """Oracle (kind "port") on a bounded sample: 1 clip x T frames through ViT-L/14 (23 layers) and
-    2 of the L Llama layers at S = 320+T, scaled by L/2; fp32, all host threads."""
+    4 of the L Llama layers at S = 320+T, scaled by L/4; fp32.  Threads: the host GEMM rate of the
+    256-core GPU box peaks at 16 threads (tools/cpu_threads_probe.py: 830 GFLOP/s at 16, 111 at 128)."""
     from oracle import valley_oracle as O
     torch.set_num_threads(threads)
     T, H, I, L = cfg["T"], cfg["H"], cfg["I"], cfg["L"]
@@ -71,7 +72,7 @@ def cpu_baseline(cfg, threads):
             vw[p + n + ".weight"], vw[p + n + ".bias"] = torch.ones(1024), torch.zeros(1024)
         vw[p + "mlp.fc1.weight"], vw[p + "mlp.fc1.bias"] = rn(4096, 1024), rn(4096)
         vw[p + "mlp.fc2.weight"], vw[p + "mlp.fc2.bias"] = rn(1024, 4096), rn(1024)
-    nl = 2
+    nl = 4
     lw = {"model.norm.weight": torch.ones(H)}
     for i in range(nl):
         p = f"model.layers.{i}."
@@ -239,7 +240,7 @@ def main():
                                                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
+                result["cpu_baseline"] = cpu_baseline(cfg, min(16, os.cpu_count() or 1))
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
