@@ -21,6 +21,7 @@
 #ifndef VALLEY_HIP_H
 #define VALLEY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,6 +58,21 @@ const char *vly_last_error(void);
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);
+
+/* Persistent stream-K variant of vly_gemm_bf16 (same math, epilogues and constraints): the
+ *   (tile, k-tile) iteration space is cut into equal contiguous ranges over CUs x occupancy persistent
+ *   workgroups, so small-M problems (configs[1]: M = 1312) keep every CU busy; partial tiles are
+ *   combined through fp32 slabs in `workspace` (>= vly_gemm_streamk_workspace_bytes(), 16-byte
+ *   aligned, ZEROED once by the caller, then owned by this entry point on one stream at a time).
+ *   `epoch` must be non-zero and different on every launch that shares the workspace.
+ *   Deterministic for a given shape, but the in-tile summation order depends on M (not
+ *   batch-invariant like vly_gemm_bf16). */
+int    vly_gemm_bf16_streamk(const void *A, const void *W, const float *bias, const float *residual, void *C,
+                             int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+                             int epilogue, int out_dtype, int tile_hint,
+                             void *workspace, size_t workspace_bytes, unsigned epoch, void *stream);
+size_t vly_gemm_streamk_workspace_bytes(void);
+int    vly_gemm_streamk_tile_for(int M, int N, int K);
 
 /* The tile configuration vly_gemm_bf16 picks for (M,N) when tile_hint == 0 (1/2/3 as above); lets a
  *   caller label launches when it profiles (bench.py's per-kernel roofline). */

@@ -48,7 +48,11 @@ def main():
         ("square 8192", 8192, 8192, 8192, 0),
     ]
     if quick:
-        shapes = shapes[:4] + shapes[-2:-1]
+        shapes = shapes[:4] + shapes[7:11] + shapes[-2:-1]
+    if "--gemm-only" in sys.argv:
+        only_gemm = True
+    else:
+        only_gemm = False
     for name, M, N, K, epi in shapes:
         a = torch.randn((M, K), device=d).to(torch.bfloat16)
         w = (torch.randn((N, K), device=d) * 0.05).to(torch.bfloat16)
@@ -61,9 +65,14 @@ def main():
         out = torch.empty((M, N // 2 if epi == 2 else N), device=d, dtype=torch.bfloat16)
         t = timeit(lambda: ops.gemm_mfma(a, w, bias, epilogue=epi, out=out, tile_hint=0))
         row["auto_TF"] = round(2.0 * M * N * K / t / 1e12, 1)
+        for tile in (1, 2, 3, 0):
+            t = timeit(lambda: ops.gemm_streamk(a, w, bias, epilogue=epi, out=out, tile_hint=tile))
+            row[f"sk{tile}_TF"] = round(2.0 * M * N * K / t / 1e12, 1)
         print(json.dumps(row), flush=True)
         del a, w
 
+    if only_gemm:
+        return
     # ViT attention
     for F in (32, 128):
         qkv = torch.randn((F * 257, 3072), device=d).to(torch.bfloat16)

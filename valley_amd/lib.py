@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 from . import build as _build
 
@@ -18,6 +18,10 @@ _SIGS = {
     "vly_last_error": (c_char_p, []),
     "vly_gemm_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemm_tile_for": (c_int, [c_int, c_int]),
+    "vly_gemm_bf16_streamk": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      _P, c_size_t, c_uint, _P]),
+    "vly_gemm_streamk_workspace_bytes": (c_size_t, []),
+    "vly_gemm_streamk_tile_for": (c_int, [c_int, c_int, c_int]),
     "vly_layernorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_rmsnorm": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_patchify": (c_int, [_P, _P, c_int, _P]),

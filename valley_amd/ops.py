@@ -5,6 +5,7 @@ libvalley_hip.so.  Every wrapper validates dtype/device/contiguity and raises on
 error codes."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -63,23 +64,50 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     od = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
     L = _lib.load()
     fn = getattr(L, fn_name)
-    rec = _RECORDER if fn_name == "vly_gemm_bf16" else None
+    rec = _RECORDER if fn_name in ("vly_gemm_bf16", "vly_gemm_bf16_streamk") else None
     if rec is not None:
-        tile = extra[0] or L.vly_gemm_tile_for(M, N)
+        sk = fn_name.endswith("streamk")
+        tile = extra[0] or (L.vly_gemm_streamk_tile_for(M, N, K) if sk else L.vly_gemm_tile_for(M, N))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
     if rec is not None:
         e1.record()
-        rec.append((f"gemm_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}>", 2.0 * M * N * K, e0, e1))
+        rec.append((f"{'gemm_sk_kernel' if sk else 'gemm_kernel'}<{TILE_NAMES[tile]}, {epilogue}, {od}>", 2.0 * M * N * K, e0, e1))
     _lib.check(rc, fn_name)
     return out
 
 
 def gemm_mfma(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
-    """MFMA tile kernel: out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual."""
+    """MFMA tile kernel (batch-invariant): out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual."""
     return _gemm_common("vly_gemm_bf16", a, w, bias, residual, epilogue, out_dtype, out, (tile_hint,))
+
+
+_SK_WS = {}          # device index -> [workspace tensor, epoch]
+
+
+def _sk_workspace(device):
+    ent = _SK_WS.get(device.index)
+    if ent is None:
+        nbytes = _lib.load().vly_gemm_streamk_workspace_bytes()
+        ent = [torch.zeros((nbytes + 15) // 16 * 4, dtype=torch.int32, device=device), 0]
+        _SK_WS[device.index] = ent
+    ent[1] = ent[1] % 0xFFFFFFF0 + 1
+    return ent[0], ent[1]
+
+
+def sk_error_flag(device) -> int:
+    """Non-zero if a stream-K owner ever gave up waiting for a contributor (should never happen)."""
+    ent = _SK_WS.get(torch.device(device).index)
+    return 0 if ent is None else int(ent[0][4000].item())
+
+
+def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
+    """Persistent stream-K MFMA kernel: same contract as gemm_mfma, balanced over all CUs."""
+    ws, epoch = _sk_workspace(a.device)
+    return _gemm_common("vly_gemm_bf16_streamk", a, w, bias, residual, epilogue, out_dtype, out,
+                        (tile_hint, ws.data_ptr(), ws.numel() * 4, epoch))
 
 
 def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None):
@@ -87,11 +115,17 @@ def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
 
+GEMM_MODE = os.environ.get("VALLEY_GEMM_MODE", "streamk")     # "streamk" (fast) | "tiles" (batch-invariant)
+
+
 def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
-    """Dispatch on M: <= 8 rows stream the weights (HBM-bound), otherwise MFMA tiles."""
+    """Dispatch on M: <= 8 rows stream the weights (HBM-bound); otherwise MFMA — persistent stream-K by
+    default, whole-tile scheduling when VALLEY_GEMM_MODE=tiles (bit-identical across batch sizes)."""
     if a.shape[0] <= 8:
         return gemv(a, w, bias, residual, epilogue, out_dtype, out)
-    return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
+    if GEMM_MODE == "tiles":
+        return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
+    return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_f32: bool = False,

@@ -140,7 +140,7 @@ class HipCLIPVisionTower:
         F = frames.shape[0]
         ws = self._workspace(F)
         ops.patchify(frames, out=ws["cols"])
-        ops.gemm_mfma(ws["cols"], self.w_patch, out=ws["patch"])
+        ops.gemm(ws["cols"], self.w_patch, out=ws["patch"])
         return ops.vit_embed_ln(ws["patch"], self.cls, self.pos, self.pre_g, self.pre_b, F, self.config.layer_norm_eps, out=h)
 
     def layer_forward(self, h: torch.Tensor, L: Dict[str, torch.Tensor], F: int):
@@ -148,12 +148,12 @@ class HipCLIPVisionTower:
         ws = self._workspace(F)
         eps = self.config.layer_norm_eps
         ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
-        ops.gemm_mfma(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
-        ops.gemm_mfma(ws["att"], L["w_o"], L["b_o"], residual=h, out=h)
+        ops.gemm(ws["att"], L["w_o"], L["b_o"], residual=h, out=h)
         ops.layernorm(h, L["ln2_g"], L["ln2_b"], eps, out=ws["x"])
-        ops.gemm_mfma(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
-        ops.gemm_mfma(ws["mlp"], L["w_fc2"], L["b_fc2"], residual=h, out=h)
+        ops.gemm(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
+        ops.gemm(ws["mlp"], L["w_fc2"], L["b_fc2"], residual=h, out=h)
 
     def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: int = 256,
                keep_all: bool = False):
