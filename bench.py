@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=list(CONFIGS))
     ap.add_argument("--prefill", default="sharded", choices=["sharded", "replicated"])
+    ap.add_argument("--decode", type=int, default=0, metavar="N",
+                    help="instead of the prefill step: prefill once, then time N greedy hipGraph decode steps (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (rocprof runs)")
     args = ap.parse_args()
@@ -154,6 +156,41 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     stage_events = []
+
+    if args.decode:
+        # configs[4]: T-frame visual prefix, B=1, N generated tokens through the captured decode step
+        from valley_amd.decode import DecodeSession
+        n_new = args.decode
+        dcache = mm.llama.new_cache(1, S + n_new + 8)
+        out = model(input_ids=input_ids[:1], images=frames[:1], past_key_values=dcache, use_cache=True)
+        sess = DecodeSession(mm.llama, dcache, use_graph=True)
+        sess.begin(out.logits[:, -1].argmax(-1))
+        for _ in range(args.warmup):
+            sess.step()
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(n_new):
+            sess.step()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms_tok = e0.elapsed_time(e1) / n_new
+        wbytes = 2.0 * (L * (4 * H * H + 3 * H * I) + H * mm.llama.Vpad)
+        ctx_mid = S + args.warmup + n_new / 2
+        kvbytes = 2.0 * 2 * L * H * ctx_mid
+        ach = (wbytes + kvbytes) / (ms_tok * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "decode tokens/sec (KV-cache, greedy, hipGraph step)", "value": round(1e3 / ms_tok, 2), "unit": "tokens/s",
+            "n_gpus": 1, "steps": n_new, "warmup": args.warmup, "ms_per_step": round(ms_tok, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg['label']} -> autoregressive decode, B=1, prefix S={S}, {n_new} tokens", "name": args.config},
+            "wall_ms_per_token": round(wall / n_new * 1e3, 4),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                         "traffic": None, "bytes_per_token": int(wbytes + kvbytes),
+                         "note": "algorithmic bytes = all matmul weights once (bf16) + K and V of the mean context"}}), flush=True)
+        return
 
     def step(record):
         e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)

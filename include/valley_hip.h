@@ -120,18 +120,23 @@ int vly_embed_splice(const int32_t *row_map, const void *embed_bf16, const void 
  *   position of row s = past_len + s (independent of padding).  cos/sin: fp32 tables
  *   [ctx_max, 64] indexed by absolute position (built by the host exactly as
  *   hf:llama/modeling_llama.py:95-124).  Rotation :127-157, KV append :261-262 (legacy tuple cat
- *   at the pinned commit). */
+ *   at the pinned commit).
+ *   past_len_dev (nullable): device int32 that overrides past_len at execution time, so that a
+ *   hipGraph-captured decode step can be replayed while the position advances on the device. */
 int vly_rope_kv(void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
-                const float *sin_table, int B, int S, int heads, int past_len, int ctx_max, void *stream);
+                const float *sin_table, int B, int S, int heads, int past_len, const int32_t *past_len_dev,
+                int ctx_max, void *stream);
 
 /* Causal self-attention over the KV cache, head_dim 128:
  *   q from qkv bf16 [B*S, 3*heads*128] (first third), K/V from the caches, kv_len = past_len+S.
- *   key_valid uint8 [B, kv_len] or NULL (1 = attend; the padding half of HF's additive mask).
- *   out bf16 [B*S, heads*128].  Works for S == 1 (decode) too.
+ *   key_valid uint8 [B, key_valid_stride >= kv_len] or NULL (1 = attend; the padding half of HF's
+ *   additive mask).  out bf16 [B*S, heads*128].  S == 1 takes the HBM-bound decode kernel (one
+ *   workgroup per head streams the head's K and V once; serve/model_worker.py:380-387).
+ *   past_len_dev: as in vly_rope_kv.
  *   hf:llama/modeling_llama.py:191-213, mask = causal AND padding (:386-397 / masking_utils). */
 int vly_llama_attention(const void *qkv_bf16, const void *kcache_bf16, const void *vcache_bf16,
-                        const uint8_t *key_valid, void *out_bf16, int B, int S, int heads,
-                        int past_len, int ctx_max, void *stream);
+                        const uint8_t *key_valid, int key_valid_stride, void *out_bf16, int B, int S,
+                        int heads, int past_len, const int32_t *past_len_dev, int ctx_max, void *stream);
 
 /* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
@@ -145,8 +150,12 @@ int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *
  *   projector has to see every token, valley_model.py:190,209). */
 int vly_cast_f32_bf16(const float *x, void *y_bf16, long n, void *stream);
 
-/* argmax over the last dim of fp32 [M,N] -> int32 [M].  serve/model_worker.py:389-391. */
-int vly_argmax(const float *x, int32_t *idx, int M, int N, void *stream);
+/* p[i] += delta for i < n (the device-side position counter of a captured decode step). */
+int vly_incr_i32(int32_t *p, int n, int delta, void *stream);
+
+/* argmax over the last dim of fp32 [M,N] (row stride ld >= N) -> int32 [M]; first maximal index.
+ *   serve/model_worker.py:389-391. */
+int vly_argmax(const float *x, int32_t *idx, int M, int N, int ld, void *stream);
 
 #ifdef __cplusplus
 }

@@ -171,7 +171,8 @@ constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row str
 
 __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
                                                          const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
-                                                         uint16_t* __restrict__ out, int S, int heads, int past, int ctx_max) {
+                                                         uint16_t* __restrict__ out, int S, int heads, int past,
+                                                         const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
     __shared__ __attribute__((aligned(16))) char smem[LK_BYTES + 128 * LVT_STRIDE * 2];
     char* sK = smem;
     uint16_t* sVt = (uint16_t*)(smem + LK_BYTES);
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
     const int l15 = lane & 15, g = lane >> 4;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int Hq = heads * 128;
+    if (past_dev) past = min(*past_dev, ctx_max - S);
     const int kv_len = past + S;
 
     const int q = qb * 64 + wave * 16 + l15;             // query row inside this call
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
 
     const uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
     const uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
-    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_len : nullptr;
+    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
 
     const int q_last = min(qb * 64 + 63, S - 1);
     const int kv_end = min(past + q_last + 1, kv_len);
@@ -317,6 +319,93 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode attention (S = 1): one workgroup per (head, batch), HBM-bound on the KV cache
+// (kv_len * 512 bytes per head).  Phase 1: thread <-> key, q.k over 128 d with 16-byte K loads, scores
+// to LDS; phase 2: block max / sum; phase 3: 16 threads share a V row (8 d each), 16 keys per pass,
+// fp32 partial sums reduced through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int DEC_MAX_CTX = 8192;
+
+__global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
+                                                          const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
+                                                          uint16_t* __restrict__ out, int heads, int past,
+                                                          const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
+    __shared__ float sc[DEC_MAX_CTX];
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float acc_s[16][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int Hq = heads * 128;
+    if (past_dev) past = min(*past_dev, ctx_max - 1);
+    const int kv_len = past + 1;
+    const uint16_t* qp = qkv + (size_t)b * 3 * Hq + h * 128;
+    if (tid < 128) qs[tid] = bf16_to_f32(qp[tid]) * (0.08838834764831845f * LOG2E);
+    __syncthreads();
+    const uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
+
+    float m = NEG_BIG;
+    for (int j = tid; j < kv_len; j += 256) {
+        float s = NEG_BIG;
+        if (!kvld || kvld[j]) {
+            const u32x4* kr = (const u32x4*)(kbase + (size_t)j * 128);
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const u32x4 kk = kr[c];
+                const f32x4 q0 = *(const f32x4*)(qs + 8 * c), q1 = *(const f32x4*)(qs + 8 * c + 4);
+                a = fmaf(__uint_as_float(kk[0] << 16), q0[0], a); a = fmaf(__uint_as_float(kk[0] & 0xffff0000u), q0[1], a);
+                a = fmaf(__uint_as_float(kk[1] << 16), q0[2], a); a = fmaf(__uint_as_float(kk[1] & 0xffff0000u), q0[3], a);
+                a = fmaf(__uint_as_float(kk[2] << 16), q1[0], a); a = fmaf(__uint_as_float(kk[2] & 0xffff0000u), q1[1], a);
+                a = fmaf(__uint_as_float(kk[3] << 16), q1[2], a); a = fmaf(__uint_as_float(kk[3] & 0xffff0000u), q1[3], a);
+            }
+            s = a;
+        }
+        sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int j = tid; j < kv_len; j += 256) {
+        const float p = exp2f(sc[j] - m);
+        sc[j] = p;
+        l += p;
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+
+    // phase 3: thread = (key group kg = tid >> 4, d chunk dc = tid & 15 -> d = 8*dc .. 8*dc+7)
+    const int kg = tid >> 4, dc = tid & 15;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    for (int j = kg; j < kv_len; j += 16) {
+        const float p = sc[j];
+        const u32x4 vv = *(const u32x4*)(vbase + (size_t)j * 128 + 8 * dc);
+        o[0] = fmaf(p, __uint_as_float(vv[0] << 16), o[0]); o[1] = fmaf(p, __uint_as_float(vv[0] & 0xffff0000u), o[1]);
+        o[2] = fmaf(p, __uint_as_float(vv[1] << 16), o[2]); o[3] = fmaf(p, __uint_as_float(vv[1] & 0xffff0000u), o[3]);
+        o[4] = fmaf(p, __uint_as_float(vv[2] << 16), o[4]); o[5] = fmaf(p, __uint_as_float(vv[2] & 0xffff0000u), o[5]);
+        o[6] = fmaf(p, __uint_as_float(vv[3] << 16), o[6]); o[7] = fmaf(p, __uint_as_float(vv[3] & 0xffff0000u), o[7]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc_s[kg][8 * dc + i] = o[i];
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += acc_s[k2][tid];
+        out[(size_t)b * Hq + h * 128 + tid] = f32_to_bf16(t / l);
+    }
+}
+
 }  // namespace
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
@@ -326,14 +415,25 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
 }
 
 extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const void* vcache, const uint8_t* key_valid,
-                                   void* out, int B, int S, int heads, int past_len, int ctx_max, void* stream) {
+                                   int key_valid_stride, void* out, int B, int S, int heads, int past_len,
+                                   const int32_t* past_len_dev, int ctx_max, void* stream) {
     if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || past_len + S > ctx_max || B > 65535 || heads > 65535 ||
         ((uintptr_t)qkv & 15) || ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) || ((uintptr_t)out & 7)) {
         vly_set_error("vly_llama_attention: bad args B=%d S=%d heads=%d past=%d ctx_max=%d", B, S, heads, past_len, ctx_max);
         return -22;
     }
+    if (key_valid && key_valid_stride < past_len + S) {
+        vly_set_error("vly_llama_attention: key_valid_stride %d < kv_len %d", key_valid_stride, past_len + S);
+        return -22;
+    }
+    if (S == 1 && ctx_max <= DEC_MAX_CTX) {
+        hipLaunchKernelGGL(decode_attn_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                           (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out, heads, past_len,
+                           past_len_dev, key_valid_stride, ctx_max);
+        return vly_check_launch("vly_llama_attention(decode)");
+    }
     hipLaunchKernelGGL(llama_attn_kernel, dim3((S + 63) / 64, heads, B), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
-                       S, heads, past_len, ctx_max);
+                       S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
     return vly_check_launch("vly_llama_attention");
 }

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 4;           // 4 waves, one row each
+constexpr int ROWS_PER_BLOCK = 2;           // 2 waves per block, one row each (more blocks for small M)
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm / RMSNorm: fp32 [M,D] -> bf16 (and optionally fp32).  One wave per row, the row is
@@ -15,7 +15,7 @@ constexpr int ROWS_PER_BLOCK = 4;           // 4 waves, one row each
 // register copy, like torch), written as 8-byte bf16x4.  bytes/row = 4D read + 2D (+4D) written.
 // ---------------------------------------------------------------------------------------------
 template <int NV, bool RMS>
-__global__ void __launch_bounds__(256) norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(128) norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, uint16_t* __restrict__ y16,
                                                    float* __restrict__ y32, int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -83,7 +83,7 @@ int launch_norm(const float* x, const float* gamma, const float* beta, void* y16
         vly_set_error("%s: unsupported shape/alignment M=%d D=%d", name, M, D);
         return -22;
     }
-    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     const int nv = (D / 4 + 63) / 64;
 #define VLY_NORM(NV) hipLaunchKernelGGL((norm_kernel<NV, RMS>), grid, block, 0, st, x, gamma, beta, (uint16_t*)y16, y32, M, D, eps)
     if (nv <= 4) VLY_NORM(4);
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) embed_splice_kernel(const int32_t* __rest
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
                                                       const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                      int B, int S, int heads, int past, int ctx_max) {
+                                                      int B, int S, int heads, int past, const int32_t* __restrict__ past_dev, int ctx_max) {
     const int lane = threadIdx.x & 63;
     const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (b*S + s)*heads + h
     if (unit >= (long)B * S * heads) return;
@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv
     const long rs = unit / heads;
     const int s = (int)(rs % S), b = (int)(rs / S);
     const int Hq = heads * 128;
+    if (past_dev) past = min(*past_dev, ctx_max - S);       // device-side position (hipGraph replay); clamp = no OOB ever
     const int pos = past + s;
     const float cs = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
     uint16_t* q = qkv + (size_t)rs * 3 * Hq + h * 128;
@@ -266,10 +267,10 @@ __global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ x, 
 }
 
 // argmax over rows of fp32 [M,N]; first maximal index (torch.argmax tie rule on CPU).
-__global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N) {
+__global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N, int ld) {
     __shared__ float sv[4];
     __shared__ int si[4];
-    const float* r = x + (size_t)blockIdx.x * N;
+    const float* r = x + (size_t)blockIdx.x * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < N; i += 256) {
@@ -340,20 +341,20 @@ extern "C" int vly_embed_splice(const int32_t* row_map, const void* embed, const
 }
 
 extern "C" int vly_rope_kv(void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
-                           int B, int S, int heads, int past_len, int ctx_max, void* stream) {
+                           int B, int S, int heads, int past_len, const int32_t* past_len_dev, int ctx_max, void* stream) {
     if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || past_len + S > ctx_max) {
         vly_set_error("vly_rope_kv: bad args B=%d S=%d heads=%d past=%d ctx_max=%d", B, S, heads, past_len, ctx_max);
         return -22;
     }
     const long units = (long)B * S * heads;
     hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
-                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, B, S, heads, past_len, ctx_max);
+                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, B, S, heads, past_len, past_len_dev, ctx_max);
     return vly_check_launch("vly_rope_kv");
 }
 
-extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, void* stream) {
-    if (M <= 0 || N <= 0) { vly_set_error("vly_argmax: bad args"); return -22; }
-    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, idx, N);
+extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, int ld, void* stream) {
+    if (M <= 0 || N <= 0 || ld < N) { vly_set_error("vly_argmax: bad args"); return -22; }
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, idx, N, ld);
     return vly_check_launch("vly_argmax");
 }
 
@@ -362,4 +363,15 @@ extern "C" int vly_cast_f32_bf16(const float* x, void* y, long n, void* stream) 
     const long n8 = n / 8;
     hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, n8);
     return vly_check_launch("vly_cast_f32_bf16");
+}
+
+__global__ void incr_kernel(int32_t* p, int n, int delta) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) p[i] += delta;
+}
+
+extern "C" int vly_incr_i32(int32_t* p, int n, int delta, void* stream) {
+    if (!p || n <= 0) { vly_set_error("vly_incr_i32: bad args"); return -22; }
+    hipLaunchKernelGGL(incr_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, n, delta);
+    return vly_check_launch("vly_incr_i32");
 }

@@ -1,0 +1,94 @@
+"""hipGraph-captured autoregressive decode step (BASELINE.json configs[4]; the loop of
+valley/serve/model_worker.py:380-394 and of HF ``generate`` behind valley_model.py:432).
+
+One decode step = embedding gather of the current token -> L x [RMSNorm, q|k|v GEMV, RoPE + KV append,
+decode attention, o GEMV(+res), RMSNorm, gate/up GEMV with SwiGLU, down GEMV(+res)] -> RMSNorm ->
+lm_head GEMV -> argmax -> position += 1.  Every kernel is HBM-bound weight/KV streaming, ~8 launches
+per layer: launched eagerly from Python the step would be host-bound (>300 launches x ~15 us), so the
+step is captured ONCE into a hipGraph and replayed.  Static shapes are what capture needs: the KV
+cache is pre-allocated to ctx_max, and the only thing that changes between replays — the position —
+lives on the device (``pos``) and is read by vly_rope_kv / vly_llama_attention through their
+``past_len_dev`` argument."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .llama import HipKVCache, HipLlama
+
+
+class DecodeSession:
+    def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True):
+        self.ll, self.cache = llama, cache
+        B, d = cache.batch, llama.device
+        if B > 8:
+            raise ValueError("decode sessions stream weights with the GEMV kernel: batch <= 8")
+        self.B = B
+        self.tok = torch.zeros((B,), dtype=torch.int32, device=d)          # token fed to the next step
+        self.pos = torch.zeros((1,), dtype=torch.int32, device=d)          # == cache.seq_len, on the device
+        self.h = torch.empty((B, llama.H), dtype=torch.float32, device=d)
+        bf = torch.bfloat16
+        self.x = torch.empty((B, llama.H), dtype=bf, device=d)
+        self.qkv = torch.empty((B, 3 * llama.H), dtype=bf, device=d)
+        self.att = torch.empty((B, llama.H), dtype=bf, device=d)
+        self.mlp = torch.empty((B, llama.I), dtype=bf, device=d)
+        self.logits = torch.empty((B, llama.Vpad), dtype=torch.float32, device=d)
+        self.use_graph = use_graph
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _enqueue_step(self):
+        ll, c = self.ll, self.cache
+        B = self.B
+        ops.embed_splice(self.tok, ll.embed, None, out=self.h)
+        for li in range(ll.L):
+            L = ll.layers[li]
+            ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
+            ops.gemv(self.x, L["w_qkv"], out=self.qkv)
+            ops.rope_kv(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, B, 1, ll.heads, 0, past_dev=self.pos)
+            ops.llama_attention(self.qkv, c.k[li], c.v[li], c.key_valid, B, 1, ll.heads, 0, out=self.att, past_dev=self.pos)
+            ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
+            ops.rmsnorm(self.h, L["ln2"], ll.eps, out=self.x)
+            ops.gemv(self.x, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)
+            ops.gemv(self.mlp, L["w_down"], residual=self.h, out=self.h)
+        ops.rmsnorm(self.h, ll.norm, ll.eps, out=self.x)
+        ops.gemv(self.x, ll.lm_head, out=self.logits)
+        # greedy next token straight into the input slot of the next step (the V-padding columns of the
+        # lm_head buffer are excluded through the row stride)
+        ops.argmax(self.logits[:, :ll.V], out=self.tok)
+        ops.incr_i32(self.pos, 1)
+
+    def begin(self, first_token: torch.Tensor):
+        """Call after the prefill filled ``cache``: sets the device position and the first input token."""
+        self.pos.fill_(self.cache.seq_len)
+        self.tok.copy_(first_token.to(torch.int32).view(-1))
+        if self.cache.key_valid is not None:
+            self.cache.key_valid[:, self.cache.seq_len:] = 1           # generated positions are always attended
+        if self.use_graph and self.graph is None:
+            # warm-up outside capture on a side stream (module loading, lazy init), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            pos0, tok0 = self.pos.clone(), self.tok.clone()
+            with torch.cuda.stream(s):
+                self._enqueue_step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.pos.copy_(pos0)
+            self.tok.copy_(tok0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_step()
+            self.graph = g
+
+    def step(self) -> torch.Tensor:
+        """Run one decode step; returns the (device) int32 [B] buffer holding the newly chosen token.
+        ``self.logits[:, :V]`` holds that step's logits (for temperature sampling on the host side)."""
+        if self.cache.seq_len + 1 > self.cache.ctx_max:
+            raise ValueError("KV cache full")
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue_step()
+        self.cache.seq_len += 1
+        return self.tok

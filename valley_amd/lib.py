@@ -29,10 +29,11 @@ _SIGS = {
     "vly_vit_attention": (c_int, [_P, _P, c_int, _P]),
     "vly_pool_tokens": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vly_embed_splice": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
-    "vly_rope_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "vly_llama_attention": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_rope_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "vly_llama_attention": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "vly_argmax": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
 }
 EXPORTS = tuple(_SIGS)

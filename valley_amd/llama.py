@@ -144,9 +144,7 @@ class HipLlama:
             raise ValueError("cache batch mismatch")
         M = B * S
         ws = self._workspace(M)
-        kv = None
-        if cache.key_valid is not None:
-            kv = cache.key_valid[:, :past + S].contiguous()
+        kv = cache.key_valid                                # uint8 [B, ctx_max] or None (row stride = ctx_max)
         nl = self.L if n_layers is None else n_layers
         for li in range(nl):
             L = self.layers[li]

@@ -115,17 +115,70 @@ def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
 
-GEMM_MODE = os.environ.get("VALLEY_GEMM_MODE", "streamk")     # "streamk" (fast) | "tiles" (batch-invariant)
+# "tuned"  (default): per (M,N,K,epilogue,out dtype) pick the fastest of {whole-tile, stream-K} x {256x256,
+#                      128x128, 256x128} by timing each once on first use (measure, don't guess);
+# "tiles":  whole-tile kernel with its static heuristic — bit-identical results across batch sizes;
+# "streamk": always the persistent stream-K kernel.
+GEMM_MODE = os.environ.get("VALLEY_GEMM_MODE", "tuned")
+_TUNED = {}
+
+
+def _tune(key, a, w, bias, residual, epilogue, out):
+    """Time every candidate on the real operands (outputs go to a scratch tensor so that an in-place
+    residual update is not applied more than once) and remember the winner."""
+    scratch = torch.empty_like(out)
+    best, best_t = ("tile", 0), float("inf")
+    cands = [("tile", t) for t in (1, 2, 3)] + [("sk", t) for t in (1, 2, 3)]
+    for kind, t in cands:
+        fn = gemm_mfma if kind == "tile" else gemm_streamk
+        try:
+            fn(a, w, bias, residual, epilogue, out.dtype, scratch, t)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn(a, w, bias, residual, epilogue, out.dtype, scratch, t)
+            e1.record()
+            torch.cuda.synchronize()
+            dt = e0.elapsed_time(e1)
+        except _lib.ValleyHipError:
+            continue
+        if dt < best_t:
+            best, best_t = (kind, t), dt
+    _TUNED[key] = best
+    return best
 
 
 def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
-    """Dispatch on M: <= 8 rows stream the weights (HBM-bound); otherwise MFMA — persistent stream-K by
-    default, whole-tile scheduling when VALLEY_GEMM_MODE=tiles (bit-identical across batch sizes)."""
-    if a.shape[0] <= 8:
+    """Dispatch on M: <= 8 rows stream the weights (HBM-bound); otherwise an MFMA kernel chosen by
+    GEMM_MODE (see above)."""
+    _chk(a, torch.bfloat16, "a", contiguous=False)
+    M = a.shape[0]
+    if M <= 8:
         return gemv(a, w, bias, residual, epilogue, out_dtype, out)
-    if GEMM_MODE == "tiles":
+    if GEMM_MODE == "tiles" or tile_hint:
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
-    return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
+    if GEMM_MODE == "streamk":
+        return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, 0)
+    N, K = w.shape
+    if out is None:
+        out = torch.empty((M, N // 2 if epilogue == EPI_SWIGLU else N), dtype=out_dtype, device=a.device)
+    key = (M, N, K, epilogue, out.dtype, bias is not None, residual is not None)
+    choice = _TUNED.get(key)
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing():
+            choice = ("tile", 0)
+        else:
+            rec = _RECORDER
+            set_recorder(None)
+            try:
+                choice = _tune(key, a, w, bias, residual, epilogue, out)
+            finally:
+                set_recorder(rec)
+    kind, t = choice
+    if kind == "tile":
+        return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t)
+    return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, t)
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_f32: bool = False,
@@ -192,20 +245,21 @@ def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN) -> t
     return out
 
 
-def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[torch.Tensor]) -> torch.Tensor:
+def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[torch.Tensor], out=None) -> torch.Tensor:
     _chk(row_map, torch.int32, "row_map")
     _chk(embed, torch.bfloat16, "embed")
     R, H = row_map.numel(), embed.shape[1]
     if visual is not None:
         _chk(visual, torch.bfloat16, "visual")
-    out = torch.empty((R, H), dtype=torch.float32, device=embed.device)
+    if out is None:
+        out = torch.empty((R, H), dtype=torch.float32, device=embed.device)
     rc = _lib.load().vly_embed_splice(row_map.data_ptr(), embed.data_ptr(), _ptr(visual), out.data_ptr(), R, H, _stream())
     _lib.check(rc, "vly_embed_splice")
     return out
 
 
 def rope_kv(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
-            B: int, S: int, heads: int, past_len: int):
+            B: int, S: int, heads: int, past_len: int, past_dev: Optional[torch.Tensor] = None):
     _chk(qkv, torch.bfloat16, "qkv")
     _chk(kcache, torch.bfloat16, "kcache")
     _chk(vcache, torch.bfloat16, "vcache")
@@ -213,30 +267,35 @@ def rope_kv(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: 
     assert tuple(kcache.shape) == (B, heads, ctx_max, 128) and vcache.shape == kcache.shape
     assert cos.shape[0] >= past_len + S and cos.shape[1] == 64 and cos.dtype == torch.float32 and cos.is_contiguous()
     rc = _lib.load().vly_rope_kv(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                 B, S, heads, past_len, ctx_max, _stream())
+                                 B, S, heads, past_len, _ptr(past_dev), ctx_max, _stream())
     _lib.check(rc, "vly_rope_kv")
 
 
 def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, key_valid: Optional[torch.Tensor],
-                    B: int, S: int, heads: int, past_len: int, out=None) -> torch.Tensor:
+                    B: int, S: int, heads: int, past_len: int, out=None, past_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(qkv, torch.bfloat16, "qkv")
     ctx_max = kcache.shape[2]
+    kv_stride = 0
     if key_valid is not None:
         _chk(key_valid, torch.uint8, "key_valid")
-        assert tuple(key_valid.shape) == (B, past_len + S)
+        assert key_valid.shape[0] == B and key_valid.shape[1] >= past_len + S
+        kv_stride = key_valid.stride(0)
     if out is None:
         out = torch.empty((B * S, heads * 128), dtype=torch.bfloat16, device=qkv.device)
-    rc = _lib.load().vly_llama_attention(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), _ptr(key_valid),
-                                         out.data_ptr(), B, S, heads, past_len, ctx_max, _stream())
+    rc = _lib.load().vly_llama_attention(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), _ptr(key_valid), kv_stride,
+                                         out.data_ptr(), B, S, heads, past_len, _ptr(past_dev), ctx_max, _stream())
     _lib.check(rc, "vly_llama_attention")
     return out
 
 
-def argmax(x: torch.Tensor) -> torch.Tensor:
-    _chk(x, torch.float32, "x")
+def argmax(x: torch.Tensor, out=None) -> torch.Tensor:
+    """x fp32 [M,N] (row stride may exceed N) -> int32 [M]."""
+    _chk(x, torch.float32, "x", contiguous=False)
     M, N = x.shape
-    out = torch.empty((M,), dtype=torch.int32, device=x.device)
-    rc = _lib.load().vly_argmax(x.data_ptr(), out.data_ptr(), M, N, _stream())
+    assert x.stride(1) == 1
+    if out is None:
+        out = torch.empty((M,), dtype=torch.int32, device=x.device)
+    rc = _lib.load().vly_argmax(x.data_ptr(), out.data_ptr(), M, N, x.stride(0), _stream())
     _lib.check(rc, "vly_argmax")
     return out
 
@@ -247,3 +306,9 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     rc = _lib.load().vly_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream())
     _lib.check(rc, "vly_cast_f32_bf16")
     return y
+
+
+def incr_i32(p: torch.Tensor, delta: int = 1):
+    _chk(p, torch.int32, "p")
+    rc = _lib.load().vly_incr_i32(p.data_ptr(), p.numel(), delta, _stream())
+    _lib.check(rc, "vly_incr_i32")

@@ -335,34 +335,54 @@ class ValleyLlamaForCausalLM:
 
     @torch.no_grad()
     def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens: int = 64, do_sample: bool = False,
-                 temperature: float = 1.0, stopping_criteria=None, eos_token_id=None, **kw):
+                 temperature: float = 1.0, stopping_criteria=None, eos_token_id=None, use_graph=True, **kw):
         """Prefill + per-token KV decode (the loop of serve/model_worker.py:371-394; the reference's CLI
         path reaches the same through HF ``generate``, valley_model.py:432).  Greedy when not sampling or
-        temperature < 1e-4, else temperature softmax + multinomial."""
+        temperature < 1e-4, else temperature softmax + multinomial.  Decode steps run through a
+        hipGraph-captured DecodeSession (``use_graph=True``), eagerly through it (False) or through the
+        generic forward (None)."""
         input_ids = input_ids.to(self.device)
         B, S = input_ids.shape
         ctx = min(getattr(self.config, "max_position_embeddings", 2048), S + max_new_tokens)
         cache = self.model.llama.new_cache(B, max(ctx, S + 1))
+        out = self.forward(input_ids=input_ids, images=images, attention_mask=attention_mask, past_key_values=cache,
+                           use_cache=True)
+        greedy = not (do_sample and temperature >= 1e-4)
+        last = out.logits[:, -1, :].contiguous()
+        token = ops.argmax(last).to(torch.long) if greedy else \
+            torch.multinomial(torch.softmax(last / temperature, dim=-1), num_samples=1).view(B)
+        seq = torch.cat([input_ids, token[:, None]], dim=1)
+        if B > 8:
+            use_graph = None                                 # GEMV decode path is for <= 8 sequences
+        sess = None
+        if use_graph is not None:
+            from .decode import DecodeSession
+            sess = DecodeSession(self.model.llama, cache, use_graph=bool(use_graph))
+            sess.begin(token)
         mask = attention_mask
-        out = self.forward(input_ids=input_ids, images=images, attention_mask=mask, past_key_values=cache, use_cache=True)
-        seq = input_ids
-        for _ in range(max_new_tokens):
-            last = out.logits[:, -1, :].contiguous()
-            if do_sample and temperature >= 1e-4:
-                probs = torch.softmax(last / temperature, dim=-1)
-                token = torch.multinomial(probs, num_samples=1).view(B)
-            else:
-                token = ops.argmax(last).to(torch.long)
-            seq = torch.cat([seq, token[:, None]], dim=1)
+        for _ in range(max_new_tokens - 1):
             if eos_token_id is not None and bool((token == eos_token_id).all()):
                 break
             if stopping_criteria is not None and all(bool(c(seq, None)) for c in stopping_criteria):
                 break
             if cache.seq_len + 1 > cache.ctx_max:
                 break
-            if mask is not None:
-                mask = torch.cat([mask.to(self.device), torch.ones((B, 1), dtype=mask.dtype, device=self.device)], dim=1)
-            out = self.forward(input_ids=token[:, None], attention_mask=mask, past_key_values=cache, use_cache=True)
+            if sess is not None:
+                nxt = sess.step()
+                if greedy:
+                    token = nxt.to(torch.long).clone()
+                else:
+                    probs = torch.softmax(sess.logits[:, :self.model.llama.V] / temperature, dim=-1)
+                    token = torch.multinomial(probs, num_samples=1).view(B)
+                    sess.tok.copy_(token.to(torch.int32))
+            else:
+                if mask is not None:
+                    mask = torch.cat([mask.to(self.device), torch.ones((B, 1), dtype=mask.dtype, device=self.device)], dim=1)
+                out = self.forward(input_ids=token[:, None], attention_mask=mask, past_key_values=cache, use_cache=True)
+                last = out.logits[:, -1, :].contiguous()
+                token = ops.argmax(last).to(torch.long) if greedy else \
+                    torch.multinomial(torch.softmax(last / temperature, dim=-1), num_samples=1).view(B)
+            seq = torch.cat([seq, token[:, None]], dim=1)
         return seq
 
     # -- tokenizer / prompt glue -----------------------------------------------------------------------
