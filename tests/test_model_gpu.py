@@ -202,7 +202,7 @@ def test_vit_frame_order_equivariance_full_size(monkeypatch):
     c = tower.encode(frames[perm], -2)
     r = float((c - b).norm() / b.norm())
     print("tuned vs tiles rel-L2", r)
-    assert r < 2e-3
+    assert r < 5e-3
     assert ops.sk_error_flag("cuda:0") == 0
 
 

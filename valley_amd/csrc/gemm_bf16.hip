@@ -216,6 +216,8 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         case 1: return launch_tile<256, 256, 128, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
         case 2: return launch_tile<128, 128, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
         case 3: return launch_tile<256, 128, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        case 4: return launch_tile<128, 256, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        case 5: return launch_tile<192, 256, 96, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
         default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
     }
 }

@@ -309,6 +309,8 @@ extern "C" int vly_gemm_bf16_streamk(const void* A, const void* W, const float* 
         case 1: return launch_sk<256, 256, 128, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
         case 2: return launch_sk<128, 128, 64, 64, 2>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
         case 3: return launch_sk<256, 128, 64, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
+        case 4: return launch_sk<128, 256, 64, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
+        case 5: return launch_sk<192, 256, 96, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
         default: vly_set_error("vly_gemm_bf16_streamk: bad tile_hint %d", tile_hint); return -22;
     }
 }

@@ -20,7 +20,8 @@ POOL_MEAN, POOL_MAX = 0, 1
 # Optional per-launch recorder (bench.py's live per-kernel timing): a list that receives
 # (kernel_label, algorithmic_flops, start_event, end_event) for every MFMA GEMM launch.
 _RECORDER = None
-TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64"}
+TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64", 4: "128, 256, 64, 64",
+              5: "192, 256, 96, 64"}
 
 
 def set_recorder(rec):
@@ -128,7 +129,7 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     residual update is not applied more than once) and remember the winner."""
     scratch = torch.empty_like(out)
     best, best_t = ("tile", 0), float("inf")
-    cands = [("tile", t) for t in (1, 2, 3)] + [("sk", t) for t in (1, 2, 3)]
+    cands = [("tile", t) for t in (1, 2, 3, 4, 5)] + [("sk", t) for t in (1, 2, 3, 4, 5)]
     for kind, t in cands:
         fn = gemm_mfma if kind == "tile" else gemm_streamk
         try:
