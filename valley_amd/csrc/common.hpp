@@ -50,3 +50,4 @@ VLY_DEVICE void glds16(const void* gsrc, void* lds_wave_base) {
 
 void vly_set_error(const char* fmt, ...);
 int vly_check_launch(const char* what);
+int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n);

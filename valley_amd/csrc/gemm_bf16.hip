@@ -17,6 +17,15 @@
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
+// Bytes that must come from beyond an XCD's L2 under each tile order (8 XCDs, each owning a contiguous
+// run of tiles): n-fastest -> A once + W min(8, tiles_m) times; m-fastest -> W once + A min(8, tiles_n) times.
+int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n) {
+    const double a = (double)M * K, w = (double)N * K;
+    const double n_fast = a + w * (tiles_m < 8 ? tiles_m : 8);
+    const double m_fast = w + a * (tiles_n < 8 ? tiles_n : 8);
+    return m_fast < n_fast;
+}
+
 namespace {
 
 constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 chunks of 16 B
@@ -25,7 +34,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int OUT>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
-            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_n) {
+            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int m_fast) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -44,7 +53,11 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
     const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int m0 = (swz / tiles_n) * BM, n0 = (swz % tiles_n) * BN;
+    // tile order inside the XCD-contiguous run: n-fastest keeps an A row-panel in the XCD's L2 while the
+    // W panels stream (A read once, W up to 8x); m-fastest keeps a W panel while the A panels stream.
+    // The host picks the order that moves fewer bytes (small-M Llama GEMMs: m-fastest, W read once).
+    const int m0 = (m_fast ? swz % tiles_m : swz / tiles_n) * BM;
+    const int n0 = (m_fast ? swz / tiles_m : swz % tiles_n) * BN;
 
     // ---- per-thread staging sources (element offsets; the K offset is added per tile) -------
     uint32_t offA[PA], offW[PW];
@@ -156,10 +169,11 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
                 int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
     dim3 grid(tm * tn), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O>), grid, block, 0, st, (const uint16_t*)A,   \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tn)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);

@@ -33,8 +33,8 @@ template <int BM, int BN, int WM, int WN, int EPI, int OUT>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
                const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc,
-               int ldr, int tiles_n, int total_iters, float* __restrict__ slabs, unsigned* __restrict__ flags,
-               unsigned epoch) {
+               int ldr, int tiles_m, int tiles_n, int m_fast, int total_iters, float* __restrict__ slabs,
+               unsigned* __restrict__ flags, unsigned epoch) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -60,7 +60,8 @@ gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 
     uint32_t offA[PA], offW[PW];
     auto set_tile = [&](int tile) {
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const int m0 = (m_fast ? tile % tiles_m : tile / tiles_n) * BM;
+        const int n0 = (m_fast ? tile / tiles_m : tile % tiles_n) * BN;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
@@ -161,12 +162,13 @@ gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                     for (int i = 0; i < MI; ++i) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j) acc[i][j] += *(const f32x4*)(s2 + ((i * NI + j) * NT + tid) * 4);
-                        asm volatile("" ::: "memory");          // keep at most NI slab loads in flight (VGPR budget)
+                        if (i & 1) asm volatile("" ::: "memory");   // at most 2*NI slab loads in flight (VGPR budget)
                     }
                 }
             }
             // ------------------------------ epilogue ------------------------------------------------
-            const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+            const int m0 = (m_fast ? tile % tiles_m : tile / tiles_n) * BM;
+            const int n0 = (m_fast ? tile / tiles_m : tile % tiles_n) * BN;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 asm volatile("" ::: "memory");                  // one fragment row of bias/residual loads at a time
@@ -225,6 +227,7 @@ int launch_sk(const void* A, const void* W, const float* bias, const float* R, v
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const long total = (long)tm * tn * (K / BK);
+    const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
     int G = num_cus() * PER_CU;
     G -= G & 7;
     if (total < G) G = (int)total;
@@ -239,7 +242,7 @@ int launch_sk(const void* A, const void* W, const float* bias, const float* R, v
     dim3 grid(G), block(NT);
 #define VLY_SK_LAUNCH(E, O)                                                                                 \
     hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, E, O>), grid, block, 0, st, (const uint16_t*)A,      \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tn, (int)total, slabs, flags, epoch)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, (int)total, slabs, flags, epoch)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_SK_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
