@@ -54,8 +54,8 @@ const char *vly_last_error(void);
  *   (hf:clip/modeling_clip.py:148-154,209), q/k/v/out_proj (:293-296), fc1/fc2 (:343-344),
  *   mm_projector (valley_model.py:54-55,190), Llama q/k/v/o (hf:llama/modeling_llama.py:230-241),
  *   gate/up/down (:166-168), lm_head (valley_model.py:264,305).
- *   tile_hint: 0 = auto, 1 = 256x256, 2 = 128x128, 3 = 256x128, 4 = 128x256, 5 = 192x256 (BM x BN;
- *   tuning / tests). */
+ *   tile_hint: 0 = auto, 1 = 256x256, 2 = 128x128, 3 = 256x128, 4 = 128x256, 5 = 192x256 (BM x BN);
+ *   +10 selects the counted-vmcnt half-tile pipeline instead of the 2-stage loop (tuning / tests). */
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);

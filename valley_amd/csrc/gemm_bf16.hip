@@ -30,7 +30,7 @@ namespace {
 
 constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 chunks of 16 B
 
-template <int BM, int BN, int WM, int WN, int EPI, int OUT>
+template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
@@ -59,58 +59,122 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     const int m0 = (m_fast ? swz % tiles_m : swz / tiles_n) * BM;
     const int n0 = (m_fast ? swz / tiles_m : swz % tiles_n) * BN;
 
-    // ---- per-thread staging sources (element offsets; the K offset is added per tile) -------
-    uint32_t offA[PA], offW[PW];
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-        const int gr = min(m0 + row, M - 1);
-        offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
-    }
-#pragma unroll
-    for (int p = 0; p < PW; ++p) {
-        const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-        const int gr = min(n0 + row, N - 1);
-        offW[p] = (uint32_t)gr * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
-    }
-
-    auto stage = [&](int kt, int buf) {
-        char* sA = smem + buf * STAGE;
-        char* sW = sA + A_BYTES;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
-#pragma unroll
-        for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
-    };
-
-    // ---- wave position and fragment read offsets --------------------------------------------
     const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
-    // row & 7 == l15 & 7 for every fragment row (all bases are multiples of 16)
-    const int rdA = (wm0 + l15) * 128, rdW = (wn0 + l15) * 128;
-    const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
-
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int nk = K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                                  // tile kt landed; buffer (kt+1)&1 is free
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* sA = smem + (kt & 1) * STAGE;
-        const char* sW = sA + A_BYTES;
+
+    if constexpr (PIPE == 0) {
+        // ================= 2-stage loop: whole K tiles, vmcnt(0) + one barrier per tile ================
+        uint32_t offA[PA], offW[PW];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int sw = kk ? sw1 : sw0;
+        for (int p = 0; p < PA; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            const int gr = min(m0 + row, M - 1);
+            offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            const int gr = min(n0 + row, N - 1);
+            offW[p] = (uint32_t)gr * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+        auto stage = [&](int kt, int buf) {
+            char* sA = smem + buf * STAGE;
+            char* sW = sA + A_BYTES;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+        };
+        // row & 7 == l15 & 7 for every fragment row (all bases are multiples of 16)
+        const int rdA = (wm0 + l15) * 128, rdW = (wn0 + l15) * 128;
+        const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                              // tile kt landed; buffer (kt+1)&1 is free
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            const char* sA = smem + (kt & 1) * STAGE;
+            const char* sW = sA + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int sw = kk ? sw1 : sw0;
+                bf16x8 af[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + rdA + i * 2048 + sw);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(sW + rdW + j * 2048 + sw);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            }
+        }
+    } else {
+        // ================= 4-region half-tile pipeline: counted vmcnt, raw barrier ======================
+        // The K loop advances in HALF tiles (32 k = one MFMA k-step = 64-byte LDS rows).  LDS holds four
+        // half-tile regions; the loads of half-tile p+3 are issued while half-tile p is computed, so 1.5
+        // K tiles are always in flight and vmcnt never drains inside the loop.  Per phase:
+        //     s_waitcnt vmcnt(2*LPH)   this lane's loads of half-tile p have landed
+        //     s_barrier                everyone's have, and everyone finished reading region (p-1)&3
+        //     issue loads of p+3 into region (p+3)&3 == (p-1)&3
+        //     ds_read_b128 fragments of p, MFMAs.
+        // 64-byte rows: chunk' = chunk ^ ((row >> 2) & 2) is conflict-free for ds_read_b128's lane groups.
+        constexpr int HA = BM * 64, REGION = (BM + BN) * 64;      // bytes
+        constexpr int PAH = (BM * 4 + NT - 1) / NT, PWH = (BN * 4 + NT - 1) / NT, LPH = PAH + PWH;
+        static_assert(4 * REGION == 2 * STAGE, "LDS budget");
+        uint32_t offA[PAH], offW[PWH];
+        int dstA[PAH], dstW[PWH];
+#pragma unroll
+        for (int p = 0; p < PAH; ++p) {
+            int sb = p * NT + wave * 64;                           // wave-uniform slot base
+            if (sb >= BM * 4) sb -= (PAH * NT - BM * 4);            // surplus waves repeat earlier rows (same data)
+            const int s = sb + lane, row = s >> 2, cp = s & 3;
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
+            dstA[p] = sb * 16;
+        }
+#pragma unroll
+        for (int p = 0; p < PWH; ++p) {
+            int sb = p * NT + wave * 64;
+            if (sb >= BN * 4) sb -= (PWH * NT - BN * 4);
+            const int s = sb + lane, row = s >> 2, cp = s & 3;
+            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
+            dstW[p] = HA + sb * 16;
+        }
+        auto stage_half = [&](int p) {
+            char* reg = smem + (p & 3) * REGION;
+            const int k0 = p * 32;
+#pragma unroll
+            for (int q = 0; q < PAH; ++q) glds16(A + offA[q] + k0, reg + dstA[q]);
+#pragma unroll
+            for (int q = 0; q < PWH; ++q) glds16(W + offW[q] + k0, reg + dstW[q]);
+        };
+        const int swz = (g ^ ((l15 >> 2) & 2)) << 4;
+        const int rdA = (wm0 + l15) * 64 + swz, rdW = HA + (wn0 + l15) * 64 + swz;
+        const int P = 2 * nk;                                      // half tiles
+
+        stage_half(0);
+        if (P > 1) stage_half(1);
+        if (P > 2) stage_half(2);
+        for (int p = 0; p < P; ++p) {
+            const int ahead = min(2, P - 1 - p);                   // half tiles allowed to stay in flight
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPH) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (p + 3 < P) stage_half(p + 3);
+            const char* reg = smem + (p & 3) * REGION;
             bf16x8 af[MI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + rdA + i * 2048 + sw);
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(reg + rdA + i * 1024);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(sW + rdW + j * 2048 + sw);
+            for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(reg + rdW + j * 1024);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -164,7 +228,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PIPE>
 int launch_tile(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
                 int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -172,7 +236,7 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
     const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
     dim3 grid(tm * tn), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O>), grid, block, 0, st, (const uint16_t*)A,   \
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O, PIPE>), grid, block, 0, st, (const uint16_t*)A,   \
                        (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
@@ -226,12 +290,19 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
     if (epilogue == VLY_EPI_SWIGLU && residual) { vly_set_error("vly_gemm_bf16: SWIGLU takes no residual"); return -22; }
     hipStream_t st = (hipStream_t)stream;
     const int t = tile_hint ? tile_hint : pick_tile(M, N);
-    switch (t) {
-        case 1: return launch_tile<256, 256, 128, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
-        case 2: return launch_tile<128, 128, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
-        case 3: return launch_tile<256, 128, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
-        case 4: return launch_tile<128, 256, 64, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
-        case 5: return launch_tile<192, 256, 96, 64>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+#define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st
+    switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline
+        case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
+        case 2: return launch_tile<128, 128, 64, 64, 0>(VLY_TILE_ARGS);
+        case 3: return launch_tile<256, 128, 64, 64, 0>(VLY_TILE_ARGS);
+        case 4: return launch_tile<128, 256, 64, 64, 0>(VLY_TILE_ARGS);
+        case 5: return launch_tile<192, 256, 96, 64, 0>(VLY_TILE_ARGS);
+        case 11: return launch_tile<256, 256, 128, 64, 1>(VLY_TILE_ARGS);
+        case 12: return launch_tile<128, 128, 64, 64, 1>(VLY_TILE_ARGS);
+        case 13: return launch_tile<256, 128, 64, 64, 1>(VLY_TILE_ARGS);
+        case 14: return launch_tile<128, 256, 64, 64, 1>(VLY_TILE_ARGS);
+        case 15: return launch_tile<192, 256, 96, 64, 1>(VLY_TILE_ARGS);
         default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
     }
+#undef VLY_TILE_ARGS
 }

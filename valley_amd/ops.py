@@ -75,7 +75,9 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
     if rec is not None:
         e1.record()
-        rec.append((f"{'gemm_sk_kernel' if sk else 'gemm_kernel'}<{TILE_NAMES[tile]}, {epilogue}, {od}>", 2.0 * M * N * K, e0, e1))
+        name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}>" if sk else \
+            f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {tile // 10}>"
+        rec.append((name, 2.0 * M * N * K, e0, e1))
     _lib.check(rc, fn_name)
     return out
 
@@ -129,7 +131,7 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     residual update is not applied more than once) and remember the winner."""
     scratch = torch.empty_like(out)
     best, best_t = ("tile", 0), float("inf")
-    cands = [("tile", t) for t in (1, 2, 3, 4, 5)] + [("sk", t) for t in (1, 2, 3, 4, 5)]
+    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 11, 12, 13, 14, 15)] + [("sk", t) for t in (1, 2, 3, 4, 5)]
     for kind, t in cands:
         fn = gemm_mfma if kind == "tile" else gemm_streamk
         try:
