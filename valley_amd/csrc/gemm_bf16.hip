@@ -115,6 +115,85 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
             }
         }
+    } else if constexpr (PIPE == 3) {
+        // ================= role-split half-tile pipeline (8 waves) ==========================================
+        // PMC on the 2-stage loop: MFMA pipe busy 50 %, waves parked 36 % — every wave of the workgroup is in
+        // the same state at the same time (all loading after the barrier, then all multiplying), so the
+        // two waves that share a SIMD cannot cover for each other.  Here waves 0-3 (group 0) and waves 4-7
+        // (group 1: same SIMDs) run the SAME phase sequence  R(p) = {issue loads of half-tile p+3, ds_read
+        // fragments of p},  M(p) = {MFMAs of p}  but group 1 runs one phase behind (one extra barrier up
+        // front, one extra at the end for group 0): while one wave of a SIMD multiplies, its partner loads.
+        // LDS = 4 half-tile regions (as PIPE 1), loads 1.5 K tiles ahead, counted vmcnt, raw barriers.
+        static_assert(NW == 8, "role-split pipeline needs two waves per SIMD");
+        constexpr int HA = BM * 64, REGION = (BM + BN) * 64;
+        constexpr int PAH = (BM * 4 + NT - 1) / NT, PWH = (BN * 4 + NT - 1) / NT, LPH = PAH + PWH;
+        uint32_t offA[PAH], offW[PWH];
+        int dstA[PAH], dstW[PWH];
+#pragma unroll
+        for (int p = 0; p < PAH; ++p) {
+            int sb = p * NT + wave * 64;
+            if (sb >= BM * 4) sb -= (PAH * NT - BM * 4);
+            const int s = sb + lane, row = s >> 2, cp = s & 3;
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
+            dstA[p] = sb * 16;
+        }
+#pragma unroll
+        for (int p = 0; p < PWH; ++p) {
+            int sb = p * NT + wave * 64;
+            if (sb >= BN * 4) sb -= (PWH * NT - BN * 4);
+            const int s = sb + lane, row = s >> 2, cp = s & 3;
+            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
+            dstW[p] = HA + sb * 16;
+        }
+        auto stage_half = [&](int p) {
+            char* reg = smem + (p & 3) * REGION;
+            const int k0 = p * 32;
+#pragma unroll
+            for (int q = 0; q < PAH; ++q) glds16(A + offA[q] + k0, reg + dstA[q]);
+#pragma unroll
+            for (int q = 0; q < PWH; ++q) glds16(W + offW[q] + k0, reg + dstW[q]);
+        };
+        auto wait_ahead = [&](int ahead) {                       // leave `ahead` half tiles of my loads in flight
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPH) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const int swz = (g ^ ((l15 >> 2) & 2)) << 4;
+        const int rdA = (wm0 + l15) * 64 + swz, rdW = HA + (wn0 + l15) * 64 + swz;
+        const int P = 2 * nk;
+        const int grp = wave >> 2;                                  // wave-uniform (readfirstlane'd above)
+
+        stage_half(0);
+        if (P > 1) stage_half(1);
+        if (P > 2) stage_half(2);
+        wait_ahead(min(2, P - 1));                                  // half tile 0 landed (mine)
+        __builtin_amdgcn_s_barrier();                               // ... and everyone's
+        if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 starts one phase late
+        for (int p = 0; p < P; ++p) {
+            // ---------------- R(p)
+            if (p + 3 < P) stage_half(p + 3);
+            const char* reg = smem + (p & 3) * REGION;
+            bf16x8 af[MI], wf[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(reg + rdW + j * 1024);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(reg + rdA + i * 1024);
+            if (grp == 1) wait_ahead(min(2, P - 2 - p));            // my loads of half tile p+1 landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- M(p)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) wait_ahead(min(2, P - 2 - p));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
     } else {
         // ================= 4-region half-tile pipeline: counted vmcnt, raw barrier ======================
         // The K loop advances in HALF tiles (32 k = one MFMA k-step = 64-byte LDS rows).  LDS holds four
@@ -291,7 +370,7 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
     hipStream_t st = (hipStream_t)stream;
     const int t = tile_hint ? tile_hint : pick_tile(M, N);
 #define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st
-    switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline
+    switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split pipeline
         case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
         case 2: return launch_tile<128, 128, 64, 64, 0>(VLY_TILE_ARGS);
         case 3: return launch_tile<256, 128, 64, 64, 0>(VLY_TILE_ARGS);
@@ -302,6 +381,10 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         case 13: return launch_tile<256, 128, 64, 64, 1>(VLY_TILE_ARGS);
         case 14: return launch_tile<128, 256, 64, 64, 1>(VLY_TILE_ARGS);
         case 15: return launch_tile<192, 256, 96, 64, 1>(VLY_TILE_ARGS);
+        case 31: return launch_tile<256, 256, 128, 64, 3>(VLY_TILE_ARGS);
+        case 33: return launch_tile<256, 128, 64, 64, 3>(VLY_TILE_ARGS);
+        case 34: return launch_tile<128, 256, 64, 64, 3>(VLY_TILE_ARGS);
+        case 35: return launch_tile<192, 256, 96, 64, 3>(VLY_TILE_ARGS);
         default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
     }
 #undef VLY_TILE_ARGS
