@@ -36,7 +36,7 @@ constexpr int VLD = 3072;          // qkv row stride (elements)
 constexpr int VT_STRIDE = 296;     // V^T row stride in elements (592 B = 2*256 + 16*5)
 constexpr int VK_BYTES = VNT * 16 * 128;
 
-__global__ void __launch_bounds__(256) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+__global__ void __launch_bounds__(256, 2) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2];
     char* sK = smem;
     uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256) vit_attn_kernel(const uint16_t* __restric
                 acc = mfma16(kf, qf[kk], acc);
             }
             s[t] = acc * sc;
+            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
         }
         // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
 #pragma unroll
@@ -147,6 +148,7 @@ __global__ void __launch_bounds__(256) vit_attn_kernel(const uint16_t* __restric
                 vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
                 o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
             }
+            asm volatile("" ::: "memory");
         }
         if (q < VN) {
             const float inv = 1.f / l;
@@ -206,43 +208,55 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < ntiles; ++kt) {
+    // Register-staged K/V tiles (async-stage split): the global loads of tile t+1 are issued right
+    // before tile t's MFMAs and written to LDS after the next barrier, so HBM/L2 latency hides under
+    // compute instead of sitting between two barriers.
+    const int p_v = tid & 31, dg_v = tid >> 5;              // V^T staging: thread <-> (key pair, group of 16 d)
+    u32x4 kreg[4], va0, va1, vb0, vb1;
+    bool okreg = false;
+    auto load_tile = [&](int kt) {
         const int kv0 = kt * 64;
-        __syncthreads();                                  // previous tile fully consumed
-        // ---- stage K tile (row-major, swizzled) ---------------------------------------------
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int s = i * 256 + tid, row = s >> 4, c = s & 15;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (kv0 + row < kv_len) v = *(const u32x4*)(kbase + (size_t)(kv0 + row) * 128 + c * 8);
-            *(u32x4*)(sK + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+            kreg[i] = (kv0 + row < kv_len) ? *(const u32x4*)(kbase + (size_t)(kv0 + row) * 128 + c * 8) : z;
         }
-        // ---- stage V^T tile: thread <-> (key pair p, group of 16 d) -----------------------------
-        {
-            const int p = tid & 31, dg = tid >> 5;
-            const int r0 = kv0 + 2 * p, r1 = r0 + 1;
-            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
-            if (r0 < kv_len) {
-                const uint16_t* x = vbase + (size_t)r0 * 128 + dg * 16;
-                a0 = *(const u32x4*)x;
-                a1 = *(const u32x4*)(x + 8);
-            }
-            if (r1 < kv_len) {
-                const uint16_t* x = vbase + (size_t)r1 * 128 + dg * 16;
-                b0 = *(const u32x4*)x;
-                b1 = *(const u32x4*)(x + 8);
-            }
+        const int r0 = kv0 + 2 * p_v, r1 = r0 + 1;
+        va0 = va1 = vb0 = vb1 = z;
+        if (r0 < kv_len) {
+            const uint16_t* x = vbase + (size_t)r0 * 128 + dg_v * 16;
+            va0 = *(const u32x4*)x;
+            va1 = *(const u32x4*)(x + 8);
+        }
+        if (r1 < kv_len) {
+            const uint16_t* x = vbase + (size_t)r1 * 128 + dg_v * 16;
+            vb0 = *(const u32x4*)x;
+            vb1 = *(const u32x4*)(x + 8);
+        }
+        const int kvl = kv0 + lane;
+        okreg = kvl < kv_len && (!kvld || kvld[kvl] != 0);
+    };
+    if (ntiles > 0) load_tile(0);
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int kv0 = kt * 64;
+        __syncthreads();                                  // previous tile fully consumed
+        // ---- registers -> LDS: K row-major swizzled, V transposed ----------------------------------
 #pragma unroll
-            for (int dd = 0; dd < 16; ++dd) {
-                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
-                *(uint32_t*)(sVt + (dg * 16 + dd) * LVT_STRIDE + 2 * p) = w;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int s = i * 256 + tid, row = s >> 4, c = s & 15;
+            *(u32x4*)(sK + row * 256 + ((c ^ (row & 15)) << 4)) = kreg[i];
+        }
+#pragma unroll
+        for (int dd = 0; dd < 16; ++dd) {
+            const uint32_t w = sel16(va0, va1, dd) | (sel16(vb0, vb1, dd) << 16);
+            *(uint32_t*)(sVt + (dg_v * 16 + dd) * LVT_STRIDE + 2 * p_v) = w;
         }
         // key validity of this tile as a 64-bit wave mask (lane <-> key kv0 + lane)
-        const int kvl = kv0 + lane;
-        const bool ok = kvl < kv_len && (!kvld || kvld[kvl] != 0);
-        const unsigned long long vmask = __ballot(ok);
+        const unsigned long long vmask = __ballot(okreg);
         __syncthreads();
+        if (kt + 1 < ntiles) load_tile(kt + 1);           // in flight while this tile is multiplied
 
         // ---- S^T tile ---------------------------------------------------------------------------
         f32x4 s[4];
@@ -387,13 +401,24 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     float o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
-    for (int j = kg; j < kv_len; j += 16) {
-        const float p = sc[j];
-        const u32x4 vv = *(const u32x4*)(vbase + (size_t)j * 128 + 8 * dc);
-        o[0] = fmaf(p, __uint_as_float(vv[0] << 16), o[0]); o[1] = fmaf(p, __uint_as_float(vv[0] & 0xffff0000u), o[1]);
-        o[2] = fmaf(p, __uint_as_float(vv[1] << 16), o[2]); o[3] = fmaf(p, __uint_as_float(vv[1] & 0xffff0000u), o[3]);
-        o[4] = fmaf(p, __uint_as_float(vv[2] << 16), o[4]); o[5] = fmaf(p, __uint_as_float(vv[2] & 0xffff0000u), o[5]);
-        o[6] = fmaf(p, __uint_as_float(vv[3] << 16), o[6]); o[7] = fmaf(p, __uint_as_float(vv[3] & 0xffff0000u), o[7]);
+    for (int j0 = kg; j0 < kv_len; j0 += 64) {                  // 4 independent 16-byte V loads in flight per lane
+        u32x4 vv[4];
+        float pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 16 * u;
+            const bool in = j < kv_len;
+            pp[u] = in ? sc[j] : 0.f;
+            vv[u] = *(const u32x4*)(vbase + (size_t)(in ? j : kg) * 128 + 8 * dc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float p = pp[u];
+            o[0] = fmaf(p, __uint_as_float(vv[u][0] << 16), o[0]); o[1] = fmaf(p, __uint_as_float(vv[u][0] & 0xffff0000u), o[1]);
+            o[2] = fmaf(p, __uint_as_float(vv[u][1] << 16), o[2]); o[3] = fmaf(p, __uint_as_float(vv[u][1] & 0xffff0000u), o[3]);
+            o[4] = fmaf(p, __uint_as_float(vv[u][2] << 16), o[4]); o[5] = fmaf(p, __uint_as_float(vv[u][2] & 0xffff0000u), o[5]);
+            o[6] = fmaf(p, __uint_as_float(vv[u][3] << 16), o[6]); o[7] = fmaf(p, __uint_as_float(vv[u][3] & 0xffff0000u), o[7]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc_s[kg][8 * dc + i] = o[i];

@@ -75,6 +75,73 @@ __global__ void __launch_bounds__(128) norm_kernel(const float* __restrict__ x, 
     }
 }
 
+// Small-M variant (decode: M = batch <= 8): one 256-thread workgroup per row so the row's loads are
+// spread over 4 waves instead of queued in one; block reduction through LDS.
+template <bool RMS>
+__global__ void __launch_bounds__(256) norm_row_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, uint16_t* __restrict__ y16,
+                                                       float* __restrict__ y32, int D, float eps) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const float4* xr = (const float4*)(x + (size_t)row * D);
+    const int nvec = D >> 2;
+    float4 v[8];                                               // D <= 8192
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        else s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    float mean = 0.f, rstd;
+    if constexpr (RMS) {
+        rstd = rsqrtf(s / (float)D + eps);
+    } else {
+        mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nvec) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += a * a + b * b + cc * cc + d * d;
+            }
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[4 + wave] = q;
+        __syncthreads();
+        rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i;
+        if (c >= nvec) continue;
+        const float4 gm = ((const float4*)gamma)[c];
+        float4 o;
+        if constexpr (RMS) {
+            o.x = gm.x * (v[i].x * rstd); o.y = gm.y * (v[i].y * rstd);
+            o.z = gm.z * (v[i].z * rstd); o.w = gm.w * (v[i].w * rstd);
+        } else {
+            const float4 bt = ((const float4*)beta)[c];
+            o.x = (v[i].x - mean) * rstd * gm.x + bt.x; o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+            o.z = (v[i].z - mean) * rstd * gm.z + bt.z; o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        }
+        if (y16) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(o.x, o.y);
+            pk[1] = pack_bf16x2(o.z, o.w);
+            *(u32x2*)(y16 + (size_t)row * D + 4 * c) = pk;
+        }
+        if (y32) ((float4*)(y32 + (size_t)row * D))[c] = o;
+    }
+}
+
 template <bool RMS>
 int launch_norm(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int M, int D, float eps,
                 hipStream_t st, const char* name) {
@@ -82,6 +149,10 @@ int launch_norm(const float* x, const float* gamma, const float* beta, void* y16
         (beta && ((uintptr_t)beta & 15)) || ((uintptr_t)y16 & 7) || ((uintptr_t)y32 & 15)) {
         vly_set_error("%s: unsupported shape/alignment M=%d D=%d", name, M, D);
         return -22;
+    }
+    if (M <= 64) {
+        hipLaunchKernelGGL((norm_row_kernel<RMS>), dim3(M), dim3(256), 0, st, x, gamma, beta, (uint16_t*)y16, y32, D, eps);
+        return vly_check_launch(name);
     }
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     const int nv = (D / 4 + 63) / 64;
