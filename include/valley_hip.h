@@ -35,6 +35,8 @@ extern "C" {
 #define VLY_EPI_QUICK_GELU  1   /* C = q(A W^T + bias), q(x) = x*sigmoid(1.702x)  hf:activations.py  */
 #define VLY_EPI_SWIGLU      2   /* W rows interleaved (gate_j, up_j): C[:, j] = silu(g_j) * u_j,
                                    C is N/2 wide                     hf:llama/modeling_llama.py:171 */
+#define VLY_EPI_RELU        3   /* C = max(A W^T + bias, 0): the FFN of the v3 temporal transformer layer
+                                   (torch.nn.TransformerEncoderLayer default activation)            */
 /* output dtypes */
 #define VLY_OUT_BF16 0
 #define VLY_OUT_F32  1
@@ -42,6 +44,7 @@ extern "C" {
 /* pooling modes of vly_pool_tokens (valley/model/valley_model.py:206-209) */
 #define VLY_POOL_MEAN 0
 #define VLY_POOL_MAX  1
+#define VLY_POOL_IMPORTANCE 2   /* v2: softmax over frames of Linear(256*H -> 1) scores, weighted sum (:113-121) */
 
 int         vly_abi_version(void);
 const char *vly_last_error(void);
@@ -105,8 +108,30 @@ int vly_vit_attention(const void *qkv_bf16, void *out_bf16, int F, void *stream)
 
 /* Temporal pooling + per-frame CLS pick for B clips of T frames:
  *   feats fp32 [B,T,257,W] -> out bf16 [B, 256+T, W]; rows 0..255 = mean/max over T of patch
- *   tokens, rows 256.. = CLS token of each frame.  valley/model/valley_model.py:206-215. */
-int vly_pool_tokens(const float *feats_f32, void *out_bf16, int B, int T, int W, int mode, void *stream);
+ *   tokens, rows 256.. = CLS token of each frame.  valley/model/valley_model.py:206-215.
+ *   mode VLY_POOL_IMPORTANCE needs `scores` fp32 [B,T] (vly_temporal_scores); NULL otherwise. */
+int vly_pool_tokens(const float *feats_f32, void *out_bf16, int B, int T, int W, int mode,
+                    const float *scores, void *stream);
+
+/* v2 temporal-importance frame scores: scores[f] = w . flatten(feats[f, 1:257, :]) + bias[0],
+ *   feats fp32 [F,257,W], w fp32 [256*W].  valley/model/valley_model.py:42,115-116. */
+int vly_temporal_scores(const float *feats_f32, const float *w, const float *bias, float *scores,
+                        int F, int W, void *stream);
+
+/* v3 "temporal transformer delta" pooling glue (valley/model/valley_model.py:123-133; the GEMMs of the
+ *   1-layer nn.TransformerEncoderLayer(d_model=H, nhead=8, post-LN, ReLU FFN) go through vly_gemm_bf16):
+ *   vly_delta_prep     feats fp32 [B,T,257,H] (projected), pos fp32 [>=T,H] ->
+ *                      x_all bf16 [B*256*T, H] = patch[t,p] + pos[t] in (p-major, t-minor) order (:124-129),
+ *                      x_last (bf16 and fp32) [B*256, H] = its t = T-1 rows, mean fp32 [B*256, H] (:131)
+ *   vly_delta_attention  q bf16 [nseq,H] (last step only), kv bf16 [nseq*T, 2H] -> out bf16 [nseq,H];
+ *                      softmax over the T keys, head_dim H/nhead <= 1024, T <= 32
+ *   vly_delta_finish   out bf16 [B,256+T,H]: rows<256 = delta + mean (:132), rows>=256 = frame CLS (:215) */
+int vly_delta_prep(const float *feats_f32, const float *pos_f32, void *x_all_bf16, void *x_last_bf16,
+                   float *x_last_f32, float *mean_f32, int B, int T, int H, void *stream);
+int vly_delta_attention(const void *q_bf16, const void *kv_bf16, void *out_bf16, int nseq, int T, int H,
+                        int nhead, void *stream);
+int vly_delta_finish(const float *delta_f32, const float *mean_f32, const float *feats_f32, void *out_bf16,
+                     int B, int T, int H, void *stream);
 
 /* Token-embedding gather + visual-token splice -> fp32 residual stream:
  *   row_map int32 [R]: v >= 0 -> embed_table[v];  v < 0 -> visual[-v-1].

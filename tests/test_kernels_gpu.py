@@ -262,3 +262,21 @@ def test_argmax():
     x[3, 9] = 60.0
     got = ops.argmax(x.to(dev())).cpu()
     assert got.tolist() == x.argmax(-1).tolist()
+
+
+def test_temporal_importance_pooling():
+    """v2: scores = Linear(256*W -> 1)(flatten(patches)); softmax over frames; weighted sum (valley_model.py:113-121)."""
+    from valley_amd import ops
+    d = dev()
+    B, T, W = 2, 6, 256
+    f = rnd((B, T, 257, W), 50)
+    w = rnd((256 * W,), 51, 0.02)
+    b = rnd((1,), 52)
+    sc = ops.temporal_scores(f.to(d).view(-1, W), w.to(d), b.to(d), B * T)
+    ref_sc = (f[:, :, 1:].reshape(B * T, -1) @ w) + b
+    assert maxabs(sc, ref_sc) < 2e-3
+    out = ops.pool_tokens(f.to(d).view(-1, W), B, T, ops.POOL_IMPORTANCE, sc)
+    wt = torch.softmax(ref_sc.view(B, T), dim=1)
+    pooled = (wt[:, :, None, None] * f[:, :, 1:]).sum(1)
+    ref = torch.cat([pooled, f[:, :, 0]], dim=1)
+    assert relerr(out, ref) < 3e-3

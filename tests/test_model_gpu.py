@@ -62,10 +62,15 @@ def test_tower_vs_golden():
         assert rel(h.cpu().numpy()[:, ::8, ::4], g[f"hs{i}"]) < 6e-3, i
 
 
-@pytest.mark.parametrize("method", ["mean", "max"])
+@pytest.mark.parametrize("method", ["mean", "max", "temporal_importance", "temporal_transformer"])
 def test_forward_vs_golden(method):
     g = np.load(os.path.join(GOLD, f"g2_forward_{method}.npz"))
     model = build_golden_model(method)
+    if method in ("temporal_importance", "temporal_transformer"):
+        sd = dict(G.llama_state())
+        sd.update(G.extra_pool_state(method))
+        model.load_state_dict(sd)
+        model.get_model().patch_pooling_method = method
     T = G.GCFG["T"]
     ids, mask = G.golden_ids("main")
     images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224).cuda()
@@ -158,12 +163,15 @@ def test_generate_matches_manual_loop():
     assert rec.tolist() == seq[0, ids.shape[1]:].tolist()
 
 
-def test_unbuilt_pooling_variants_fail_loudly():
-    model = build_golden_model("temporal_importance")
+def test_pooling_variant_without_weights_fails_loudly():
+    model = build_golden_model("temporal_transformer")       # weights of the v3 encoder were never loaded
     T = G.GCFG["T"]
     ids, _ = G.golden_ids("decode")
     img1 = torch.from_numpy(G.golden_pixels(T, "mixed")).view(1, T, 3, 224, 224).cuda()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
+        model(input_ids=torch.from_numpy(ids).cuda(), images=img1)
+    model.get_model().patch_pooling_method = "bogus"
+    with pytest.raises(ValueError):
         model(input_ids=torch.from_numpy(ids).cuda(), images=img1)
 
 
@@ -280,3 +288,35 @@ def test_generate_graph_equals_eager_with_padding():
     c = model.generate(torch.from_numpy(ids).cuda(), use_graph=None, **kw)
     assert a.shape == (2, ids.shape[1] + 6)
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_from_pretrained_checkpoint_roundtrip(tmp_path):
+    """an HF-layout checkpoint directory (config.json + safetensors, reference key names
+    incl. ``model.vision_tower.vision_model.*`` of the pinned transformers and ``model.mm_projector.*``)
+    loads through ``ValleyLlamaForCausalLM.from_pretrained`` and reproduces the golden logits."""
+    import json
+    from safetensors.numpy import save_file
+    from valley_amd import valley_model as vm
+    c = G.GCFG
+    sd = dict(G.llama_state())
+    sd.update({"model.vision_tower.vision_model." + k: v for k, v in G.vision_state().items()})
+    half = len(sd) // 2
+    keys = sorted(sd)
+    save_file({k: np.ascontiguousarray(sd[k]) for k in keys[:half]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: np.ascontiguousarray(sd[k]) for k in keys[half:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    cfg = dict(architectures=["ValleyLlamaForCausalLM"], model_type="valley", vocab_size=c["vocab"], hidden_size=c["H"],
+               intermediate_size=c["I"], num_hidden_layers=c["L"], num_attention_heads=c["heads"],
+               num_key_value_heads=c["heads"], rms_norm_eps=c["eps"], max_position_embeddings=2048,
+               use_mm_proj=True, mm_hidden_size=1024, mm_vision_select_layer=-2, mm_vision_tower="openai/clip-vit-large-patch14")
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    model = vm.ValleyLlamaForCausalLM.from_pretrained(str(tmp_path))
+    tower = model.get_model().vision_tower
+    assert tower is not None and len(tower.layers) == c["VL"]
+    tower.config.num_hidden_layers = c["VL"]
+    for k, v in G.special().items():
+        setattr(tower.config, k, v)
+    g = np.load(os.path.join(GOLD, "g5_decode.npz"))
+    ids, _ = G.golden_ids("decode")
+    img1 = torch.from_numpy(G.golden_pixels(c["T"], "mixed")).view(1, c["T"], 3, 224, 224).cuda()
+    out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1)
+    assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < 6e-2

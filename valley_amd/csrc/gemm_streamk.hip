@@ -184,6 +184,10 @@ gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
                     }
+                    if constexpr (EPI == VLY_EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
                     if constexpr (EPI == VLY_EPI_SWIGLU) {
                         const float o0 = v[0] / (1.f + __expf(-v[0])) * v[1];
                         const float o1 = v[2] / (1.f + __expf(-v[2])) * v[3];
@@ -247,6 +251,7 @@ int launch_sk(const void* A, const void* W, const float* bias, const float* R, v
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_SK_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_RELU && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_RELU, VLY_OUT_BF16);
     else {
         vly_set_error("vly_gemm_bf16_streamk: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
         return -22;

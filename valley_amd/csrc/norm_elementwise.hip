@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(256) vit_embed_ln_kernel(const float* __restri
 // Thread per 4 columns of one output row; rows < 256 reduce over T, rows >= 256 copy a CLS row.
 // bytes/clip = 4*T*257*W read + 2*(256+T)*W written.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pool_kernel(const float* __restrict__ feats, uint16_t* __restrict__ out, int B, int T, int W, int mode) {
+__global__ void __launch_bounds__(256) pool_kernel(const float* __restrict__ feats, uint16_t* __restrict__ out, int B, int T, int W, int mode,
+                                                   const float* __restrict__ scores) {
     const int wv = W >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * (256 + T) * wv;
@@ -252,7 +253,20 @@ __global__ void __launch_bounds__(256) pool_kernel(const float* __restrict__ fea
     const int r = (int)(rr % (256 + T)), b = (int)(rr / (256 + T));
     const float* fb = feats + (size_t)b * T * 257 * W;
     float4 o;
-    if (r < 256) {
+    if (r < 256 && mode == VLY_POOL_IMPORTANCE) {
+        // valley_model.py:113-121: softmax over the T frame scores, weighted sum of the frames
+        const float* sc = scores + (size_t)b * T;
+        float mx = sc[0];
+        for (int t = 1; t < T; ++t) mx = fmaxf(mx, sc[t]);
+        float den = 0.f;
+        for (int t = 0; t < T; ++t) den += __expf(sc[t] - mx);
+        o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < T; ++t) {
+            const float wt = __expf(sc[t] - mx) / den;
+            const float4 a = ((const float4*)(fb + ((size_t)t * 257 + 1 + r) * W))[c];
+            o.x += wt * a.x; o.y += wt * a.y; o.z += wt * a.z; o.w += wt * a.w;
+        }
+    } else if (r < 256) {
         o = ((const float4*)(fb + (size_t)(1 + r) * W))[c];
         for (int t = 1; t < T; ++t) {
             const float4 a = ((const float4*)(fb + ((size_t)t * 257 + 1 + r) * W))[c];
@@ -392,14 +406,46 @@ extern "C" int vly_vit_embed_ln(const float* patch_out, const float* cls, const 
     return vly_check_launch("vly_vit_embed_ln");
 }
 
-extern "C" int vly_pool_tokens(const float* feats, void* out, int B, int T, int W, int mode, void* stream) {
-    if (B <= 0 || T <= 0 || W <= 0 || W % 4 || (mode != VLY_POOL_MEAN && mode != VLY_POOL_MAX)) {
+// Frame scores of the v2 "temporal importance" pooling: score[f] = w . flatten(feats[f, 1:257, :]) + b
+// (valley_model.py:42,115-116: Linear(256*H -> 1) on the flattened patch tokens).  One workgroup per
+// frame streams 256*W contiguous floats against the weight vector; HBM-bound, 8*256*W bytes per frame.
+__global__ void __launch_bounds__(256) temporal_score_kernel(const float* __restrict__ feats, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ scores, int W) {
+    __shared__ float red[4];
+    const float4* x = (const float4*)(feats + ((size_t)blockIdx.x * 257 + 1) * W);
+    const float4* wv = (const float4*)w;
+    const int n4 = 64 * W;                                     // 256 * W / 4
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = x[i], b = wv[i];
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) scores[blockIdx.x] = red[0] + red[1] + red[2] + red[3] + (bias ? bias[0] : 0.f);
+}
+
+extern "C" int vly_temporal_scores(const float* feats, const float* w, const float* bias, float* scores, int F, int W,
+                                   void* stream) {
+    if (F <= 0 || W <= 0 || W % 4 || ((uintptr_t)feats & 15) || ((uintptr_t)w & 15)) {
+        vly_set_error("vly_temporal_scores: bad args F=%d W=%d", F, W);
+        return -22;
+    }
+    hipLaunchKernelGGL(temporal_score_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, feats, w, bias, scores, W);
+    return vly_check_launch("vly_temporal_scores");
+}
+
+extern "C" int vly_pool_tokens(const float* feats, void* out, int B, int T, int W, int mode, const float* scores,
+                               void* stream) {
+    if (B <= 0 || T <= 0 || W <= 0 || W % 4 || mode < VLY_POOL_MEAN || mode > VLY_POOL_IMPORTANCE ||
+        (mode == VLY_POOL_IMPORTANCE && !scores)) {
         vly_set_error("vly_pool_tokens: bad args B=%d T=%d W=%d mode=%d", B, T, W, mode);
         return -22;
     }
     const long total = (long)B * (256 + T) * (W / 4);
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feats,
-                       (uint16_t*)out, B, T, W, mode);
+                       (uint16_t*)out, B, T, W, mode, scores);
     return vly_check_launch("vly_pool_tokens");
 }
 

@@ -27,7 +27,11 @@ _SIGS = {
     "vly_patchify": (c_int, [_P, _P, c_int, _P]),
     "vly_vit_embed_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_float, _P]),
     "vly_vit_attention": (c_int, [_P, _P, c_int, _P]),
-    "vly_pool_tokens": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vly_pool_tokens": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vly_temporal_scores": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "vly_delta_prep": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vly_delta_attention": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vly_delta_finish": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vly_embed_splice": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "vly_rope_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_llama_attention": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -12,9 +12,9 @@ import torch
 
 from . import lib as _lib
 
-EPI_NONE, EPI_QUICK_GELU, EPI_SWIGLU = 0, 1, 2
+EPI_NONE, EPI_QUICK_GELU, EPI_SWIGLU, EPI_RELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32 = 0, 1
-POOL_MEAN, POOL_MAX = 0, 1
+POOL_MEAN, POOL_MAX, POOL_IMPORTANCE = 0, 1, 2
 
 
 # Optional per-launch recorder (bench.py's live per-kernel timing): a list that receives
@@ -254,13 +254,25 @@ def vit_attention(qkv: torch.Tensor, F: int, out=None) -> torch.Tensor:
     return out
 
 
-def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN) -> torch.Tensor:
+def temporal_scores(feats: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, F: int) -> torch.Tensor:
+    """feats fp32 [F*257, W], w fp32 [256*W], bias fp32 [1] -> fp32 [F] (v2 importance scores)."""
+    _chk(feats, torch.float32, "feats")
+    _chk(w, torch.float32, "w")
+    W = feats.shape[-1]
+    assert feats.numel() == F * 257 * W and w.numel() == 256 * W
+    out = torch.empty((F,), dtype=torch.float32, device=feats.device)
+    rc = _lib.load().vly_temporal_scores(feats.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), F, W, _stream())
+    _lib.check(rc, "vly_temporal_scores")
+    return out
+
+
+def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN, scores: Optional[torch.Tensor] = None) -> torch.Tensor:
     """feats fp32 [B*T*257, W] -> bf16 [B, 256+T, W]."""
     _chk(feats, torch.float32, "feats")
     W = feats.shape[-1]
     assert feats.numel() == B * T * 257 * W
     out = torch.empty((B, 256 + T, W), dtype=torch.bfloat16, device=feats.device)
-    rc = _lib.load().vly_pool_tokens(feats.data_ptr(), out.data_ptr(), B, T, W, mode, _stream())
+    rc = _lib.load().vly_pool_tokens(feats.data_ptr(), out.data_ptr(), B, T, W, mode, _ptr(scores), _stream())
     _lib.check(rc, "vly_pool_tokens")
     return out
 
@@ -332,3 +344,40 @@ def incr_i32(p: torch.Tensor, delta: int = 1):
     _chk(p, torch.int32, "p")
     rc = _lib.load().vly_incr_i32(p.data_ptr(), p.numel(), delta, _stream())
     _lib.check(rc, "vly_incr_i32")
+
+
+def delta_prep(feats: torch.Tensor, pos: torch.Tensor, B: int, T: int):
+    """projected feats fp32 [B*T*257, H] -> (x_all bf16 [B*256*T,H], x_last bf16, x_last fp32, mean fp32 [B*256,H])."""
+    _chk(feats, torch.float32, "feats")
+    _chk(pos, torch.float32, "pos")
+    H, d = feats.shape[-1], feats.device
+    assert feats.numel() == B * T * 257 * H and pos.shape[0] >= T and pos.shape[1] == H
+    x_all = torch.empty((B * 256 * T, H), dtype=torch.bfloat16, device=d)
+    x16 = torch.empty((B * 256, H), dtype=torch.bfloat16, device=d)
+    x32 = torch.empty((B * 256, H), dtype=torch.float32, device=d)
+    mean = torch.empty((B * 256, H), dtype=torch.float32, device=d)
+    rc = _lib.load().vly_delta_prep(feats.data_ptr(), pos.data_ptr(), x_all.data_ptr(), x16.data_ptr(), x32.data_ptr(),
+                                    mean.data_ptr(), B, T, H, _stream())
+    _lib.check(rc, "vly_delta_prep")
+    return x_all, x16, x32, mean
+
+
+def delta_attention(q: torch.Tensor, kv: torch.Tensor, T: int, nhead: int) -> torch.Tensor:
+    _chk(q, torch.bfloat16, "q")
+    _chk(kv, torch.bfloat16, "kv")
+    nseq, H = q.shape
+    assert tuple(kv.shape) == (nseq * T, 2 * H)
+    out = torch.empty_like(q)
+    rc = _lib.load().vly_delta_attention(q.data_ptr(), kv.data_ptr(), out.data_ptr(), nseq, T, H, nhead, _stream())
+    _lib.check(rc, "vly_delta_attention")
+    return out
+
+
+def delta_finish(delta: torch.Tensor, mean: torch.Tensor, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    _chk(delta, torch.float32, "delta")
+    _chk(mean, torch.float32, "mean")
+    H = delta.shape[-1]
+    out = torch.empty((B, 256 + T, H), dtype=torch.bfloat16, device=delta.device)
+    rc = _lib.load().vly_delta_finish(delta.data_ptr(), mean.data_ptr(), feats.data_ptr(), out.data_ptr(), B, T, H, _stream())
+    _lib.check(rc, "vly_delta_finish")
+    return out

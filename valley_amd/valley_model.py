@@ -110,6 +110,8 @@ class ValleyLlamaModel:
                               getattr(c, "max_position_embeddings", 2048), device=self.device)
         self.vision_tower: Optional[HipCLIPVisionTower] = None
         self.mm_projector: Optional[HipLinear] = None
+        self.pooling_layer = None                            # v2: SimpleNamespace(weight fp32 [256*H], bias fp32 [1])
+        self.delta_encoder = None                            # v3: dict of packed TransformerEncoderLayer weights
         if getattr(config, "mm_vision_tower", None):         # :29-38
             self.vision_tower = build_vision_tower(config.mm_vision_tower, device=self.device)
         if getattr(config, "use_patch_importance_pooling", False):   # :40-43
@@ -161,31 +163,60 @@ class ValleyLlamaModel:
         sel = getattr(self.config, "mm_vision_select_layer", -1)
         feats = self.vision_tower.encode(frames, select_layer=sel)            # fp32 [F,257,1024]
         method = self.patch_pooling_method
-        if method not in ("mean", "max"):
-            raise NotImplementedError(f"patch_pooling_method={method!r}: the v2/v3 temporal modules are not built yet "
-                                      "(SURVEY.md §8f N4)")
+        if method not in ("mean", "max", "temporal_importance", "temporal_transformer"):
+            raise ValueError(f"unknown patch_pooling_method {method!r}")
         W = 1024
-        if method == "max":
+        if method in ("max", "temporal_importance", "temporal_transformer"):
             # max does not commute with the projector: project every token first (reference order)
             x16 = ops.cast_bf16(feats.view(-1, 1024))
             feats = ops.gemm(x16, self.mm_projector.weight, self.mm_projector.bias, out_dtype=torch.float32)
             W = feats.shape[-1]
             feats = feats.view(-1, 257, W)
-        mode = ops.POOL_MEAN if method == "mean" else ops.POOL_MAX
+        if method == "temporal_transformer":
+            outs, f0 = [], 0
+            for T in Ts:                                             # one encoder pass per clip length
+                outs.append(self.temporal_transformer_delta(feats[f0:f0 + T].reshape(-1, W), 1, T).view(-1, W))
+                f0 += T
+            return (outs[0] if len(outs) == 1 else torch.cat(outs, 0)), Ts
+        mode = {"mean": ops.POOL_MEAN, "max": ops.POOL_MAX, "temporal_importance": ops.POOL_IMPORTANCE}[method]
+        scores = None
+        if method == "temporal_importance":                              # valley_model.py:113-121
+            if self.pooling_layer is None:
+                raise RuntimeError("temporal_importance pooling needs model.pooling_layer weights")
+            scores = ops.temporal_scores(feats.reshape(-1, W), self.pooling_layer.weight, self.pooling_layer.bias, sum(Ts))
         outs, f0 = [], 0
         if len(set(Ts)) == 1:
-            pooled = ops.pool_tokens(feats.reshape(-1, W), len(Ts), Ts[0], mode).view(-1, W)
+            pooled = ops.pool_tokens(feats.reshape(-1, W), len(Ts), Ts[0], mode, scores).view(-1, W)
         else:
             for T in Ts:
-                outs.append(ops.pool_tokens(feats[f0:f0 + T].reshape(-1, W), 1, T, mode).view(-1, W))
+                sc = None if scores is None else scores[f0:f0 + T].contiguous()
+                outs.append(ops.pool_tokens(feats[f0:f0 + T].reshape(-1, W), 1, T, mode, sc).view(-1, W))
                 f0 += T
             pooled = torch.cat(outs, 0)
         return pooled, Ts
 
+    def temporal_transformer_delta(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """valley_model.py:123-133 on B clips of T frames (projected feats fp32 [B*T*257, H]) ->
+        bf16 [B, 256+T, H].  Only the last time step of the encoder output is consumed (:130), so the
+        query projection, out_proj, both LayerNorms and the FFN run on 256 rows per clip."""
+        de = self.delta_encoder
+        if de is None:
+            raise RuntimeError("temporal_transformer pooling needs model.transformer_delta_encoder weights")
+        x_all, x16, x32, mean = ops.delta_prep(feats, de["pos"], B, T)
+        kv = ops.gemm(x_all, de["w_kv"], de["b_kv"])                       # [B*256*T, 2H]
+        q = ops.gemm(x16, de["w_q"], de["b_q"])                            # [B*256, H]
+        att = ops.delta_attention(q, kv, T, 8)
+        h1 = ops.gemm(att, de["w_o"], de["b_o"], residual=x32, out_dtype=torch.float32)
+        y16, y32 = ops.layernorm(h1, de["n1_g"], de["n1_b"], 1e-5, want_f32=True)
+        f = ops.gemm(y16, de["w_1"], de["b_1"], epilogue=ops.EPI_RELU)
+        h2 = ops.gemm(f, de["w_2"], de["b_2"], residual=y32, out_dtype=torch.float32)
+        _, delta = ops.layernorm(h2, de["n2_g"], de["n2_b"], 1e-5, want_f32=True)
+        return ops.delta_finish(delta, mean, feats, B, T)
+
     def project_pooled(self, pooled: torch.Tensor) -> torch.Tensor:
         """pooled bf16 [NV, 1024] -> visual tokens bf16 [NV, H] (mm_projector, valley_model.py:190)."""
-        if pooled.shape[-1] == self.config.hidden_size and self.patch_pooling_method == "max":
-            return pooled
+        if pooled.shape[-1] == self.config.hidden_size and self.patch_pooling_method != "mean":
+            return pooled                                    # these variants project every token before pooling
         return ops.gemm(pooled, self.mm_projector.weight, self.mm_projector.bias)
 
     def embed_inputs(self, input_ids, images=None, visual_tokens: Optional[torch.Tensor] = None,
@@ -280,6 +311,23 @@ class ValleyLlamaForCausalLM:
             self.model.mm_projector = HipLinear(_dev(sd["model.mm_projector.weight"], self.device, torch.bfloat16),
                                                 _dev(sd["model.mm_projector.bias"], self.device, torch.float32))
             self.config.use_mm_proj = True
+        if "model.pooling_layer.weight" in sd:               # v2 temporal importance (valley_model.py:42)
+            self.model.pooling_layer = SimpleNamespace(
+                weight=_dev(sd["model.pooling_layer.weight"], self.device, torch.float32).reshape(-1),
+                bias=_dev(sd["model.pooling_layer.bias"], self.device, torch.float32).reshape(-1))
+        pfx = "model.transformer_delta_encoder.layers.0."
+        if pfx + "self_attn.in_proj_weight" in sd:            # v3 temporal transformer (valley_model.py:45-52)
+            d, bf, f32 = self.device, torch.bfloat16, torch.float32
+            H = self.config.hidden_size
+            win, bin_ = _dev(sd[pfx + "self_attn.in_proj_weight"], d, bf), _dev(sd[pfx + "self_attn.in_proj_bias"], d, f32)
+            self.model.delta_encoder = dict(
+                w_q=win[:H].contiguous(), b_q=bin_[:H].contiguous(), w_kv=win[H:].contiguous(), b_kv=bin_[H:].contiguous(),
+                w_o=_dev(sd[pfx + "self_attn.out_proj.weight"], d, bf), b_o=_dev(sd[pfx + "self_attn.out_proj.bias"], d, f32),
+                w_1=_dev(sd[pfx + "linear1.weight"], d, bf), b_1=_dev(sd[pfx + "linear1.bias"], d, f32),
+                w_2=_dev(sd[pfx + "linear2.weight"], d, bf), b_2=_dev(sd[pfx + "linear2.bias"], d, f32),
+                n1_g=_dev(sd[pfx + "norm1.weight"], d, f32), n1_b=_dev(sd[pfx + "norm1.bias"], d, f32),
+                n2_g=_dev(sd[pfx + "norm2.weight"], d, f32), n2_b=_dev(sd[pfx + "norm2.bias"], d, f32),
+                pos=_dev(sd["model.position_matrix"], d, f32))
         vt = {k[len("model.vision_tower."):]: v for k, v in sd.items() if k.startswith("model.vision_tower.")}
         if vt:
             if self.model.vision_tower is None:

@@ -84,6 +84,10 @@ class HipCLIPVisionTower:
             L["w_fc1"], L["b_fc1"] = _dev(g(p + "mlp.fc1.weight"), d, bf), _dev(g(p + "mlp.fc1.bias"), d, f32)
             L["w_fc2"], L["b_fc2"] = _dev(g(p + "mlp.fc2.weight"), d, bf), _dev(g(p + "mlp.fc2.bias"), d, f32)
             self.layers.append(L)
+        if len(self.layers) < c.num_hidden_layers and (prefix + f"encoder.layers.{len(self.layers)}.layer_norm1.weight") not in sd \
+                and not getattr(c, "truncated_ok", False):
+            # a checkpoint of a shallower tower: hidden_states indexing follows the real depth
+            c.num_hidden_layers = len(self.layers)
         self.loaded = True
         return self
 
