@@ -84,6 +84,9 @@ class HipCLIPVisionTower:
             L["w_fc1"], L["b_fc1"] = _dev(g(p + "mlp.fc1.weight"), d, bf), _dev(g(p + "mlp.fc1.bias"), d, f32)
             L["w_fc2"], L["b_fc2"] = _dev(g(p + "mlp.fc2.weight"), d, bf), _dev(g(p + "mlp.fc2.bias"), d, f32)
             self.layers.append(L)
+        if self.layers and self.layers[0]["w_fc1"].shape[0] != c.intermediate_size:
+            c.intermediate_size = int(self.layers[0]["w_fc1"].shape[0])     # trust the checkpoint
+            self._ws.clear()
         if len(self.layers) < c.num_hidden_layers and (prefix + f"encoder.layers.{len(self.layers)}.layer_norm1.weight") not in sd \
                 and not getattr(c, "truncated_ok", False):
             # a checkpoint of a shallower tower: hidden_states indexing follows the real depth
