@@ -91,6 +91,16 @@ int vly_layernorm(const float *x, const float *gamma, const float *beta, void *y
 /* RMSNorm (fp32 statistics) of fp32 [M,D] -> bf16.  hf:llama/modeling_llama.py:61-66.  Same D limits. */
 int vly_rmsnorm(const float *x, const float *gamma, void *y_bf16, int M, int D, float eps, void *stream);
 
+/* Residual update fused with the following norm:  h[M,D] (fp32, in place) += delta (bf16, the output of the
+ *   sub-layer's last GEMM), then y = LayerNorm/RMSNorm(h) -> bf16.  gamma == NULL: add only (the last
+ *   residual update of a stack).  Moves the `residual + hidden_states` of hf:clip/modeling_clip.py:376,381
+ *   and hf:llama/modeling_llama.py:317,323 out of the GEMM epilogue (64-byte row pieces, exposed) into a
+ *   streaming kernel.  Same D limits as vly_layernorm. */
+int vly_add_layernorm(float *h, const void *delta_bf16, const float *gamma, const float *beta, void *y_bf16,
+                      int M, int D, float eps, void *stream);
+int vly_add_rmsnorm(float *h, const void *delta_bf16, const float *gamma, void *y_bf16, int M, int D, float eps,
+                    void *stream);
+
 /* im2col for the 14x14/stride-14 patch conv: images bf16 [F,3,224,224] -> patches bf16 [F*256, 640]
  *   (k = c*196 + ky*14 + kx, columns 588..639 zero) so that Conv2d becomes vly_gemm_bf16 with the
  *   zero-padded [1024,640] weight.  hf:clip/modeling_clip.py:209-210. */

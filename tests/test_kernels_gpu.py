@@ -280,3 +280,27 @@ def test_temporal_importance_pooling():
     pooled = (wt[:, :, None, None] * f[:, :, 1:]).sum(1)
     ref = torch.cat([pooled, f[:, :, 0]], dim=1)
     assert relerr(out, ref) < 3e-3
+
+
+@pytest.mark.parametrize("D,rms", [(1024, False), (4096, True), (5120, True)])
+def test_add_norm(D, rms):
+    """h += delta (bf16) fused with the following LayerNorm / RMSNorm; gamma=None -> add only."""
+    from valley_amd import ops
+    d = dev()
+    M = 333
+    h = rnd((M, D), 60, 2.0)
+    delta = rnd((M, D), 61, 0.5, dtype=torch.bfloat16)
+    g = rnd((D,), 62, 0.1) + 1.0
+    b = rnd((D,), 63, 0.1)
+    hd = h.to(d).clone()
+    y = ops.add_norm(hd, delta.to(d), g.to(d), None if rms else b.to(d), 1e-5, rms=rms)
+    hs = h + delta.float()
+    assert maxabs(hd, hs) == 0.0
+    if rms:
+        ref = g * (hs * torch.rsqrt(hs.pow(2).mean(-1, keepdim=True) + 1e-5))
+    else:
+        ref = torch.nn.functional.layer_norm(hs, (D,), g, b, 1e-5)
+    assert relerr(y, ref) < 3e-3
+    hd2 = h.to(d).clone()
+    assert ops.add_norm(hd2, delta.to(d), None, None, 1e-5, rms=rms) is None
+    assert maxabs(hd2, hs) == 0.0

@@ -14,14 +14,18 @@ constexpr int ROWS_PER_BLOCK = 2;           // 2 waves per block, one row each (
 // read once into registers (NV float4 per lane), statistics in fp32 (two-pass variance on the
 // register copy, like torch), written as 8-byte bf16x4.  bytes/row = 4D read + 2D (+4D) written.
 // ---------------------------------------------------------------------------------------------
-template <int NV, bool RMS>
-__global__ void __launch_bounds__(128) norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// ADD: x is the fp32 residual stream, `delta` the bf16 output of the sub-layer GEMM: the kernel first
+// does x += delta (written back), then normalises the sum — the residual update rides on the
+// streaming norm kernel (5-6 TB/s) instead of the GEMM epilogue (64-byte row pieces, exposed).
+template <int NV, bool RMS, bool ADD>
+__global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const uint16_t* __restrict__ delta,
+                                                   const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, uint16_t* __restrict__ y16,
                                                    float* __restrict__ y32, int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float4* xr = (const float4*)(x + (size_t)row * D);
+    float4* xr = (float4*)(x + (size_t)row * D);
     const int nvec = D >> 2;                 // float4 per row; lane handles v = lane + 64*i
     float4 v[NV];
     float s = 0.f;
@@ -29,9 +33,18 @@ __global__ void __launch_bounds__(128) norm_kernel(const float* __restrict__ x, 
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (ADD) {
+            if (c < nvec) {
+                const u32x2 dk = *(const u32x2*)(delta + (size_t)row * D + 4 * c);
+                v[i].x += __uint_as_float(dk[0] << 16); v[i].y += __uint_as_float(dk[0] & 0xffff0000u);
+                v[i].z += __uint_as_float(dk[1] << 16); v[i].w += __uint_as_float(dk[1] & 0xffff0000u);
+                xr[c] = v[i];
+            }
+        }
         if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         else s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
+    if (gamma == nullptr) return;            // ADD-only call (last residual update of the stack)
     s = wave_sum(s);
     float mean = 0.f, rstd;
     if constexpr (RMS) {
@@ -143,20 +156,26 @@ __global__ void __launch_bounds__(256) norm_row_kernel(const float* __restrict__
 }
 
 template <bool RMS>
-int launch_norm(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int M, int D, float eps,
-                hipStream_t st, const char* name) {
-    if (M <= 0 || D <= 0 || D % 4 || D > 8192 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) ||
+int launch_norm(const float* x, const void* delta, const float* gamma, const float* beta, void* y16, float* y32, int M, int D,
+                float eps, hipStream_t st, const char* name) {
+    if (M <= 0 || D <= 0 || D % 4 || D > 8192 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)delta & 7) ||
         (beta && ((uintptr_t)beta & 15)) || ((uintptr_t)y16 & 7) || ((uintptr_t)y32 & 15)) {
         vly_set_error("%s: unsupported shape/alignment M=%d D=%d", name, M, D);
         return -22;
     }
-    if (M <= 64) {
+    if (M <= 64 && !delta) {
         hipLaunchKernelGGL((norm_row_kernel<RMS>), dim3(M), dim3(256), 0, st, x, gamma, beta, (uint16_t*)y16, y32, D, eps);
         return vly_check_launch(name);
     }
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     const int nv = (D / 4 + 63) / 64;
-#define VLY_NORM(NV) hipLaunchKernelGGL((norm_kernel<NV, RMS>), grid, block, 0, st, x, gamma, beta, (uint16_t*)y16, y32, M, D, eps)
+#define VLY_NORM(NV)                                                                                              \
+    do {                                                                                                          \
+        if (delta) hipLaunchKernelGGL((norm_kernel<NV, RMS, true>), grid, block, 0, st, (float*)x, (const uint16_t*)delta, \
+                                      gamma, beta, (uint16_t*)y16, y32, M, D, eps);                               \
+        else hipLaunchKernelGGL((norm_kernel<NV, RMS, false>), grid, block, 0, st, (float*)x, (const uint16_t*)nullptr,   \
+                                gamma, beta, (uint16_t*)y16, y32, M, D, eps);                                     \
+    } while (0)
     if (nv <= 4) VLY_NORM(4);
     else if (nv <= 8) VLY_NORM(8);
     else if (nv <= 16) VLY_NORM(16);
@@ -382,11 +401,23 @@ __global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x
 extern "C" int vly_layernorm(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                              int M, int D, float eps, void* stream) {
     if (!beta) { vly_set_error("vly_layernorm: beta is required"); return -22; }
-    return launch_norm<false>(x, gamma, beta, y_bf16, y_f32, M, D, eps, (hipStream_t)stream, "vly_layernorm");
+    return launch_norm<false>(x, nullptr, gamma, beta, y_bf16, y_f32, M, D, eps, (hipStream_t)stream, "vly_layernorm");
 }
 
 extern "C" int vly_rmsnorm(const float* x, const float* gamma, void* y_bf16, int M, int D, float eps, void* stream) {
-    return launch_norm<true>(x, gamma, nullptr, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_rmsnorm");
+    return launch_norm<true>(x, nullptr, gamma, nullptr, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_rmsnorm");
+}
+
+extern "C" int vly_add_layernorm(float* h, const void* delta_bf16, const float* gamma, const float* beta, void* y_bf16,
+                                 int M, int D, float eps, void* stream) {
+    if (!delta_bf16 || (gamma && !beta)) { vly_set_error("vly_add_layernorm: delta (and beta with gamma) required"); return -22; }
+    return launch_norm<false>(h, delta_bf16, gamma, beta, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_add_layernorm");
+}
+
+extern "C" int vly_add_rmsnorm(float* h, const void* delta_bf16, const float* gamma, void* y_bf16, int M, int D, float eps,
+                               void* stream) {
+    if (!delta_bf16) { vly_set_error("vly_add_rmsnorm: delta required"); return -22; }
+    return launch_norm<true>(h, delta_bf16, gamma, nullptr, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_add_rmsnorm");
 }
 
 extern "C" int vly_patchify(const void* images, void* patches, int F, void* stream) {

@@ -24,6 +24,8 @@ _SIGS = {
     "vly_gemm_streamk_tile_for": (c_int, [c_int, c_int, c_int]),
     "vly_layernorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_rmsnorm": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
+    "vly_add_layernorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "vly_add_rmsnorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_patchify": (c_int, [_P, _P, c_int, _P]),
     "vly_vit_embed_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_float, _P]),
     "vly_vit_attention": (c_int, [_P, _P, c_int, _P]),

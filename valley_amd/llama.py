@@ -126,7 +126,8 @@ class HipLlama:
         if ws is None:
             d, bf = self.device, torch.bfloat16
             ws = dict(x=torch.empty((M, self.H), dtype=bf, device=d), qkv=torch.empty((M, 3 * self.H), dtype=bf, device=d),
-                      att=torch.empty((M, self.H), dtype=bf, device=d), mlp=torch.empty((M, self.I), dtype=bf, device=d))
+                      att=torch.empty((M, self.H), dtype=bf, device=d), mlp=torch.empty((M, self.I), dtype=bf, device=d),
+                      delta=torch.empty((M, self.H), dtype=bf, device=d))
             if len(self._ws) > 6:
                 self._ws.clear()
             self._ws[M] = ws
@@ -146,17 +147,30 @@ class HipLlama:
         ws = self._workspace(M)
         kv = cache.key_valid                                # uint8 [B, ctx_max] or None (row stride = ctx_max)
         nl = self.L if n_layers is None else n_layers
+        fused = M > 8            # prefill: residual adds ride on the norm kernels; decode keeps the GEMV epilogue
         for li in range(nl):
             L = self.layers[li]
-            ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
+            if fused and li > 0:
+                ops.add_norm(h, ws["delta"], L["ln1"], None, self.eps, out=ws["x"], rms=True)
+            else:
+                ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
             ops.gemm(ws["x"], L["w_qkv"], out=ws["qkv"])
             ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
             ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
-            ops.gemm(ws["att"], L["w_o"], residual=h, out=h)
-            ops.rmsnorm(h, L["ln2"], self.eps, out=ws["x"])
+            if fused:
+                ops.gemm(ws["att"], L["w_o"], out=ws["delta"])
+                ops.add_norm(h, ws["delta"], L["ln2"], None, self.eps, out=ws["x"], rms=True)
+            else:
+                ops.gemm(ws["att"], L["w_o"], residual=h, out=h)
+                ops.rmsnorm(h, L["ln2"], self.eps, out=ws["x"])
             ops.gemm(ws["x"], L["w_gu"], epilogue=ops.EPI_SWIGLU, out=ws["mlp"])
-            ops.gemm(ws["mlp"], L["w_down"], residual=h, out=h)
+            if fused:
+                ops.gemm(ws["mlp"], L["w_down"], out=ws["delta"])
+            else:
+                ops.gemm(ws["mlp"], L["w_down"], residual=h, out=h)
         cache.seq_len = past + S
+        if fused and nl > 0:
+            return ops.add_norm(h, ws["delta"], self.norm, None, self.eps, out=ws["x"], rms=True)
         return ops.rmsnorm(h, self.norm, self.eps, out=ws["x"])
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:

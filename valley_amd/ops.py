@@ -222,6 +222,25 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: Optional[torc
     return y
 
 
+def add_norm(h: torch.Tensor, delta: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+             out: Optional[torch.Tensor] = None, rms: bool = False) -> Optional[torch.Tensor]:
+    """h (fp32, in place) += delta (bf16); returns norm(h) as bf16 (None when gamma is None: add only)."""
+    _chk(h, torch.float32, "h")
+    _chk(delta, torch.bfloat16, "delta")
+    M, D = h.shape
+    assert tuple(delta.shape) == (M, D)
+    y = None
+    if gamma is not None:
+        y = out if out is not None else torch.empty((M, D), dtype=torch.bfloat16, device=h.device)
+    L = _lib.load()
+    if rms:
+        rc = L.vly_add_rmsnorm(h.data_ptr(), delta.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())
+    else:
+        rc = L.vly_add_layernorm(h.data_ptr(), delta.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(y), M, D, eps, _stream())
+    _lib.check(rc, "vly_add_norm")
+    return y
+
+
 def patchify(images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[F,3,224,224] bf16 -> [F*256, 640] bf16."""
     _chk(images, torch.bfloat16, "images")

@@ -129,6 +129,7 @@ class HipCLIPVisionTower:
                       x=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
                       qkv=torch.empty((M, 3072), dtype=torch.bfloat16, device=d),
                       att=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
+                      delta=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
                       mlp=torch.empty((M, I), dtype=torch.bfloat16, device=d))
             if len(self._ws) > 4:
                 self._ws.clear()
@@ -150,17 +151,25 @@ class HipCLIPVisionTower:
         ops.gemm(ws["cols"], self.w_patch, out=ws["patch"])
         return ops.vit_embed_ln(ws["patch"], self.cls, self.pos, self.pre_g, self.pre_b, F, self.config.layer_norm_eps, out=h)
 
-    def layer_forward(self, h: torch.Tensor, L: Dict[str, torch.Tensor], F: int):
-        """One pre-LN encoder layer, in place on the fp32 residual stream h [F*257,1024]."""
+    def layer_forward(self, h: torch.Tensor, L: Dict[str, torch.Tensor], F: int, pending: bool, nxt):
+        """One pre-LN encoder layer on the fp32 residual stream h [F*257,1024] (in place).  The residual
+        adds ride on the norm kernels: on entry ``pending`` says that ws["delta"] still holds the previous
+        layer's MLP output (added here, together with LN1); on exit ws["delta"] holds this layer's MLP
+        output, to be added by the next layer's first norm — or by the caller (``nxt`` is None)."""
         ws = self._workspace(F)
         eps = self.config.layer_norm_eps
-        ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
+        if pending:
+            ops.add_norm(h, ws["delta"], L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
+        else:
+            ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
         ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
-        ops.gemm(ws["att"], L["w_o"], L["b_o"], residual=h, out=h)
-        ops.layernorm(h, L["ln2_g"], L["ln2_b"], eps, out=ws["x"])
+        ops.gemm(ws["att"], L["w_o"], L["b_o"], out=ws["delta"])
+        ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"])
         ops.gemm(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
-        ops.gemm(ws["mlp"], L["w_fc2"], L["b_fc2"], residual=h, out=h)
+        ops.gemm(ws["mlp"], L["w_fc2"], L["b_fc2"], out=ws["delta"])
+        if nxt is None:
+            ops.add_norm(h, ws["delta"], None, None, eps)               # last residual update of the stack
 
     def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: int = 256,
                keep_all: bool = False):
@@ -182,8 +191,10 @@ class HipCLIPVisionTower:
             h = out[f0 * 257:(f0 + F) * 257]
             self.embed(frames[f0:f0 + F], h)
             states = [h.clone()] if keep_all else None
-            for L in self.layers[:nl]:
-                self.layer_forward(h, L, F)
+            for li, L in enumerate(self.layers[:nl]):
+                last = li == nl - 1
+                # with keep_all every layer flushes its pending MLP output so that h is a complete hidden state
+                self.layer_forward(h, L, F, pending=(li > 0 and not keep_all), nxt=None if (last or keep_all) else True)
                 if keep_all:
                     states.append(h.clone())
             if keep_all:
