@@ -274,8 +274,18 @@ def main():
             dom = max(agg.items(), key=lambda kv: kv[1][0])
             name, (tsum, fsum, n) = dom
             ach = fsum / tsum / 1e12
+            traffic = None                                      # HBM bytes per launch from a committed PMC run
+            tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.config}.json")
+            if os.path.exists(tpath):
+                tk = json.load(open(tpath)).get("kernels", {})
+                key = name.replace(" ", "")
+                for k, v in tk.items():
+                    if k.replace(" ", "") == key:
+                        traffic = v["hbm_bytes_per_launch"]
             result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                                  "traffic_source": "profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                                    "x1024, separate passes; tools/pmc_traffic.sh)" % args.config if traffic else None,
                                   "launches": n, "avg_launch_us": round(tsum / n * 1e6, 2),
                                   "avg_flop_per_launch": round(fsum / n / 1e9, 3),
                                   "share_of_step_time": round(tsum / args.steps / (ms_step * 1e-3), 3),
