@@ -320,3 +320,36 @@ def test_from_pretrained_checkpoint_roundtrip(tmp_path):
     img1 = torch.from_numpy(G.golden_pixels(c["T"], "mixed")).view(1, c["T"], 3, 224, 224).cuda()
     out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1)
     assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < 6e-2
+
+
+def test_generate_video_stream_matches_reference_loop():
+    """the worker's streaming loop (model_worker.py:321-426) on the HIP path — chunks,
+    prompt expansion with the real frame count, greedy decode — equals the same loop written with the
+    generic forward (the structure of the reference), token for token."""
+    import json
+    from tests.fake_tokenizer import SPECIALS, FakeTokenizer
+    from valley_amd.serving import expand_video_prompt, generate_video_stream
+    model = build_golden_model()
+    model.config.mm_use_im_start_end = True
+    T = G.GCFG["T"]
+    tok = FakeTokenizer(G.GCFG["vocab_text"])
+    tok.add_tokens(SPECIALS[:2], special_tokens=True)       # same id order as valley_model.py:357-360
+    tok.add_tokens(SPECIALS[2:], special_tokens=True)
+    for k in ("im_patch_token", "vi_frame_token", "im_start_token", "im_end_token", "vi_start_token", "vi_end_token"):
+        assert getattr(model.get_model().vision_tower.config, k) == G.special()[k]
+    video = torch.from_numpy(G.golden_pixels(T, "mixed")).permute(1, 0, 2, 3).contiguous()      # [3,T,224,224]
+    params = dict(prompt="describe <video> please now", temperature=0.0, max_new_tokens=9, stop="###")
+    chunks = [json.loads(c[:-1]) for c in generate_video_stream(model, tok, params, video=video.cuda(), stream_interval=2)]
+    assert all(c["error_code"] == 0 for c in chunks) and len(chunks) == 6       # i = 0,2,4,6,8 and the last
+    # reference-structured loop on the generic forward
+    ids = tok(expand_video_prompt(params["prompt"], T)).input_ids
+    out = model(input_ids=torch.as_tensor([ids]).cuda(), images=video.permute(1, 0, 2, 3).unsqueeze(0).cuda(), use_cache=True)
+    past, pred = out.past_key_values, []
+    logits = out.logits
+    for i in range(9):
+        token = int(torch.argmax(logits[0][-1]))
+        pred.append(token)
+        o = model(input_ids=torch.as_tensor([[token]]).cuda(), use_cache=True, past_key_values=past,
+                  attention_mask=torch.ones(1, past[0][0].shape[-2] + 1).cuda())
+        logits, past = o.logits, o.past_key_values
+    assert chunks[-1]["text"] == params["prompt"] + tok.decode(pred)

@@ -16,7 +16,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = os.path.join(d, f"{c}_counter_collection.csv")
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c:
-            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            name = re.sub(r">\(.*", ">", name) if ">(" in name else re.sub(r"\(.*", "", name)
             agg[name][c].append(float(r["Counter_Value"]))
 out = {}
 for k, v in agg.items():

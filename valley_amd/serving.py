@@ -1,0 +1,92 @@
+"""The decode service loop of the reference worker (valley/serve/model_worker.py:321-426) on the HIP
+path: prompt expansion with the clip's real frame count, prefill, per-token KV decode
+with greedy / temperature sampling, stop-token and stop-string handling, and ``json\\0`` chunks every
+``stream_interval`` tokens.  The HTTP fabric around it (FastAPI worker, controller, gradio) is out of
+scope; this generator is what those routes would wrap.
+
+Decode steps run through the hipGraph-captured ``DecodeSession``: the greedy token never leaves the
+device between steps; with temperature sampling the step's logits are sampled by torch.multinomial (as in
+the reference) and the chosen token is written back into the session's input slot."""
+from __future__ import annotations
+
+import json
+from typing import Iterator, Optional
+
+import torch
+
+from .decode import DecodeSession
+from .valley_model import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_VI_END_TOKEN,
+                           DEFAULT_VI_START_TOKEN, DEFAULT_VIDEO_FRAME_TOKEN, DEFAULT_VIDEO_TOKEN)
+
+
+def expand_video_prompt(prompt: str, n_frames: int, use_im_start_end: bool = True) -> str:
+    """model_worker.py:338-341."""
+    replace_token = DEFAULT_IMAGE_PATCH_TOKEN * 256
+    if use_im_start_end:
+        replace_token = DEFAULT_IM_START_TOKEN + replace_token + DEFAULT_IM_END_TOKEN + DEFAULT_VI_START_TOKEN + \
+            DEFAULT_VIDEO_FRAME_TOKEN * n_frames + DEFAULT_VI_END_TOKEN
+    return prompt.replace(DEFAULT_VIDEO_TOKEN, replace_token)
+
+
+def generate_video_stream(model, tokenizer, params: dict, video: Optional[torch.Tensor] = None, stream_interval: int = 2,
+                          context_len: int = 2048, use_graph: bool = True) -> Iterator[bytes]:
+    """``params``: prompt, temperature, max_new_tokens, stop (model_worker.py:323-358).  ``video``: preprocessed
+    frames [3,T,224,224] (what ``load_video`` returns) or None."""
+    prompt = params["prompt"]
+    ori_prompt = prompt
+    images = None
+    if video is not None:
+        assert prompt.count(DEFAULT_VIDEO_TOKEN) == 1, "Number of video does not match number of <video> tokens in prompt"
+        frames = video.permute(1, 0, 2, 3)
+        prompt = expand_video_prompt(prompt, frames.shape[0], getattr(model.config, "mm_use_im_start_end", True))
+        images = frames.unsqueeze(0)
+    temperature = float(params.get("temperature", 1.0))
+    max_new_tokens = min(int(params.get("max_new_tokens", 256)), 1024)
+    stop_str = params.get("stop", None)
+    stop_idx = None
+    if stop_str is not None:
+        stop_idx = tokenizer(stop_str).input_ids
+        stop_idx = stop_idx[0] if len(stop_idx) == 1 else None
+    input_ids = tokenizer(prompt).input_ids
+    max_src_len = context_len - max_new_tokens - 8
+    input_ids = input_ids[-max_src_len:]
+    pred_ids = []
+    dev = model.device
+    ll = model.get_model().llama
+    cache = ll.new_cache(1, min(context_len, len(input_ids) + max_new_tokens + 1))
+    sess = None
+    ret = None
+    for i in range(max_new_tokens):
+        if i == 0:
+            out = model(input_ids=torch.as_tensor([input_ids], device=dev), use_cache=True, images=images, past_key_values=cache)
+            last = out.logits[0, -1]
+        else:
+            if sess is None:
+                sess = DecodeSession(ll, cache, use_graph=use_graph)
+                sess.begin(torch.as_tensor([token], device=dev))
+            else:
+                sess.tok.copy_(torch.as_tensor([token], device=dev, dtype=torch.int32))
+            sess.step()
+            last = sess.logits[0, :ll.V]
+        if temperature < 1e-4:
+            token = int(torch.argmax(last))
+        else:
+            probs = torch.softmax(last / temperature, dim=-1)
+            token = int(torch.multinomial(probs, num_samples=1))
+        pred_ids.append(token)
+        if stop_idx is not None and token == stop_idx:
+            stopped = True
+        elif token == getattr(tokenizer, "eos_token_id", None):
+            stopped = True
+        else:
+            stopped = False
+        if i % stream_interval == 0 or i == max_new_tokens - 1 or stopped:
+            cur_out = tokenizer.decode(pred_ids, skip_special_tokens=True)
+            pos = cur_out.rfind(stop_str) if stop_str is not None else -1
+            if pos != -1:
+                cur_out = cur_out[:pos]
+                stopped = True
+            ret = {"text": ori_prompt + cur_out, "error_code": 0}
+            yield json.dumps(ret).encode() + b"\0"
+        if stopped or cache.seq_len + 1 > cache.ctx_max:
+            break
