@@ -187,6 +187,18 @@ int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *
  *   projector has to see every token, valley_model.py:190,209). */
 int vly_cast_f32_bf16(const float *x, void *y_bf16, long n, void *stream);
 
+/* Frame preprocessing in front of the path (valley/util/data_util.py:262-281): Pillow's 8-bit separable
+ *   bilinear resample restricted to the centre crop, then /255 and CLIP mean/std.
+ *   vly_resize_h_u8:   in u8 [T,H,W,3] -> out u8 [T,H,OW,3]; bounds int32 [OW,2] (first input x, tap
+ *                      count), taps int32 [OW,ksize] (22-bit fixed point) for the OW kept columns.
+ *   vly_resize_v_norm: in u8 [T,H,W,3] -> out bf16|fp32 [T,3,OS,OS]; vertical taps for the OS kept rows,
+ *                      columns x_off .. x_off+OS-1, out = (clip8(acc>>22)/255 - mean[c]) / std[c]. */
+int vly_resize_h_u8(const uint8_t *in, const int32_t *bounds, const int32_t *taps, uint8_t *out,
+                    int T, int H, int W, int OW, int ksize, void *stream);
+int vly_resize_v_norm(const uint8_t *in, const int32_t *bounds, const int32_t *taps, const float *mean,
+                      const float *stdv, void *out, int T, int H, int W, int x_off, int OS, int ksize,
+                      int out_f32, void *stream);
+
 /* p[i] += delta for i < n (the device-side position counter of a captured decode step). */
 int vly_incr_i32(int32_t *p, int n, int delta, void *stream);
 

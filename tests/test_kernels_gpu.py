@@ -304,3 +304,19 @@ def test_add_norm(D, rms):
     hd2 = h.to(d).clone()
     assert ops.add_norm(hd2, delta.to(d), None, None, 1e-5, rms=rms) is None
     assert maxabs(hd2, hs) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 360, 480), (2, 480, 270), (1, 200, 310), (3, 256, 256), (1, 720, 1280)])
+def test_preprocess_frames_gpu_vs_oracle(shape):
+    """N2: GPU Pillow-equivalent resize + crop + normalise vs the CPU oracle (itself bit-exact vs PIL and
+    pinned to the reference fixture).  fp32 output: bit-level (same integer resample, same fp32 formula
+    up to one ulp of the division); bf16 output: one rounding."""
+    from oracle import preprocess_oracle as P
+    from valley_amd.preprocess import preprocess_frames_gpu
+    T, H, Wd = shape
+    frames = np.random.default_rng(H + Wd).integers(0, 256, (T, H, Wd, 3), dtype=np.uint8)
+    ref = torch.from_numpy(P.preprocess_frames(frames)).permute(1, 0, 2, 3)          # [T,3,224,224]
+    got = preprocess_frames_gpu(torch.from_numpy(frames).to(dev()), out_dtype=torch.float32)
+    assert maxabs(got, ref) < 2e-6
+    got16 = preprocess_frames_gpu(torch.from_numpy(frames).to(dev()))
+    assert maxabs(got16, ref.to(torch.bfloat16)) <= 0.016

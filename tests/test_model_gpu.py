@@ -340,7 +340,7 @@ def test_generate_video_stream_matches_reference_loop():
     video = torch.from_numpy(G.golden_pixels(T, "mixed")).permute(1, 0, 2, 3).contiguous()      # [3,T,224,224]
     params = dict(prompt="describe <video> please now", temperature=0.0, max_new_tokens=9, stop="###")
     chunks = [json.loads(c[:-1]) for c in generate_video_stream(model, tok, params, video=video.cuda(), stream_interval=2)]
-    assert all(c["error_code"] == 0 for c in chunks) and len(chunks) == 6       # i = 0,2,4,6,8 and the last
+    assert all(c["error_code"] == 0 for c in chunks) and len(chunks) == 5       # i = 0,2,4,6,8 (8 is also the last)
     # reference-structured loop on the generic forward
     ids = tok(expand_video_prompt(params["prompt"], T)).input_ids
     out = model(input_ids=torch.as_tensor([ids]).cuda(), images=video.permute(1, 0, 2, 3).unsqueeze(0).cuda(), use_cache=True)

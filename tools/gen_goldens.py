@@ -47,8 +47,19 @@ def import_reference():
         sys.modules[name] = m
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     sys.modules["skimage"].transform = sys.modules["skimage.transform"]
-    sys.path.insert(0, "/root/reference")
-    import valley.model.valley_model as vm
+    # This repo ships its own drop-in ``valley`` package (a regular package, which would shadow the
+    # reference's namespace package whatever the path order): take the repo root (and cwd) off sys.path
+    # while the reference is imported, and make sure the module that comes back IS the reference's file.
+    for k in [k for k in sys.modules if k == "valley" or k.startswith("valley.")]:
+        del sys.modules[k]
+    saved = list(sys.path)
+    sys.path[:] = ["/root/reference"] + [p for p in saved if os.path.abspath(p or ".") != ROOT]
+    try:
+        import valley.model.valley_model as vm
+        import valley.data.video_transform  # noqa: F401  (used by tools/gen_preprocess_goldens.py)
+    finally:
+        sys.path[:] = saved
+    assert vm.__file__.startswith("/root/reference/"), vm.__file__
     return vm
 
 

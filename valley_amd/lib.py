@@ -37,6 +37,8 @@ _SIGS = {
     "vly_embed_splice": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "vly_rope_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_llama_attention": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "vly_resize_h_u8": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_resize_v_norm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
