@@ -79,8 +79,9 @@ def preprocess_frames_gpu(frames_u8: torch.Tensor, out_dtype=torch.bfloat16, sca
         bw, kw = resample_tables(Wd, nw)
         bw, kw = bw[x1:x1 + crop].copy(), kw[x1:x1 + crop].copy()
         tmp = torch.empty((T, H, crop, 3), dtype=torch.uint8, device=d)
-        rc = L.vly_resize_h_u8(src.data_ptr(), torch.from_numpy(bw).to(d).data_ptr(), torch.from_numpy(kw).to(d).data_ptr(),
-                               tmp.data_ptr(), T, H, Wd, crop, kw.shape[1], _stream())
+        bw_d, kw_d = torch.from_numpy(bw).to(d), torch.from_numpy(kw).to(d)      # keep alive across the launch
+        rc = L.vly_resize_h_u8(src.data_ptr(), bw_d.data_ptr(), kw_d.data_ptr(), tmp.data_ptr(), T, H, Wd, crop, kw.shape[1],
+                               _stream())
         _lib.check(rc, "vly_resize_h_u8")
         src, x_off = tmp, 0
     else:
