@@ -514,8 +514,12 @@ class ValleyLlamaForCausalLM:
         from .video import KeywordsStoppingCriteria, load_video
         inputs = self.build_inputs(tokenizer, message)
         input_ids = torch.as_tensor(inputs.input_ids).to(self.device)
-        images = video if isinstance(video, torch.Tensor) else load_video(video)
-        images = images.permute(1, 0, 2, 3).unsqueeze(0)
+        if isinstance(video, (np.ndarray, torch.Tensor)) and video.dtype in (np.uint8, torch.uint8):
+            from .video import load_video_gpu               # decoded frames [N,H,W,3]: preprocess on the GPU
+            images = load_video_gpu(video, device=self.device)
+        else:
+            images = video if isinstance(video, torch.Tensor) else load_video(video)
+            images = images.permute(1, 0, 2, 3).unsqueeze(0)
         stopping = KeywordsStoppingCriteria(['###'], tokenizer, input_ids)
         gk = {k: v for k, v in gen_kwargs.items() if k in ("max_new_tokens", "do_sample", "temperature", "eos_token_id")}
         output_ids = self.generate(input_ids=input_ids, images=images, stopping_criteria=[stopping], **gk)

@@ -73,3 +73,15 @@ def load_video(path, fixed_frame_number: int = 8) -> torch.Tensor:
     else:
         raise FileNotFoundError(path)
     return preprocess_frames(frames[sample_indices(len(frames), fixed_frame_number)])
+
+
+def load_video_gpu(frames_u8, device="cuda:0", fixed_frame_number: int = 8, dtype=torch.bfloat16) -> torch.Tensor:
+    """Decoded frames uint8 [N,H,W,3] (numpy or tensor) -> the hot path's input [1,T,3,224,224] on the
+    device: uniform sampling of ``fixed_frame_number`` frames (data_util.py:264-265), then the GPU
+    preprocessing kernels (valley_amd/preprocess.py; Pillow-exact resize, crop, normalise)."""
+    from .preprocess import preprocess_frames_gpu
+    if isinstance(frames_u8, np.ndarray):
+        frames_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8))
+    idx = torch.from_numpy(sample_indices(frames_u8.shape[0], fixed_frame_number))
+    sel = frames_u8[idx].to(device).contiguous()
+    return preprocess_frames_gpu(sel, out_dtype=dtype).unsqueeze(0)
