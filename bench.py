@@ -220,6 +220,7 @@ def main():
             stage_events.append((e0, e1, e2))
         return out
 
+    step(False)              # untimed: first use of every GEMM shape runs the one-off kernel selection (ops._tune)
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
