@@ -13,16 +13,17 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 VLY_DEVICE float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet); matches torch's .to(bfloat16)
-VLY_DEVICE uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even: the native conversion lowers to ONE v_cvt_pk_bf16_f32 per pair
+// on gfx950 (a hand-written integer RNE costs ~6 VALU ops per value, which showed up in the attention
+// softmax and in every GEMM epilogue).
+typedef __attribute__((ext_vector_type(2))) float vly_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vly_bf16x2;
+
+VLY_DEVICE uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 VLY_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const vly_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vly_bf16x2));
 }
 
 // D(16x16) += A(16x32) * B(32x16).  Lane l supplies A[row = l&15][k = 8*(l>>4) .. +7] and
