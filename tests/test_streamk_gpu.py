@@ -19,7 +19,7 @@ SHAPES = [(1312, 4096, 4096), (1312, 12288, 4096), (8224, 1024, 1024), (8224, 30
           (64, 512, 64), (2688, 5120, 1024), (513, 4096, 640), (1028, 1024, 4096)]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 41, 42, 45])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_streamk_matches_tile_kernel(M, N, K, tile):
     from valley_amd import ops

@@ -33,7 +33,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int OUT>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
                const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc,
-               int ldr, int tiles_m, int tiles_n, int m_fast, int total_iters, float* __restrict__ slabs,
+               int ldr, int tiles_m, int tiles_n, int m_fast, int total_iters, int unit, float* __restrict__ slabs,
                unsigned* __restrict__ flags, unsigned epoch) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
@@ -53,8 +53,11 @@ gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     const int G = gridDim.x;
     const int w = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
     const int nk = K / BK;
-    const int q = total_iters / G, rem = total_iters % G;
-    auto range_begin = [&](int x) { return x * q + min(x, rem); };
+    // unit == 1: ranges may cut tiles anywhere (stream-K); unit == nk: ranges are whole tiles (persistent
+    // data-parallel: no fix-up, still no per-tile prologue bubble)
+    const int units = total_iters / unit;
+    const int q = units / G, rem = units % G;
+    auto range_begin = [&](int x) { return (x * q + min(x, rem)) * unit; };
     const int it0 = range_begin(w), it1 = range_begin(w + 1);
     if (it0 >= it1) return;
 
@@ -227,14 +230,16 @@ int num_cus() {
 
 template <int BM, int BN, int WM, int WN, int PER_CU>
 int launch_sk(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
-              int ldw, int ldc, int ldr, int epi, int out, void* ws, size_t ws_bytes, unsigned epoch, hipStream_t st) {
+              int ldw, int ldc, int ldr, int epi, int out, void* ws, size_t ws_bytes, unsigned epoch, hipStream_t st,
+              bool aligned = false) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const long total = (long)tm * tn * (K / BK);
     const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
     int G = num_cus() * PER_CU;
     G -= G & 7;
-    if (total < G) G = (int)total;
+    const int unit = aligned ? K / BK : 1;
+    if (total / unit < G) G = (int)(total / unit);
     // workspace = [FLAG_BYTES of flags (fixed place: stale contents are always old epochs)] [G slabs]
     const size_t need = FLAG_BYTES + (size_t)G * BM * BN * 4;
     if (!ws || ws_bytes < need || (size_t)(G + 8) * 4 > FLAG_BYTES) {
@@ -246,7 +251,7 @@ int launch_sk(const void* A, const void* W, const float* bias, const float* R, v
     dim3 grid(G), block(NT);
 #define VLY_SK_LAUNCH(E, O)                                                                                 \
     hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, E, O>), grid, block, 0, st, (const uint16_t*)A,      \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, (int)total, slabs, flags, epoch)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, (int)total, unit, slabs, flags, epoch)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_SK_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_SK_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
@@ -319,6 +324,12 @@ extern "C" int vly_gemm_bf16_streamk(const void* A, const void* W, const float* 
         case 3: return launch_sk<256, 128, 64, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
         case 4: return launch_sk<128, 256, 64, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
         case 5: return launch_sk<192, 256, 96, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st);
+        // 41..45: persistent whole-tile ranges (no fix-up)
+        case 41: return launch_sk<256, 256, 128, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st, true);
+        case 42: return launch_sk<128, 128, 64, 64, 2>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st, true);
+        case 43: return launch_sk<256, 128, 64, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st, true);
+        case 44: return launch_sk<128, 256, 64, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st, true);
+        case 45: return launch_sk<192, 256, 96, 64, 1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace, workspace_bytes, epoch, st, true);
         default: vly_set_error("vly_gemm_bf16_streamk: bad tile_hint %d", tile_hint); return -22;
     }
 }

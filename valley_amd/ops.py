@@ -69,6 +69,8 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     if rec is not None:
         sk = fn_name.endswith("streamk")
         tile = extra[0] or (L.vly_gemm_streamk_tile_for(M, N, K) if sk else L.vly_gemm_tile_for(M, N))
+        if sk:
+            tile %= 40 if tile > 40 else 100
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
