@@ -58,8 +58,9 @@ const char *vly_last_error(void);
  *   mm_projector (valley_model.py:54-55,190), Llama q/k/v/o (hf:llama/modeling_llama.py:230-241),
  *   gate/up/down (:166-168), lm_head (valley_model.py:264,305).
  *   tile_hint: 0 = auto, 1 = 256x256, 2 = 128x128, 3 = 256x128, 4 = 128x256, 5 = 192x256 (BM x BN);
- *   +10 selects the counted-vmcnt half-tile pipeline, +30 (8-wave tiles: 31, 33, 34, 35) the role-split
- *   pipeline (the two waves of a SIMD run one phase apart) instead of the 2-stage loop (tuning / tests). */
+ *   +10 selects the counted-vmcnt half-tile pipeline; +30 / +50 (8-wave tiles only) the role-split pipelines
+ *   (the two waves of a SIMD run one phase apart; +50 keeps whole-K-tile staging with 128-byte LDS rows and
+ *   is the fastest loop on most shapes) instead of the plain 2-stage loop (tuning / tests). */
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);

@@ -194,6 +194,71 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             __builtin_amdgcn_s_barrier();
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (PIPE == 4) {
+        // ================= role-split over the 2-stage full-tile buffers (8 waves) ==========================
+        // Same staging as PIPE 0 (whole K tiles, 128-byte LDS rows -> full-line global reads), but the K tile
+        // is computed in two phases (k-step 0, k-step 1) and wave group 1 (waves 4-7, the SIMD partners of
+        // waves 0-3) runs one phase behind group 0: R0 = {issue loads of tile t+1, read k-step-0 fragments},
+        // M0, R1 = {read k-step-1 fragments}, M1 — one raw barrier after every phase, MFMA phases at
+        // s_setprio 1, vmcnt(0) once per tile before the barrier that precedes the first read of tile t+1.
+        static_assert(NW == 8, "role-split pipeline needs two waves per SIMD");
+        uint32_t offA[PA], offW[PW];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+        auto stage = [&](int kt, int buf) {
+            char* sA = smem + buf * STAGE;
+            char* sW = sA + A_BYTES;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+        };
+        const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
+        const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+        const int grp = wave >> 2;
+
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // tile 0 visible to everyone
+        if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 starts one phase late
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* cur = smem + (kt & 1) * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // ---------------- R phase
+                if (kk == 0 && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+                const int sw = kk ? sw1 : sw0;
+                bf16x8 af[MI], wf[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
+                if (kk == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my loads of tile kt+1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- M phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
     } else {
         // ================= 4-region half-tile pipeline: counted vmcnt, raw barrier ======================
         // The K loop advances in HALF tiles (32 k = one MFMA k-step = 64-byte LDS rows).  LDS holds four
@@ -367,15 +432,16 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
                       M, N, K, lda, ldw, ldc, ldr);
         return -22;
     }
-    if ((size_t)M * lda >= (1ull << 32) || (size_t)N * ldw >= (1ull << 32)) {
-        vly_set_error("vly_gemm_bf16: operand exceeds 2^32 elements");
+    if ((size_t)M * lda >= (1ull << 31) || (size_t)N * ldw >= (1ull << 31)) {
+        vly_set_error("vly_gemm_bf16: operand exceeds 2^31 elements (32-bit byte offsets)");
         return -22;
     }
     if (epilogue == VLY_EPI_SWIGLU && residual) { vly_set_error("vly_gemm_bf16: SWIGLU takes no residual"); return -22; }
     hipStream_t st = (hipStream_t)stream;
     const int t = tile_hint ? tile_hint : pick_tile(M, N);
 #define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st
-    switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split pipeline
+    switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split over half tiles;
+                                                          // 51..55: role-split over the full-tile 2-stage buffers
         case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
         case 2: return launch_tile<128, 128, 64, 64, 0>(VLY_TILE_ARGS);
         case 3: return launch_tile<256, 128, 64, 64, 0>(VLY_TILE_ARGS);
@@ -386,6 +452,10 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         case 13: return launch_tile<256, 128, 64, 64, 1>(VLY_TILE_ARGS);
         case 14: return launch_tile<128, 256, 64, 64, 1>(VLY_TILE_ARGS);
         case 15: return launch_tile<192, 256, 96, 64, 1>(VLY_TILE_ARGS);
+        case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
+        case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
+        case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);
+        case 55: return launch_tile<192, 256, 96, 64, 4>(VLY_TILE_ARGS);
         case 31: return launch_tile<256, 256, 128, 64, 3>(VLY_TILE_ARGS);
         case 33: return launch_tile<256, 128, 64, 64, 3>(VLY_TILE_ARGS);
         case 34: return launch_tile<128, 256, 64, 64, 3>(VLY_TILE_ARGS);

@@ -148,7 +148,7 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     winner by median."""
     scratch = torch.empty_like(out)
     best, best_t = ("tile", 0), float("inf")
-    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 31, 33, 34, 35)] + [("sk", t) for t in (1, 3, 5)]
+    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 35, 51, 53, 54, 55)] + [("sk", t) for t in (1, 3, 5)]
     for kind, t in cands:
         fn = gemm_mfma if kind == "tile" else gemm_streamk
         try:
