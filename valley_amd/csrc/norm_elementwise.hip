@@ -335,28 +335,43 @@ __global__ void __launch_bounds__(256) embed_splice_kernel(const int32_t* __rest
 __global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
                                                       const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                       int B, int S, int heads, int past, const int32_t* __restrict__ past_dev, int ctx_max) {
-    const int lane = threadIdx.x & 63;
-    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (b*S + s)*heads + h
+    // 8 lanes per (row, head): lane j rotates dims [8j, 8j+8) against [64+8j, 64+8j+8) with 16-byte accesses.
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long unit = t >> 3;                                      // (b*S + s)*heads + h
     if (unit >= (long)B * S * heads) return;
+    const int j = (int)(t & 7);
     const int h = (int)(unit % heads);
     const long rs = unit / heads;
     const int s = (int)(rs % S), b = (int)(rs / S);
     const int Hq = heads * 128;
     if (past_dev) past = min(*past_dev, ctx_max - S);       // device-side position (hipGraph replay); clamp = no OOB ever
     const int pos = past + s;
-    const float cs = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
-    uint16_t* q = qkv + (size_t)rs * 3 * Hq + h * 128;
+    const float4 c0 = *(const float4*)(cos_t + (size_t)pos * 64 + 8 * j), c1 = *(const float4*)(cos_t + (size_t)pos * 64 + 8 * j + 4);
+    const float4 s0 = *(const float4*)(sin_t + (size_t)pos * 64 + 8 * j), s1 = *(const float4*)(sin_t + (size_t)pos * 64 + 8 * j + 4);
+    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    uint16_t* q = qkv + (size_t)rs * 3 * Hq + h * 128 + 8 * j;
     uint16_t* k = q + Hq;
     const uint16_t* v = q + 2 * Hq;
-    const float q1 = bf16_to_f32(q[lane]), q2 = bf16_to_f32(q[lane + 64]);
-    q[lane] = f32_to_bf16(q1 * cs - q2 * sn);
-    q[lane + 64] = f32_to_bf16(q2 * cs + q1 * sn);
-    const float k1 = bf16_to_f32(k[lane]), k2 = bf16_to_f32(k[lane + 64]);
-    const size_t co = (((size_t)b * heads + h) * ctx_max + pos) * 128;
-    kc[co + lane] = f32_to_bf16(k1 * cs - k2 * sn);
-    kc[co + lane + 64] = f32_to_bf16(k2 * cs + k1 * sn);
-    vc[co + lane] = v[lane];
-    vc[co + lane + 64] = v[lane + 64];
+    const size_t co = (((size_t)b * heads + h) * ctx_max + pos) * 128 + 8 * j;
+    auto rot = [&](const u32x4 lo, const u32x4 hi, u32x4& olo, u32x4& ohi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a0 = __uint_as_float(lo[i] << 16), a1 = __uint_as_float(lo[i] & 0xffff0000u);
+            const float b0 = __uint_as_float(hi[i] << 16), b1 = __uint_as_float(hi[i] & 0xffff0000u);
+            olo[i] = pack_bf16x2(a0 * cs[2 * i] - b0 * sn[2 * i], a1 * cs[2 * i + 1] - b1 * sn[2 * i + 1]);
+            ohi[i] = pack_bf16x2(b0 * cs[2 * i] + a0 * sn[2 * i], b1 * cs[2 * i + 1] + a1 * sn[2 * i + 1]);
+        }
+    };
+    u32x4 olo, ohi;
+    rot(*(const u32x4*)q, *(const u32x4*)(q + 64), olo, ohi);
+    *(u32x4*)q = olo;
+    *(u32x4*)(q + 64) = ohi;
+    rot(*(const u32x4*)k, *(const u32x4*)(k + 64), olo, ohi);
+    *(u32x4*)(kc + co) = olo;
+    *(u32x4*)(kc + co + 64) = ohi;
+    *(u32x4*)(vc + co) = *(const u32x4*)v;
+    *(u32x4*)(vc + co + 64) = *(const u32x4*)(v + 64);
 }
 
 // fp32 -> bf16 cast (round to nearest even), 8 elements per thread.
@@ -495,7 +510,7 @@ extern "C" int vly_rope_kv(void* qkv, void* kcache, void* vcache, const float* c
         return -22;
     }
     const long units = (long)B * S * heads;
-    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)((units * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, B, S, heads, past_len, past_len_dev, ctx_max);
     return vly_check_launch("vly_rope_kv");
 }

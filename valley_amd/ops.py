@@ -78,7 +78,7 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     if rec is not None:
         e1.record()
         name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}>" if sk else \
-            f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {tile // 10}>"
+            f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4})[tile // 10]}>"
         rec.append((name, 2.0 * M * N * K, e0, e1))
     _lib.check(rc, fn_name)
     return out
