@@ -42,7 +42,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;      // glds passes per tile
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[(PIPE == 6 || PIPE == 7 ? 3 : 2) * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -259,6 +259,129 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (PIPE == 6) {
+        // ================= 3-stage loop: whole K tiles, two tiles in flight, counted vmcnt ===================
+        // Little's law check: one 64 KB tile in flight per CU sustains ~32 B/clk only if the loaded L2/HBM
+        // latency stays under ~2000 cycles.  Tiles whose stage is <= 53 KB can keep THREE stages in the
+        // 160 KB LDS, i.e. two K tiles (2x the bytes) in flight, with one raw barrier per K tile.
+        constexpr int NS = 3;
+        static_assert(NS * STAGE <= 160 * 1024, "LDS budget");
+        uint32_t offA[PA], offW[PW];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+        auto stage = [&](int kt, int buf) {
+            char* sA = smem + buf * STAGE;
+            char* sW = sA + A_BYTES;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+        };
+        const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
+        const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PA + PW) : "memory");   // tile kt landed, kt+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);                           // (kt+2) % 3
+            const char* cur = smem + buf * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int sw = kk ? sw1 : sw0;
+                bf16x8 af[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else if constexpr (PIPE == 7) {
+        // ================= role-split (as PIPE 4) over THREE full-tile stages (as PIPE 6) =====================
+        static_assert(NW == 8, "role-split pipeline needs two waves per SIMD");
+        static_assert(3 * STAGE <= 160 * 1024, "LDS budget");
+        uint32_t offA[PA], offW[PW];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int s = p * NT + tid, row = s >> 3, cp = s & 7;
+            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+        }
+        auto stage = [&](int kt, int buf) {
+            char* sA = smem + buf * STAGE;
+            char* sW = sA + A_BYTES;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+        };
+        auto wait_next = [&](int kt) {                              // my loads of tile kt+1 landed; kt+2 may fly
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PA + PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
+        const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+        const int grp = wave >> 2;
+
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        wait_next(-1);
+        __builtin_amdgcn_s_barrier();                               // tile 0 visible to everyone
+        if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 starts one phase late
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* cur = smem + buf * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // ---------------- R phase
+                if (kk == 0 && kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);
+                const int sw = kk ? sw1 : sw0;
+                bf16x8 af[MI], wf[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
+                if (kk == 1 && grp == 1) wait_next(kt);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- M phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (kk == 1 && grp == 0) wait_next(kt);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
     } else {
         // ================= 4-region half-tile pipeline: counted vmcnt, raw barrier ======================
         // The K loop advances in HALF tiles (32 k = one MFMA k-step = 64-byte LDS rows).  LDS holds four
@@ -452,6 +575,14 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         case 13: return launch_tile<256, 128, 64, 64, 1>(VLY_TILE_ARGS);
         case 14: return launch_tile<128, 256, 64, 64, 1>(VLY_TILE_ARGS);
         case 15: return launch_tile<192, 256, 96, 64, 1>(VLY_TILE_ARGS);
+        case 73: return launch_tile<256, 128, 64, 64, 6>(VLY_TILE_ARGS);
+        case 74: return launch_tile<128, 256, 64, 64, 6>(VLY_TILE_ARGS);
+        case 76: return launch_tile<192, 192, 96, 48, 6>(VLY_TILE_ARGS);
+        case 6: return launch_tile<192, 192, 96, 48, 0>(VLY_TILE_ARGS);
+        case 83: return launch_tile<256, 128, 64, 64, 7>(VLY_TILE_ARGS);
+        case 84: return launch_tile<128, 256, 64, 64, 7>(VLY_TILE_ARGS);
+        case 86: return launch_tile<192, 192, 96, 48, 7>(VLY_TILE_ARGS);
+        case 56: return launch_tile<192, 192, 96, 48, 4>(VLY_TILE_ARGS);
         case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);

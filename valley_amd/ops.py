@@ -21,7 +21,7 @@ POOL_MEAN, POOL_MAX, POOL_IMPORTANCE = 0, 1, 2
 # (kernel_label, algorithmic_flops, start_event, end_event) for every MFMA GEMM launch.
 _RECORDER = None
 TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64", 4: "128, 256, 64, 64",
-              5: "192, 256, 96, 64"}
+              5: "192, 256, 96, 64", 6: "192, 192, 96, 48"}
 
 
 def set_recorder(rec):
@@ -78,7 +78,7 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     if rec is not None:
         e1.record()
         name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}>" if sk else \
-            f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4})[tile // 10]}>"
+            f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[tile // 10]}>"
         rec.append((name, 2.0 * M * N * K, e0, e1))
     _lib.check(rc, fn_name)
     return out
@@ -148,7 +148,7 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     winner by median."""
     scratch = torch.empty_like(out)
     best, best_t = ("tile", 0), float("inf")
-    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 35, 51, 53, 54, 55)] + [("sk", t) for t in (1, 3, 5)]
+    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 35, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86)] + [("sk", t) for t in (1, 3, 5)]
     for kind, t in cands:
         fn = gemm_mfma if kind == "tile" else gemm_streamk
         try:
