@@ -267,9 +267,15 @@ def main():
         }
         if rec:
             agg = {}
-            for name, flop, a, b in rec:
+            shapes = {}
+            for name, flop, a, b, shp in rec:
+                dt = a.elapsed_time(b) * 1e-3
                 d = agg.setdefault(name, [0.0, 0.0, 0])
-                d[0] += a.elapsed_time(b) * 1e-3
+                d[0] += dt
+                d[1] += flop
+                d[2] += 1
+                d = shapes.setdefault("%dx%dx%d/e%d" % shp, [0.0, 0.0, 0, name])
+                d[0] += dt
                 d[1] += flop
                 d[2] += 1
             dom = max(agg.items(), key=lambda kv: kv[1][0])
@@ -292,7 +298,10 @@ def main():
                                   "share_of_step_time": round(tsum / args.steps / (ms_step * 1e-3), 3),
                                   "all_gemm_kernels": {k: {"TFLOPs": round(v[1] / v[0] / 1e12, 1), "launches": v[2],
                                                            "ms_per_step": round(v[0] / args.steps * 1e3, 3)}
-                                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+                                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                                  "gemm_shapes": {k: {"TFLOPs": round(v[1] / v[0] / 1e12, 1), "avg_us": round(v[0] / v[2] * 1e6, 1),
+                                                      "ms_per_step": round(v[0] / args.steps * 1e3, 3), "kernel": v[3]}
+                                                  for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(cfg, min(16, os.cpu_count() or 1))

@@ -19,7 +19,7 @@ SHAPES = [(1312, 4096, 4096), (1312, 12288, 4096), (8224, 1024, 1024), (8224, 30
           (64, 512, 64), (2688, 5120, 1024), (513, 4096, 640), (1028, 1024, 4096)]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 41, 42, 45])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 41, 42, 45, 51, 55, 73, 74, 76, 83, 84, 86, 102, 151, 176, 183, 184, 186])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_streamk_matches_tile_kernel(M, N, K, tile):
     from valley_amd import ops
@@ -34,7 +34,7 @@ def test_streamk_matches_tile_kernel(M, N, K, tile):
     assert ops.sk_error_flag(d) == 0
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 51, 55, 73, 76, 83, 84, 86, 155, 186])
 def test_streamk_epilogues(tile):
     from valley_amd import ops
     d = torch.device("cuda:0")

@@ -18,7 +18,7 @@ POOL_MEAN, POOL_MAX, POOL_IMPORTANCE = 0, 1, 2
 
 
 # Optional per-launch recorder (bench.py's live per-kernel timing): a list that receives
-# (kernel_label, algorithmic_flops, start_event, end_event) for every MFMA GEMM launch.
+# (kernel_label, algorithmic_flops, start_event, end_event, (M, N, K, epilogue)) for every MFMA GEMM launch.
 _RECORDER = None
 TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64", 4: "128, 256, 64, 64",
               5: "192, 256, 96, 64", 6: "192, 192, 96, 48"}
@@ -70,16 +70,17 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
         sk = fn_name.endswith("streamk")
         tile = extra[0] or (L.vly_gemm_streamk_tile_for(M, N, K) if sk else L.vly_gemm_tile_for(M, N))
         if sk:
-            tile %= 40 if tile > 40 else 100
+            sk_loop = {0: "2, 0", 4: "2, 0", 5: "2, 1", 7: "3, 0", 8: "3, 1"}[tile % 100 // 10]
+            tile %= 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
     if rec is not None:
         e1.record()
-        name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}>" if sk else \
+        name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}, {sk_loop}>" if sk else \
             f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[tile // 10]}>"
-        rec.append((name, 2.0 * M * N * K, e0, e1))
+        rec.append((name, 2.0 * M * N * K, e0, e1, (M, N, K, epilogue)))
     _lib.check(rc, fn_name)
     return out
 
@@ -126,6 +127,34 @@ def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
 # "streamk": always the persistent stream-K kernel.
 GEMM_MODE = os.environ.get("VALLEY_GEMM_MODE", "tuned")
 _TUNED = {}
+_TUNE_CACHE = os.environ.get("VALLEY_TUNE_CACHE", "")        # JSON file: tuned choices survive the process
+_DT = {"torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}
+
+
+def load_tune_cache(path: str) -> int:
+    """Read tuned (shape -> kernel) choices saved by save_tune_cache; returns how many were loaded."""
+    import json
+    if not path or not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        ents = json.load(f)
+    for e in ents:
+        M, N, K, epi, dt, hb, hr = e["key"]
+        _TUNED[(M, N, K, epi, _DT[dt], bool(hb), bool(hr))] = (e["kind"], e["tile"])
+    return len(ents)
+
+
+def save_tune_cache(path: str) -> None:
+    import json
+    ents = [{"key": [k[0], k[1], k[2], k[3], str(k[4]), k[5], k[6]], "kind": v[0], "tile": v[1]} for k, v in _TUNED.items()]
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump(ents, f, indent=0)
+    os.replace(tmp, path)
+
+
+if _TUNE_CACHE:
+    load_tune_cache(_TUNE_CACHE)
 
 
 _FLUSH = {}
@@ -147,8 +176,9 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     a scratch tensor so that an in-place residual update is not applied more than once); remember the
     winner by median."""
     scratch = torch.empty_like(out)
+    warm = torch.empty_like(a)
     best, best_t = ("tile", 0), float("inf")
-    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 35, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86)] + [("sk", t) for t in (1, 3, 5)]
+    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 35, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86)] + [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
     for kind, t in cands:
         fn = gemm_mfma if kind == "tile" else gemm_streamk
         try:
@@ -156,6 +186,7 @@ def _tune(key, a, w, bias, residual, epilogue, out):
             times = []
             for _ in range(5):
                 _flush_caches(a.device)
+                warm.copy_(a)                              # the producer kernel leaves A in L2 / Infinity Cache
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 fn(a, w, bias, residual, epilogue, out.dtype, scratch, t)
@@ -168,6 +199,8 @@ def _tune(key, a, w, bias, residual, epilogue, out):
         if dt < best_t:
             best, best_t = (kind, t), dt
     _TUNED[key] = best
+    if _TUNE_CACHE:
+        save_tune_cache(_TUNE_CACHE)
     return best
 
 
