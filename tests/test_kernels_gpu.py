@@ -320,3 +320,36 @@ def test_preprocess_frames_gpu_vs_oracle(shape):
     assert maxabs(got, ref) < 2e-6
     got16 = preprocess_frames_gpu(torch.from_numpy(frames).to(dev()))
     assert maxabs(got16, ref.to(torch.bfloat16)) <= 0.016
+
+
+def test_gemm_online_tuner_decides_and_stays_correct(monkeypatch, tmp_path):
+    """ops.gemm in "tuned" mode: every call while the shape is undecided runs a different candidate kernel
+    on the real operands; all of them are valid results, a decision is reached after TUNE_TRIALS timed
+    calls per candidate, it is written to the cache file and later calls use it."""
+    from valley_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", "tuned")
+    monkeypatch.setattr(ops, "_TUNE_CACHE", str(tmp_path / "tune.json"))
+    monkeypatch.setattr(ops, "_TUNED", {})
+    monkeypatch.setattr(ops, "_ONLINE", {})
+    M, N, K = 1312, 1024, 512
+    a = rnd((M, K), 11, dtype=torch.bfloat16).to(dev())
+    w = rnd((N, K), 12, 0.05, dtype=torch.bfloat16).to(dev())
+    bias = rnd((N,), 13, 0.5).to(dev())
+    ref = a.float() @ w.float().t() + bias
+    calls = 0
+    while calls < 400:
+        out = ops.gemm(a, w, bias, out_dtype=torch.float32)
+        calls += 1
+        assert maxabs(out, ref) < 2e-4 * math.sqrt(K) + 1e-3
+        torch.cuda.synchronize()
+        if ops.tuning_pending() == 0:
+            break
+    assert ops.tuning_pending() == 0, "no decision after %d calls" % calls
+    assert calls <= len(ops.CANDIDATES) * ops.TUNE_TRIALS + 3
+    key = (M, N, K, ops.EPI_NONE, torch.float32, True, False)
+    assert key in ops._TUNED
+    saved = dict(ops._TUNED)
+    ops._TUNED.clear()
+    assert ops.load_tune_cache(str(tmp_path / "tune.json")) == 1 and ops._TUNED == saved
+    assert maxabs(ops.gemm(a, w, bias, out_dtype=torch.float32), ref) < 2e-4 * math.sqrt(K) + 1e-3
+    assert ops.sk_error_flag(dev()) == 0

@@ -121,8 +121,14 @@ def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
 
-# "tuned"  (default): per (M,N,K,epilogue,out dtype) pick the fastest of {whole-tile, stream-K} x {256x256,
-#                      128x128, 256x128} by timing each once on first use (measure, don't guess);
+# "tuned"  (default): per (M,N,K,epilogue,out dtype) pick the fastest of {whole-tile, stream-K} x {tile shapes}
+#                      x {loop variants} ONLINE: while a shape is undecided every call runs the next candidate
+#                      on the real operands in its real place in the step (producer output warm in cache,
+#                      weights cold) between two events; after TUNE_TRIALS timed calls per candidate the
+#                      fastest by median is fixed.  Every candidate computes the same result up to fp32
+#                      summation order, so the calls made while tuning are ordinary, valid calls;
+# "tuned-offline":     same candidates, timed back to back on first use behind a cache flush (stalls the
+#                      first call; ranks short GEMMs less faithfully: the flush leaves the caches dirty);
 # "tiles":  whole-tile kernel with its static heuristic — bit-identical results across batch sizes;
 # "streamk": always the persistent stream-K kernel.
 GEMM_MODE = os.environ.get("VALLEY_GEMM_MODE", "tuned")
@@ -171,6 +177,63 @@ def _flush_caches(device):
     buf.zero_()
 
 
+CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 35, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86)] + \
+             [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
+TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
+_ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
+
+
+def tuning_pending() -> int:
+    """Number of GEMM shapes the online tuner has seen but not decided yet."""
+    return len(_ONLINE)
+
+
+def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out):
+    st = _ONLINE.get(key)
+    if st is None:
+        st = _ONLINE[key] = {"cands": list(CANDIDATES), "times": {c: [] for c in CANDIDATES}, "pending": []}
+    still = []
+    for c, e0, e1 in st["pending"]:                       # harvest finished trials without blocking
+        if e1.query():
+            if c in st["times"]:
+                st["times"][c].append(e0.elapsed_time(e1))
+        else:
+            still.append((c, e0, e1))
+    st["pending"] = still
+    counts = {c: len(st["times"][c]) for c in st["cands"]}
+    for c, _, _ in still:
+        if c in counts:
+            counts[c] += 1
+    while st["cands"]:
+        cand = min(st["cands"], key=lambda c: counts[c])
+        if counts[cand] >= TUNE_TRIALS:
+            if still:                                     # everything issued, last timings not in yet
+                break
+            best = min(st["cands"], key=lambda c: sorted(st["times"][c])[len(st["times"][c]) // 2])
+            _TUNED[key] = best
+            del _ONLINE[key]
+            if _TUNE_CACHE:
+                save_tune_cache(_TUNE_CACHE)
+            cand = best
+            break
+        fn = gemm_mfma if cand[0] == "tile" else gemm_streamk
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        try:
+            res = fn(a, w, bias, residual, epilogue, out_dtype, out, cand[1])
+        except _lib.ValleyHipError:                       # configuration not available for this shape
+            st["cands"].remove(cand)
+            del st["times"][cand]
+            continue
+        e1.record()
+        st["pending"].append((cand, e0, e1))
+        return res
+    else:
+        raise _lib.ValleyHipError("gemm: no kernel configuration accepts this problem")
+    fn = gemm_mfma if cand[0] == "tile" else gemm_streamk
+    return fn(a, w, bias, residual, epilogue, out_dtype, out, cand[1])
+
+
 def _tune(key, a, w, bias, residual, epilogue, out):
     """Time every candidate on the real operands, cold caches, one event pair per launch (outputs go to
     a scratch tensor so that an in-place residual update is not applied more than once); remember the
@@ -178,8 +241,7 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     scratch = torch.empty_like(out)
     warm = torch.empty_like(a)
     best, best_t = ("tile", 0), float("inf")
-    cands = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 35, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86)] + [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
-    for kind, t in cands:
+    for kind, t in CANDIDATES:
         fn = gemm_mfma if kind == "tile" else gemm_streamk
         try:
             fn(a, w, bias, residual, epilogue, out.dtype, scratch, t)
@@ -223,13 +285,15 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
     if choice is None:
         if torch.cuda.is_current_stream_capturing():
             choice = ("tile", 0)
-        else:
+        elif GEMM_MODE == "tuned-offline":
             rec = _RECORDER
             set_recorder(None)
             try:
                 choice = _tune(key, a, w, bias, residual, epilogue, out)
             finally:
                 set_recorder(rec)
+        else:
+            return _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out)
     kind, t = choice
     if kind == "tile":
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t)
