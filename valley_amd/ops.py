@@ -159,6 +159,11 @@ def save_tune_cache(path: str) -> None:
     os.replace(tmp, path)
 
 
+# Decisions shipped with the package for the reference's own configurations (tuned on MI355X by the online
+# tuner, tools/README in DESIGN.md §4); VALLEY_TUNE_TABLE=0 ignores it, unseen shapes are tuned online.
+_TUNE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950.json")
+if os.environ.get("VALLEY_TUNE_TABLE", "1") != "0":
+    load_tune_cache(_TUNE_TABLE)
 if _TUNE_CACHE:
     load_tune_cache(_TUNE_CACHE)
 
