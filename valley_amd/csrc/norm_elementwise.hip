@@ -88,16 +88,17 @@ __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const 
     }
 }
 
-// Small-M variant (decode: M = batch <= 8): one 256-thread workgroup per row so the row's loads are
-// spread over 4 waves instead of queued in one; block reduction through LDS.
-template <bool RMS>
-__global__ void __launch_bounds__(256) norm_row_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// Few-rows variant: one 256-thread workgroup per row so the row's loads are spread over 4 waves instead
+// of queued in one; block reduction through LDS.  Same ADD semantics as norm_kernel.
+template <bool RMS, bool ADD>
+__global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, const uint16_t* __restrict__ delta,
+                                                       const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, uint16_t* __restrict__ y16,
                                                        float* __restrict__ y32, int D, float eps) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
-    const float4* xr = (const float4*)(x + (size_t)row * D);
+    float4* xr = (float4*)(x + (size_t)row * D);
     const int nvec = D >> 2;
     float4 v[8];                                               // D <= 8192
     float s = 0.f;
@@ -105,9 +106,18 @@ __global__ void __launch_bounds__(256) norm_row_kernel(const float* __restrict__
     for (int i = 0; i < 8; ++i) {
         const int c = tid + 256 * i;
         v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (ADD) {
+            if (c < nvec) {
+                const u32x2 dk = *(const u32x2*)(delta + (size_t)row * D + 4 * c);
+                v[i].x += __uint_as_float(dk[0] << 16); v[i].y += __uint_as_float(dk[0] & 0xffff0000u);
+                v[i].z += __uint_as_float(dk[1] << 16); v[i].w += __uint_as_float(dk[1] & 0xffff0000u);
+                xr[c] = v[i];
+            }
+        }
         if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         else s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
+    if (gamma == nullptr) return;                              // ADD-only call
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -163,8 +173,13 @@ int launch_norm(const float* x, const void* delta, const float* gamma, const flo
         vly_set_error("%s: unsupported shape/alignment M=%d D=%d", name, M, D);
         return -22;
     }
-    if (M <= 64 && !delta) {
-        hipLaunchKernelGGL((norm_row_kernel<RMS>), dim3(M), dim3(256), 0, st, x, gamma, beta, (uint16_t*)y16, y32, D, eps);
+    // one workgroup per row when one wave per row would leave the chip short of waves (decode, and the
+    // Llama residual stream at M = B*S ~ 1-3 k rows of 16-20 KB: 5 waves per CU could not cover HBM latency)
+    if (M <= 64 || (D >= 2048 && M <= 4096)) {
+        if (delta) hipLaunchKernelGGL((norm_row_kernel<RMS, true>), dim3(M), dim3(256), 0, st, (float*)x, (const uint16_t*)delta,
+                                      gamma, beta, (uint16_t*)y16, y32, D, eps);
+        else hipLaunchKernelGGL((norm_row_kernel<RMS, false>), dim3(M), dim3(256), 0, st, (float*)x, (const uint16_t*)nullptr,
+                                gamma, beta, (uint16_t*)y16, y32, D, eps);
         return vly_check_launch(name);
     }
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
