@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--prefill", default="sharded", choices=["sharded", "replicated"])
     ap.add_argument("--decode", type=int, default=0, metavar="N",
                     help="instead of the prefill step: prefill once, then time N greedy hipGraph decode steps (configs[4])")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VALLEY_BENCH_STREAMS", "1")),
+                    help="run the batch as this many independent sub-batches on separate HIP streams (tail filling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (rocprof runs)")
     args = ap.parse_args()
@@ -202,11 +204,32 @@ def main():
                          "note": "algorithmic bytes = all matmul weights once (bf16) + K and V of the mean context"}}), flush=True)
         return
 
+    NS = max(1, min(args.streams, B, Bp))
+    side = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else []
+    cuts_b = [B * i // NS for i in range(NS + 1)]                      # clips per stream (ViT)
+    cuts_p = [Bp * i // NS for i in range(NS + 1)]                     # sequences per stream (prefill)
+    sub_caches = [mm.llama.new_cache(cuts_p[i + 1] - cuts_p[i], S) for i in range(NS)] if NS > 1 else []
+
+    def fork_join(fn):
+        """Run fn(i) for every sub-batch on its own stream; the main stream waits for all of them."""
+        main = torch.cuda.current_stream()
+        outs = []
+        for i, st in enumerate(side):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(fn(i))
+        for st in side:
+            main.wait_stream(st)
+        return outs
+
     def step(record):
         e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
         if record:
             e0.record()
-        pooled, _ = mm.encode_clips(frames)                              # ViT encode + temporal pool (local clips)
+        if NS > 1:                                                       # independent sub-batches side by side
+            pooled = torch.cat(fork_join(lambda i: mm.encode_clips(frames[cuts_b[i]:cuts_b[i + 1]])[0]), 0)
+        else:
+            pooled, _ = mm.encode_clips(frames)                          # ViT encode + temporal pool (local clips)
         if world > 1:
             pooled = parallel.all_gather_rows(pooled, [pooled.shape[0]] * world)
         if record:
@@ -215,9 +238,21 @@ def main():
         if args.prefill == "sharded" and world > 1:
             n = B * (256 + T)
             visual = visual[rank * n:(rank + 1) * n]
-        cache.seq_len = 0
-        out = model(input_ids=input_ids, past_key_values=cache, use_cache=True, visual_tokens=visual,
-                    frames_per_clip=Ts_all[:Bp])
+        if NS > 1:
+            nv = 256 + T
+
+            def pre(i):
+                c = sub_caches[i]
+                c.seq_len = 0
+                return model(input_ids=input_ids[cuts_p[i]:cuts_p[i + 1]], past_key_values=c, use_cache=True,
+                             visual_tokens=visual[cuts_p[i] * nv:cuts_p[i + 1] * nv],
+                             frames_per_clip=Ts_all[cuts_p[i]:cuts_p[i + 1]])
+            outs = fork_join(pre)
+            out = outs[-1]
+        else:
+            cache.seq_len = 0
+            out = model(input_ids=input_ids, past_key_values=cache, use_cache=True, visual_tokens=visual,
+                        frames_per_clip=Ts_all[:Bp])
         if record:
             e2.record()
             stage_events.append((e0, e1, e2))
@@ -275,7 +310,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": cfg["label"] + f", S={S}, end-to-end hot path (encode+pool+project+splice+prefill+lm_head)",
                        "name": args.config, "clips_per_gpu": B, "frames_per_clip": T, "prefill_batch_per_gpu": Bp,
-                       "seq_len": S, "tune_passes": tune_passes, "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},
+                       "seq_len": S, "tune_passes": tune_passes, "streams": NS, "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},
             "stages": {"vit_frames_per_s_per_gpu": round(vit_fps, 1), "vit_ms": round(vit_ms, 3),
                        "vit_TFLOPs": round(vit_tf, 1), "vit_frac_of_bf16_peak": round(vit_tf / PEAK_BF16_TFLOPS, 4),
                        "prefill_tokens_per_s_per_gpu": round(pre_tps, 1), "prefill_ms": round(pre_ms, 3),

@@ -353,3 +353,43 @@ def test_generate_video_stream_matches_reference_loop():
                   attention_mask=torch.ones(1, past[0][0].shape[-2] + 1).cuda())
         logits, past = o.logits, o.past_key_values
     assert chunks[-1]["text"] == params["prompt"] + tok.decode(pred)
+
+
+@pytest.mark.parametrize("own_streams", [False, True])
+def test_concurrent_requests_from_threads(own_streams):
+    """The reference's worker calls one model object from a thread pool (serve/model_worker.py:467-474).
+    Requests that share a HIP stream are serialised by valley_amd.runtime.stream_lock (they would otherwise
+    overwrite each other's activation workspaces); requests on their own streams run concurrently with
+    per-stream workspaces.  Either way every thread must get exactly the single-threaded result."""
+    import threading
+    model = build_golden_model()
+    T = G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224).cuda()
+    ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    variants = [images, images.flip(0), images * 0.5, images.flip(1)]
+    want = [model(input_ids=ids_t, images=v, attention_mask=mask_t).logits.clone() for v in variants]
+    torch.cuda.synchronize()
+    got, errs = [None] * len(variants), []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream() if own_streams else torch.cuda.current_stream()
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    out = model(input_ids=ids_t, images=variants[i], attention_mask=mask_t).logits
+                got[i] = out.clone()
+                st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(variants))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(len(variants)):
+        assert torch.equal(got[i], want[i]), (i, float((got[i] - want[i]).abs().max()))

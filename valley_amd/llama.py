@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, runtime
 
 
 def _dev(t, device, dtype):
@@ -122,15 +122,16 @@ class HipLlama:
         return HipKVCache(self.L, batch, self.heads, ctx_max or self.max_positions, self.device)
 
     def _workspace(self, M: int):
-        ws = self._ws.get(M)
+        key = (M, runtime.stream_key())                    # concurrent streams never share activations
+        ws = self._ws.get(key)
         if ws is None:
             d, bf = self.device, torch.bfloat16
             ws = dict(x=torch.empty((M, self.H), dtype=bf, device=d), qkv=torch.empty((M, 3 * self.H), dtype=bf, device=d),
                       att=torch.empty((M, self.H), dtype=bf, device=d), mlp=torch.empty((M, self.I), dtype=bf, device=d),
                       delta=torch.empty((M, self.H), dtype=bf, device=d))
-            if len(self._ws) > 6:
+            if len(self._ws) > 8:
                 self._ws.clear()
-            self._ws[M] = ws
+            self._ws[key] = ws
         return ws
 
     def forward(self, h: torch.Tensor, B: int, S: int, cache: HipKVCache, n_layers: Optional[int] = None) -> torch.Tensor:
@@ -143,6 +144,10 @@ class HipLlama:
             raise ValueError(f"KV cache overflow: {past}+{S} > {cache.ctx_max}")
         if cache.batch != B:
             raise ValueError("cache batch mismatch")
+        with runtime.stream_lock():                        # launch sequences on one stream must not interleave
+            return self._forward_locked(h, B, S, cache, past, n_layers)
+
+    def _forward_locked(self, h, B, S, cache, past, n_layers):
         M = B * S
         ws = self._workspace(M)
         kv = cache.key_valid                                # uint8 [B, ctx_max] or None (row stride = ctx_max)

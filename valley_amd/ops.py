@@ -94,19 +94,20 @@ _SK_WS = {}          # device index -> [workspace tensor, epoch]
 
 
 def _sk_workspace(device):
-    ent = _SK_WS.get(device.index)
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))   # launches on different streams overlap
+    ent = _SK_WS.get(key)
     if ent is None:
         nbytes = _lib.load().vly_gemm_streamk_workspace_bytes()
         ent = [torch.zeros((nbytes + 15) // 16 * 4, dtype=torch.int32, device=device), 0]
-        _SK_WS[device.index] = ent
+        _SK_WS[key] = ent
     ent[1] = ent[1] % 0xFFFFFFF0 + 1
     return ent[0], ent[1]
 
 
 def sk_error_flag(device) -> int:
     """Non-zero if a stream-K owner ever gave up waiting for a contributor (should never happen)."""
-    ent = _SK_WS.get(torch.device(device).index)
-    return 0 if ent is None else int(ent[0][4000].item())
+    idx = torch.device(device).index or 0
+    return max([int(ent[0][4000].item()) for key, ent in list(_SK_WS.items()) if key[0] == idx] or [0])
 
 
 def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
@@ -302,6 +303,8 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
     kind, t = choice
     if kind == "tile":
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t)
+    if torch.cuda.is_current_stream_capturing():           # the stream-K workspace is per stream: none inside a capture
+        return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, 0)
     return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, t)
 
 

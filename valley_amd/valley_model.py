@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence, Union
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, runtime
 from .llama import HipKVCache, HipLlama
 from .splice import build_row_map
 from .vision_tower import HipCLIPVisionTower, VisionConfig
@@ -157,6 +157,10 @@ class ValleyLlamaModel:
         """images: [B,T,3,224,224] tensor or list of [T_i,3,224,224] (valley_model.py:168-184).
         Returns (pooled bf16 [sum(256+T_i), W], frames per clip).  W = 1024 for mean pooling (projection
         comes after), W = H for max pooling (projection first)."""
+        with runtime.stream_lock():
+            return self._encode_clips_locked(images)
+
+    def _encode_clips_locked(self, images):
         clips = list(images) if isinstance(images, (list, tuple)) else [images[b] for b in range(len(images))]
         Ts = [int(c.shape[0]) for c in clips]
         frames = torch.cat([c.to(self.device) for c in clips], 0) if len(clips) > 1 else clips[0].to(self.device)
@@ -355,12 +359,15 @@ class ValleyLlamaForCausalLM:
         """valley_model.py:272-330.  Returns CausalLMOutputWithPast(logits fp32 [B,S,V], past_key_values)."""
         if labels is not None:
             raise NotImplementedError("training loss (valley_model.py:307-318) is outside the inference hot path")
-        out = self.model.forward(input_ids=input_ids, attention_mask=attention_mask, past_key_values=past_key_values,
-                                 inputs_embeds=inputs_embeds, use_cache=use_cache, output_attentions=output_attentions,
-                                 output_hidden_states=output_hidden_states, images=images, **kw)
-        hidden = out.last_hidden_state                                    # bf16 [B,S,H]
-        B, S, H = hidden.shape
-        logits = self.model.llama.logits(hidden.view(B * S, H)).view(B, S, -1)      # lm_head on ALL positions (:304-305)
+        # one launch sequence per stream at a time (the reference's worker calls the model from a thread pool,
+        # serve/model_worker.py:467-474); requests on different HIP streams run concurrently
+        with runtime.stream_lock():
+            out = self.model.forward(input_ids=input_ids, attention_mask=attention_mask, past_key_values=past_key_values,
+                                     inputs_embeds=inputs_embeds, use_cache=use_cache, output_attentions=output_attentions,
+                                     output_hidden_states=output_hidden_states, images=images, **kw)
+            hidden = out.last_hidden_state                                    # bf16 [B,S,H] (a workspace view)
+            B, S, H = hidden.shape
+            logits = self.model.llama.logits(hidden.view(B * S, H)).view(B, S, -1)  # lm_head on ALL positions (:304-305)
         if return_dict is False:
             return (logits, out.past_key_values)
         return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=out.past_key_values,

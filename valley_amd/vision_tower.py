@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, runtime
 
 
 class VisionConfig(SimpleNamespace):
@@ -121,7 +121,8 @@ class HipCLIPVisionTower:
 
     # ---- compute ---------------------------------------------------------------------------------
     def _workspace(self, F: int):
-        ws = self._ws.get(F)
+        key = (F, runtime.stream_key())                    # concurrent streams never share activations
+        ws = self._ws.get(key)
         if ws is None:
             d, M, I = self.device, F * 257, self.config.intermediate_size
             ws = dict(cols=torch.empty((F * 256, 640), dtype=torch.bfloat16, device=d),
@@ -131,9 +132,9 @@ class HipCLIPVisionTower:
                       att=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
                       delta=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
                       mlp=torch.empty((M, I), dtype=torch.bfloat16, device=d))
-            if len(self._ws) > 4:
+            if len(self._ws) > 6:
                 self._ws.clear()
-            self._ws[F] = ws
+            self._ws[key] = ws
         return ws
 
     def n_layers_for(self, select_layer: int) -> int:
@@ -183,6 +184,10 @@ class HipCLIPVisionTower:
         nl = self.n_layers_for(select_layer)
         if nl > len(self.layers):
             raise RuntimeError(f"need {nl} encoder layers, tower holds {len(self.layers)}")
+        with runtime.stream_lock():                        # launch sequences on one stream must not interleave
+            return self._encode_locked(frames, nl, chunk, keep_all)
+
+    def _encode_locked(self, frames: torch.Tensor, nl: int, chunk: int, keep_all: bool):
         Ftot = frames.shape[0]
         out = torch.empty((Ftot * 257, 1024), dtype=torch.float32, device=self.device)
         all_states = [] if keep_all else None
