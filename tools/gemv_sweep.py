@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""GEMV (decode projection) rates on cold weights: rotates over enough weight copies to exceed the 256 MB
+Infinity Cache.  gemv_sweep.py "N,K,epi,f32res;..."  -> one JSON line per shape (TB/s of weight bytes)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from valley_amd import ops  # noqa: E402
+
+d = torch.device("cuda:0")
+for spec in sys.argv[1].split(";"):
+    N, K, epi, f32res = (int(x) for x in spec.split(","))
+    ncopy = max(2, int(600e6 // (N * K * 2)) + 1)
+    ws = [(torch.randn((N, K), device=d) * 0.02).to(torch.bfloat16) for _ in range(ncopy)]
+    a = torch.randn((1, K), device=d).to(torch.bfloat16)
+    No = N // 2 if epi == 2 else N
+    res = torch.zeros((1, N), device=d) if f32res else None
+    out = res if f32res else torch.empty((1, No), device=d, dtype=torch.bfloat16)
+    for w in ws:
+        ops.gemv(a, w, residual=res, epilogue=epi, out=out, out_dtype=out.dtype)
+    torch.cuda.synchronize()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for w in ws:
+            ops.gemv(a, w, residual=res, epilogue=epi, out=out, out_dtype=out.dtype)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * ncopy)
+    print(json.dumps({"N": N, "K": K, "epi": epi, "f32res": f32res, "us": round(us, 2),
+                      "TBps": round(N * K * 2 / us / 1e6, 2), "copies": ncopy}), flush=True)

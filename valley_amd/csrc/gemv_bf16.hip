@@ -18,12 +18,16 @@ VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {
     return s;
 }
 
-template <int MR, int EPI, int OUT>
+// KS = 1: every wave owns two weight rows.  KS = 4 (few rows: N/2 < 4096 waves could not keep enough loads in
+// flight to reach the HBM rate — o_proj / down_proj at 4.0-4.5 TB/s): the workgroup owns two rows and its four
+// waves split K, partial sums meet in LDS.
+template <int MR, int EPI, int OUT, int KS>
 __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                    const float* __restrict__ bias, const float* __restrict__ R,
                                                    void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
-    const int lane = threadIdx.x & 63;
-    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    __shared__ float red[KS == 1 ? 1 : 4 * 2 * MR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (KS == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * 2;
     if (n0 >= N) return;
     const uint16_t* w0 = W + (size_t)n0 * ldw;
     const uint16_t* w1 = W + (size_t)min(n0 + 1, N - 1) * ldw;
@@ -32,7 +36,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
     for (int m = 0; m < MR; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
     const int nch = K >> 3;
 #pragma unroll 4
-    for (int c = lane; c < nch; c += 64) {
+    for (int c = (KS == 1 ? lane : wave * 64 + lane); c < nch; c += 64 * KS) {
         const u32x4 x0 = __builtin_nontemporal_load((const u32x4*)(w0 + 8 * c));
         const u32x4 x1 = __builtin_nontemporal_load((const u32x4*)(w1 + 8 * c));
 #pragma unroll
@@ -44,6 +48,19 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
     }
 #pragma unroll
     for (int m = 0; m < MR; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
+    if constexpr (KS > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m) { red[(wave * MR + m) * 2] = acc0[m]; red[(wave * MR + m) * 2 + 1] = acc1[m]; }
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {                       // fixed order: wave 0 + 1 + 2 + 3
+            acc0[m] = red[m * 2] + red[(MR + m) * 2] + red[(2 * MR + m) * 2] + red[(3 * MR + m) * 2];
+            acc1[m] = red[m * 2 + 1] + red[(MR + m) * 2 + 1] + red[(2 * MR + m) * 2 + 1] + red[(3 * MR + m) * 2 + 1];
+        }
+    }
     if (lane != 0) return;
     const bool has1 = n0 + 1 < N;
     const float b0 = bias ? bias[n0] : 0.f, b1 = (bias && has1) ? bias[n0 + 1] : 0.f;
@@ -80,10 +97,15 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
 template <int MR>
 int launch_mr(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
               int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
-    dim3 grid((N + 7) / 8), block(256);
-#define VLY_GEMV(E, O)                                                                                     \
-    hipLaunchKernelGGL((gemv_kernel<MR, E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, \
-                       bias, R, C, M, N, K, lda, ldw, ldc, ldr)
+    const bool split = (N + 1) / 2 < 4096 && K >= 2048;     // few rows, long rows: 4 waves per row pair
+    dim3 grid(split ? (N + 1) / 2 : (N + 7) / 8), block(256);
+#define VLY_GEMV(E, O)                                                                                            \
+    do {                                                                                                          \
+        if (split) hipLaunchKernelGGL((gemv_kernel<MR, E, O, 4>), grid, block, 0, st, (const uint16_t*)A,         \
+                                      (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr);               \
+        else hipLaunchKernelGGL((gemv_kernel<MR, E, O, 1>), grid, block, 0, st, (const uint16_t*)A,               \
+                                (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr);                     \
+    } while (0)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMV(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMV(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMV(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);

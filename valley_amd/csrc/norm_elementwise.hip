@@ -400,16 +400,37 @@ __global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ x, 
     ((u32x4*)y)[i] = pk;
 }
 
-// argmax over rows of fp32 [M,N]; first maximal index (torch.argmax tie rule on CPU).
-__global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N, int ld) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+// argmax over rows of fp32 [M,N]; first maximal index (torch.argmax tie rule on CPU).  One 1024-thread
+// workgroup per row, 16-byte loads issued four at a time (a 256-thread scalar loop spent 39 us per
+// 32 k-wide row on dependent load latency: 0.7 % of a 13B decode step).
+__global__ void __launch_bounds__(1024) argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N, int ld) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
     const float* r = x + (size_t)blockIdx.x * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const float v = r[i];
+    auto take = [&](float v, int i) {
         if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    };
+    const int tid = threadIdx.x;
+    if ((((uintptr_t)r) & 15) == 0) {
+        const int nv = N >> 2;
+        for (int c0 = 0; c0 < nv; c0 += 4096) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 1024 + tid;
+                v[u] = c < nv ? ((const float4*)r)[c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (c0 + u * 1024 + tid) * 4;
+                take(v[u].x, i); take(v[u].y, i + 1); take(v[u].z, i + 2); take(v[u].w, i + 3);
+            }
+        }
+        for (int i = (nv << 2) + tid; i < N; i += 1024) take(r[i], i);
+    } else {
+        for (int i = tid; i < N; i += 1024) take(r[i], i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -417,10 +438,10 @@ __global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ x
         const int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
         idx[blockIdx.x] = bi;
     }
@@ -532,7 +553,7 @@ extern "C" int vly_rope_kv(void* qkv, void* kcache, void* vcache, const float* c
 
 extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, int ld, void* stream) {
     if (M <= 0 || N <= 0 || ld < N) { vly_set_error("vly_argmax: bad args"); return -22; }
-    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, idx, N, ld);
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, x, idx, N, ld);
     return vly_check_launch("vly_argmax");
 }
 
