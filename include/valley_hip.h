@@ -178,6 +178,15 @@ int vly_llama_attention(const void *qkv_bf16, const void *kcache_bf16, const voi
                         const uint8_t *key_valid, int key_valid_stride, void *out_bf16, int B, int S,
                         int heads, int past_len, const int32_t *past_len_dev, int ctx_max, void *stream);
 
+/* One-token decode step of a layer's attention, fused:  vly_rope_kv (S = 1) + vly_llama_attention (S = 1) in one
+ *   launch.  qkv bf16 [B, 3*heads*128] holds the new token's UNROTATED q|k|v; the rotated k and v are appended
+ *   to the caches at position past_len, the new query attends over positions 0..past_len.  Same arithmetic
+ *   as the two separate calls (serve/model_worker.py:380-387 -> hf:llama/modeling_llama.py:127-157,191-213,
+ *   261-262).  past_len_dev as in vly_rope_kv.  qkv is not modified. */
+int vly_decode_attention(const void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
+                         const float *sin_table, const uint8_t *key_valid, int key_valid_stride, void *out_bf16,
+                         int B, int heads, int past_len, const int32_t *past_len_dev, int ctx_max, void *stream);
+
 /* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
  *   serve/model_worker.py:380-387 (one-token forward). */

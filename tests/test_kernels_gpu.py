@@ -254,6 +254,42 @@ def test_rope_kv_and_llama_attention(B, S, past, heads, pad):
     assert relerr(got[rows], ref[rows]) < 6e-3
 
 
+@pytest.mark.parametrize("B,past,heads,pad,ctx_max", [(1, 0, 2, 0, 256), (2, 130, 2, 5, 512), (1, 511, 3, 0, 2048),
+                                                       (3, 700, 2, 600, 2048), (1, 1300, 1, 0, 2048)])
+def test_decode_attention_fused_equals_rope_then_attention(B, past, heads, pad, ctx_max):
+    """vly_decode_attention (RoPE + KV append + attention, one launch) vs vly_rope_kv + vly_llama_attention:
+    the appended cache rows are bit-identical, the attention output agrees to bf16 rounding (the fused kernel
+    uses a chunked online softmax: several chunks at past >= 512, incl. a fully masked first chunk)."""
+    from valley_amd import ops
+    d = dev()
+    Hq = heads * 128
+    cos, sin = _rope_tables(ctx_max)
+    cos, sin = cos.to(d), sin.to(d)
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    if past:
+        kc[:, :, :past] = rnd((B, heads, past, 128), 30, dtype=torch.bfloat16)
+        vc[:, :, :past] = rnd((B, heads, past, 128), 31, dtype=torch.bfloat16)
+    qkv = rnd((B, 3 * Hq), 32, dtype=torch.bfloat16).to(d)
+    valid = None
+    if pad:
+        valid = torch.ones((B, past + 1), dtype=torch.uint8)
+        valid[0, :pad] = 0
+        valid = valid.to(d)
+    k1, v1, q1 = kc.to(d), vc.to(d), qkv.clone()
+    ops.rope_kv(q1, k1, v1, cos, sin, B, 1, heads, past)
+    want = ops.llama_attention(q1, k1, v1, valid, B, 1, heads, past)
+    k2, v2 = kc.to(d), vc.to(d)
+    got = ops.decode_attention(qkv, k2, v2, cos, sin, valid, B, heads, past)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert maxabs(got, want) <= 2e-2 and relerr(got, want) < 4e-3, (maxabs(got, want), relerr(got, want))
+    # device-side position (hipGraph replay path)
+    k3, v3 = kc.to(d), vc.to(d)
+    pos = torch.tensor([past], dtype=torch.int32, device=d)
+    got3 = ops.decode_attention(qkv, k3, v3, cos, sin, valid, B, heads, 0, past_dev=pos)
+    assert torch.equal(got3, got) and torch.equal(k3, k2)
+
+
 def test_argmax():
     from valley_amd import ops
     x = rnd((5, 32006), 40)

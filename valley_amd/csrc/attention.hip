@@ -431,6 +431,144 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-token decode step of a layer's attention, fused: RoPE on the new q and k, KV-cache append of the
+// rotated k and of v, and the attention of the new query over positions 0..pos.  One 512-thread workgroup
+// per (head, batch).  Keys are processed in chunks of 512 with an online softmax; per chunk every thread
+// issues ALL its loads up front (16 x 16 B of V for its (key group, d chunk), then the 256-byte K row of
+// its key) so that a chunk costs one memory latency instead of one per 64 keys (the unfused kernel's V
+// loop: 13 us at kv_len ~ 400, almost all of it exposed latency), and the separate rope/append kernel
+// (4.7 us + a kernel boundary per layer) disappears.  Arithmetic identical to vly_rope_kv followed by
+// vly_llama_attention (same bf16 rounding of the rotated q/k, same dot-product order).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ kc,
+                                                           uint16_t* __restrict__ vc, const float* __restrict__ cos_t,
+                                                           const float* __restrict__ sin_t, const uint8_t* __restrict__ key_valid,
+                                                           uint16_t* __restrict__ out, int heads, int past,
+                                                           const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
+    __shared__ float sc[512];
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ __attribute__((aligned(16))) float knew[128];
+    __shared__ __attribute__((aligned(16))) float vnew[128];
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float acc_s[32][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int Hq = heads * 128;
+    if (past_dev) past = min(*past_dev, ctx_max - 1);
+    const int pos = past, kv_len = past + 1;
+    const uint16_t* qp = qkv + (size_t)b * 3 * Hq + h * 128;
+    uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
+    uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
+
+    // ---- RoPE on q, k (pair d, d+64) + append; v append -------------------------------------------------
+    if (tid < 64) {
+        const float cs = cos_t[(size_t)pos * 64 + tid], sn = sin_t[(size_t)pos * 64 + tid];
+        const float q0 = bf16_to_f32(qp[tid]), q1 = bf16_to_f32(qp[tid + 64]);
+        const float k0 = bf16_to_f32(qp[Hq + tid]), k1 = bf16_to_f32(qp[Hq + tid + 64]);
+        const float scale = 0.08838834764831845f * LOG2E;
+        qs[tid] = bf16_to_f32(f32_to_bf16(q0 * cs - q1 * sn)) * scale;
+        qs[tid + 64] = bf16_to_f32(f32_to_bf16(q1 * cs + q0 * sn)) * scale;
+        const uint16_t r0 = f32_to_bf16(k0 * cs - k1 * sn), r1 = f32_to_bf16(k1 * cs + k0 * sn);
+        knew[tid] = bf16_to_f32(r0);
+        knew[tid + 64] = bf16_to_f32(r1);
+        kbase[(size_t)pos * 128 + tid] = r0;
+        kbase[(size_t)pos * 128 + tid + 64] = r1;
+    } else if (tid < 192) {
+        const int d = tid - 64;
+        const uint16_t v = qp[2 * Hq + d];
+        vnew[d] = bf16_to_f32(v);
+        vbase[(size_t)pos * 128 + d] = v;
+    }
+    __syncthreads();
+
+    const int kg = tid >> 4, dc = tid & 15;                      // V role: key group (32), d chunk (8 dims)
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    for (int c0 = 0; c0 < kv_len; c0 += 512) {
+        // ---- issue this chunk's V loads (keys c0 + kg + 32 u), then the K row of key c0 + tid -------------
+        u32x4 vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = c0 + kg + 32 * u;
+            vv[u] = (j < pos) ? *(const u32x4*)(vbase + (size_t)j * 128 + 8 * dc) : u32x4{0u, 0u, 0u, 0u};
+        }
+        const int jk = c0 + tid;
+        float s = NEG_BIG;
+        if (jk < kv_len && (!kvld || kvld[jk])) {
+            float a = 0.f;
+            if (jk < pos) {
+                const u32x4* kr = (const u32x4*)(kbase + (size_t)jk * 128);
+                u32x4 kk[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) kk[c] = kr[c];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const f32x4 q0 = *(const f32x4*)(qs + 8 * c), q1 = *(const f32x4*)(qs + 8 * c + 4);
+                    a = fmaf(__uint_as_float(kk[c][0] << 16), q0[0], a); a = fmaf(__uint_as_float(kk[c][0] & 0xffff0000u), q0[1], a);
+                    a = fmaf(__uint_as_float(kk[c][1] << 16), q0[2], a); a = fmaf(__uint_as_float(kk[c][1] & 0xffff0000u), q0[3], a);
+                    a = fmaf(__uint_as_float(kk[c][2] << 16), q1[0], a); a = fmaf(__uint_as_float(kk[c][2] & 0xffff0000u), q1[1], a);
+                    a = fmaf(__uint_as_float(kk[c][3] << 16), q1[2], a); a = fmaf(__uint_as_float(kk[c][3] & 0xffff0000u), q1[3], a);
+                }
+            } else {                                             // the new token's key: still in LDS
+#pragma unroll 8
+                for (int d = 0; d < 128; ++d) a = fmaf(knew[d], qs[d], a);
+            }
+            s = a;
+        }
+        // ---- online softmax over the chunk --------------------------------------------------------------
+        float mc = wave_max(s);
+        if (lane == 0) red[wave] = mc;
+        __syncthreads();
+        mc = red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mc = fmaxf(mc, red[w]);
+        const float m_new = fmaxf(m_run, mc);
+        const float alpha = exp2f(m_run - m_new);
+        const float p = s > 0.5f * NEG_BIG ? exp2f(s - m_new) : 0.f;   // masked keys never count, even in an all-masked chunk
+        sc[tid] = p;
+        float lc = wave_sum(p);
+        if (lane == 0) red[8 + wave] = lc;
+        __syncthreads();                                         // sc[] and red[8..] visible
+        lc = red[8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) lc += red[8 + w];
+        l_run = l_run * alpha + lc;
+        m_run = m_new;
+        // ---- P.V for this chunk ---------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int jl = kg + 32 * u;                          // key index inside the chunk
+            const float pj = sc[jl];
+            if (c0 + jl == pos) {                                // the new token's value: from LDS
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(pj, vnew[8 * dc + i], o[i]);
+            } else {
+                o[0] = fmaf(pj, __uint_as_float(vv[u][0] << 16), o[0]); o[1] = fmaf(pj, __uint_as_float(vv[u][0] & 0xffff0000u), o[1]);
+                o[2] = fmaf(pj, __uint_as_float(vv[u][1] << 16), o[2]); o[3] = fmaf(pj, __uint_as_float(vv[u][1] & 0xffff0000u), o[3]);
+                o[4] = fmaf(pj, __uint_as_float(vv[u][2] << 16), o[4]); o[5] = fmaf(pj, __uint_as_float(vv[u][2] & 0xffff0000u), o[5]);
+                o[6] = fmaf(pj, __uint_as_float(vv[u][3] << 16), o[6]); o[7] = fmaf(pj, __uint_as_float(vv[u][3] & 0xffff0000u), o[7]);
+            }
+        }
+        __syncthreads();                                         // sc[] / red[] are rewritten by the next chunk
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc_s[kg][8 * dc + i] = o[i];
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) t += acc_s[k2][tid];
+        out[(size_t)b * Hq + h * 128 + tid] = f32_to_bf16(t / l_run);
+    }
+}
+
 }  // namespace
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
@@ -461,4 +599,22 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
                        (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
                        S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
     return vly_check_launch("vly_llama_attention");
+}
+
+extern "C" int vly_decode_attention(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
+                                    const uint8_t* key_valid, int key_valid_stride, void* out, int B, int heads, int past_len,
+                                    const int32_t* past_len_dev, int ctx_max, void* stream) {
+    if (B <= 0 || heads <= 0 || past_len < 0 || past_len + 1 > ctx_max || B > 65535 || heads > 65535 ||
+        ((uintptr_t)qkv & 15) || ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) || ((uintptr_t)out & 7) || !cos_table || !sin_table) {
+        vly_set_error("vly_decode_attention: bad args B=%d heads=%d past=%d ctx_max=%d", B, heads, past_len, ctx_max);
+        return -22;
+    }
+    if (key_valid && key_valid_stride < past_len + 1) {
+        vly_set_error("vly_decode_attention: key_valid_stride %d < kv_len %d", key_valid_stride, past_len + 1);
+        return -22;
+    }
+    hipLaunchKernelGGL(decode_fused_kernel, dim3(heads, B), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, (uint16_t*)out, heads, past_len,
+                       past_len_dev, key_valid_stride, ctx_max);
+    return vly_check_launch("vly_decode_attention");
 }

@@ -46,8 +46,8 @@ class DecodeSession:
             L = ll.layers[li]
             ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
             ops.gemv(self.x, L["w_qkv"], out=self.qkv)
-            ops.rope_kv(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, B, 1, ll.heads, 0, past_dev=self.pos)
-            ops.llama_attention(self.qkv, c.k[li], c.v[li], c.key_valid, B, 1, ll.heads, 0, out=self.att, past_dev=self.pos)
+            ops.decode_attention(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, out=self.att,
+                                 past_dev=self.pos)              # RoPE + KV append + attention in one launch
             ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
             ops.rmsnorm(self.h, L["ln2"], ll.eps, out=self.x)
             ops.gemv(self.x, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)

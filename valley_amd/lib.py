@@ -41,6 +41,7 @@ _SIGS = {
     "vly_resize_v_norm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_decode_attention": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
 }

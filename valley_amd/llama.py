@@ -160,8 +160,12 @@ class HipLlama:
             else:
                 ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
             ops.gemm(ws["x"], L["w_qkv"], out=ws["qkv"])
-            ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
-            ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
+            if S == 1:                                      # one-token step: RoPE + append + attention fused
+                ops.decode_attention(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, kv, B, self.heads, past,
+                                     out=ws["att"])
+            else:
+                ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
+                ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
             if fused:
                 ops.gemm(ws["att"], L["w_o"], out=ws["delta"])
                 ops.add_norm(h, ws["delta"], L["ln2"], None, self.eps, out=ws["x"], rms=True)

@@ -446,6 +446,29 @@ def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
     return out
 
 
+def decode_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                     key_valid: Optional[torch.Tensor], B: int, heads: int, past_len: int, out=None,
+                     past_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One new token per sequence: RoPE + KV append + attention over 0..past_len in one launch
+    (= rope_kv followed by llama_attention with S = 1; qkv holds the unrotated q|k|v and is not modified)."""
+    _chk(qkv, torch.bfloat16, "qkv")
+    _chk(cos, torch.float32, "cos")
+    _chk(sin, torch.float32, "sin")
+    ctx_max = kcache.shape[2]
+    kv_stride = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        assert key_valid.shape[0] == B and key_valid.shape[1] >= past_len + 1
+        kv_stride = key_valid.stride(0)
+    if out is None:
+        out = torch.empty((B, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+    rc = _lib.load().vly_decode_attention(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                          _ptr(key_valid), kv_stride, out.data_ptr(), B, heads, past_len, _ptr(past_dev),
+                                          ctx_max, _stream())
+    _lib.check(rc, "vly_decode_attention")
+    return out
+
+
 def argmax(x: torch.Tensor, out=None) -> torch.Tensor:
     """x fp32 [M,N] (row stride may exceed N) -> int32 [M]."""
     _chk(x, torch.float32, "x", contiguous=False)
