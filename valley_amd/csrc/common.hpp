@@ -26,6 +26,13 @@ VLY_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vly_bf16x2));
 }
 
+// x * sigmoid(a*x) with one v_exp_f32 and one v_rcp_f32 (a full IEEE division costs ~10 VALU instructions,
+// which showed up as 4-5 us of un-overlapped epilogue on the 8224 x 4096 quick_gelu GEMM); 1 ulp, far below
+// the bf16 rounding of the result.  quick_gelu: a = 1.702 (hf activations.py QuickGELU); SiLU: a = 1.
+VLY_DEVICE float x_sigmoid(float x, float a) {
+    return x * __builtin_amdgcn_rcpf(1.f + __expf(-a * x));
+}
+
 // D(16x16) += A(16x32) * B(32x16).  Lane l supplies A[row = l&15][k = 8*(l>>4) .. +7] and
 // B[k = 8*(l>>4) .. +7][col = l&15]; it receives D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
 VLY_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {

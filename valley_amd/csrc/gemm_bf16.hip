@@ -14,6 +14,8 @@
 //     8-byte (bf16) or 16-byte (fp32) pieces along the row;
 //   * block id -> tile mapping gives each XCD (private 4 MiB L2) a contiguous run of tiles.
 // Algorithmic work: 2*M*N*K flop per launch; HBM traffic floor (M*K + N*K)*2 + M*N*out bytes.
+#include <cstdlib>
+#include <cstring>
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -34,7 +36,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
-            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int m_fast) {
+            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int m_fast, int wide) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -42,7 +44,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;      // glds passes per tile
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
 
-    __shared__ __attribute__((aligned(16))) char smem[(PIPE == 6 || PIPE == 7 ? 3 : 2) * STAGE];
+    // bf16 outputs leave through LDS (see the epilogue): the C tile image may be larger than the K-loop stages
+    constexpr int BNO = EPI == VLY_EPI_SWIGLU ? BN / 2 : BN;          // output columns of the tile
+    constexpr int C_ROW = BNO * 2 + 16;                               // bytes per LDS row of the C image (+16: bank shift)
+    constexpr int K_BYTES = (PIPE == 6 || PIPE == 7 ? 3 : 2) * STAGE;
+    constexpr int SMEM_BYTES = (OUT == VLY_OUT_BF16 && BM * C_ROW > K_BYTES) ? BM * C_ROW : K_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -450,6 +457,67 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     }
 
     // ---- epilogue: lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g ----------------------
+    // bf16 outputs go through LDS: a fragment store covers 16 rows x 32 contiguous bytes (a quarter of each
+    // 128-byte line per instruction; tools/probes/store_pattern.hip: 3.0 TB/s for the 67 MB ViT fc1 output),
+    // so the tile is first assembled in LDS and then written as full lines, 16 bytes per lane with
+    // consecutive lanes along the row (4.6 TB/s).  The fused bias / activation / residual math is unchanged.
+    if constexpr (OUT == VLY_OUT_BF16) {
+        if (wide) {
+            __syncthreads();                                  // every wave is done with the K-loop stages
+            // two halves of every wave's fragment rows: the stores of the first half are in flight while the
+            // second half's bias / activation math runs (the exp of quick_gelu / SiLU is not free)
+            static_assert(MI % 2 == 0, "epilogue halves");
+            constexpr int HR = (MI / 2) * 16;                     // rows per wave-row block and half
+            constexpr int CPR = BNO / 8;                          // 16-byte chunks per tile row
+            const int n0o = EPI == VLY_EPI_SWIGLU ? n0 >> 1 : n0, No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int ii = 0; ii < MI / 2; ++ii) {
+                    const int i = half * (MI / 2) + ii;
+                    const int row = wm0 + i * 16 + l15, m = m0 + row;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int col = wn0 + j * 16 + g * 4, n = n0 + col;
+                        f32x4 v = acc[i][j];
+                        const bool in = m < M && n < N;
+                        if (bias && in) v += *(const f32x4*)(bias + n);
+                        if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
+                        }
+                        if constexpr (EPI == VLY_EPI_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        if constexpr (EPI == VLY_EPI_SWIGLU) {
+                            const float o0 = x_sigmoid(v[0], 1.f) * v[1];
+                            const float o1 = x_sigmoid(v[2], 1.f) * v[3];
+                            *(uint32_t*)(smem + row * C_ROW + (col >> 1) * 2) = pack_bf16x2(o0, o1);
+                        } else {
+                            if (R && in) v += *(const f32x4*)(R + (size_t)m * ldr + n);
+                            u32x2 pk;
+                            pk[0] = pack_bf16x2(v[0], v[1]);
+                            pk[1] = pack_bf16x2(v[2], v[3]);
+                            *(u32x2*)(smem + row * C_ROW + col * 2) = pk;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int c = tid; c < (BM / 2) * CPR; c += NT) {
+                    const int hr = c / CPR, q = c - hr * CPR;     // hr: row index inside this half's row set
+                    const int row = (hr / HR) * WM + half * HR + hr % HR;
+                    const int m = m0 + row, n = n0o + q * 8;
+                    if (m >= M || n >= No) continue;
+                    const u32x4 d = *(const u32x4*)(smem + row * C_ROW + q * 16);
+                    uint16_t* dst = (uint16_t*)Cv + (size_t)m * ldc + n;
+                    if (n + 8 <= No) *(u32x4*)dst = d;
+                    else *(u32x2*)dst = u32x2{d[0], d[1]};      // N % 4 == 0: the ragged chunk holds exactly 4 columns
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm0 + i * 16 + l15;
@@ -465,15 +533,15 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             }
             if constexpr (EPI == VLY_EPI_QUICK_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
             }
             if constexpr (EPI == VLY_EPI_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (EPI == VLY_EPI_SWIGLU) {
-                const float o0 = v[0] / (1.f + __expf(-v[0])) * v[1];
-                const float o1 = v[2] / (1.f + __expf(-v[2])) * v[3];
+                const float o0 = x_sigmoid(v[0], 1.f) * v[1];
+                const float o1 = x_sigmoid(v[2], 1.f) * v[3];
                 const size_t o = (size_t)m * ldc + (n >> 1);
                 if constexpr (OUT == VLY_OUT_BF16) {
                     *(uint32_t*)((uint16_t*)Cv + o) = pack_bf16x2(o0, o1);
@@ -505,10 +573,13 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
+    // full-line stores through LDS need 16-byte aligned output rows (VLY_EPILOGUE=frag: A/B switch for measurements)
+    static const bool frag_only = getenv("VLY_EPILOGUE") && !strcmp(getenv("VLY_EPILOGUE"), "frag");
+    const int wide = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !frag_only) ? 1 : 0;
     dim3 grid(tm * tn), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O, PIPE>), grid, block, 0, st, (const uint16_t*)A,   \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, wide)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);

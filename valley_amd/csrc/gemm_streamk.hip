@@ -294,15 +294,15 @@ gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                     if (bias) v += *(const f32x4*)(bias + n);
                     if constexpr (EPI == VLY_EPI_QUICK_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+                        for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
                     }
                     if constexpr (EPI == VLY_EPI_RELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
                     if constexpr (EPI == VLY_EPI_SWIGLU) {
-                        const float o0 = v[0] / (1.f + __expf(-v[0])) * v[1];
-                        const float o1 = v[2] / (1.f + __expf(-v[2])) * v[3];
+                        const float o0 = x_sigmoid(v[0], 1.f) * v[1];
+                        const float o1 = x_sigmoid(v[2], 1.f) * v[3];
                         const size_t o = (size_t)m * ldc + (n >> 1);
                         if constexpr (OUT == VLY_OUT_BF16) *(uint32_t*)((uint16_t*)Cv + o) = pack_bf16x2(o0, o1);
                         else *(float2*)((float*)Cv + o) = make_float2(o0, o1);

@@ -69,11 +69,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
         if (m >= M) break;
         float v0 = acc0[m] + b0, v1 = acc1[m] + b1;
         if constexpr (EPI == VLY_EPI_QUICK_GELU) {
-            v0 = v0 / (1.f + __expf(-1.702f * v0));
-            v1 = v1 / (1.f + __expf(-1.702f * v1));
+            v0 = x_sigmoid(v0, 1.702f);
+            v1 = x_sigmoid(v1, 1.702f);
         }
         if constexpr (EPI == VLY_EPI_SWIGLU) {
-            const float o = v0 / (1.f + __expf(-v0)) * v1;
+            const float o = x_sigmoid(v0, 1.f) * v1;
             const size_t off = (size_t)m * ldc + (n0 >> 1);
             if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f32_to_bf16(o);
             else ((float*)Cv)[off] = o;
