@@ -39,6 +39,9 @@ CONFIGS = {
     # name: (B clips per GPU, T frames, hidden, heads, intermediate, layers, eps, label)
     "c2": dict(B=4, T=8, H=4096, heads=32, I=11008, L=32, eps=1e-5, label="Valley2-7b: 8 frames x batch 4, ViT-L/14 + Llama-2-7B prefill"),
     "c3": dict(B=8, T=16, H=5120, heads=40, I=13824, L=40, eps=1e-6, label="Valley-13b-v1: 16 frames x batch 8, ViT-L/14 + Vicuna-13B prefill"),
+    # configs[3]: 64 clips x 32 frames over 8 GPUs = 8 clips per GPU; run with --gpus 8 --prefill replicated for the
+    # literal configuration (all 64 sequences prefilled on every rank), default --prefill sharded for weak scaling
+    "c4": dict(B=8, T=32, H=5120, heads=40, I=13824, L=40, eps=1e-6, label="Valley-13b-v1: 32 frames x 8 clips per GPU, ViT-L/14 + Vicuna-13B prefill"),
     "tiny": dict(B=2, T=4, H=256, heads=2, I=512, L=2, eps=1e-5, label="tiny plumbing config"),
 }
 VOCAB_TEXT = 32000
