@@ -14,6 +14,7 @@ shapes = [tuple(int(x) for x in s.split(",")) for s in sys.argv[1].split(";")]
 tiles = [("tile", int(t)) for t in sys.argv[2].split(",") if t]
 if len(sys.argv) > 3:
     tiles += [("sk", int(t)) for t in sys.argv[3].split(",") if t]
+WARM_W = bool(int(os.environ.get("SWEEP_WARM_W", "0")))
 d = torch.device("cuda:0")
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=d)
 for M, N, K, epi in shapes:
@@ -27,6 +28,7 @@ for M, N, K, epi in shapes:
         ref = torch.nn.functional.silu(g) * u
     out = torch.empty((M, N // 2 if epi == 2 else N), device=d, dtype=torch.bfloat16)
     warm = torch.empty_like(a)
+    warm_w = torch.empty_like(w) if WARM_W else None
     for kind, t in tiles:
         fn = ops.gemm_mfma if kind == "tile" else ops.gemm_streamk
         try:
@@ -34,6 +36,8 @@ for M, N, K, epi in shapes:
             for _ in range(7):
                 flush.zero_()
                 warm.copy_(a)                              # A is produced just before the GEMM: cache-warm
+                if WARM_W:
+                    warm_w.copy_(w)                        # experiment: weights resident in the Infinity Cache
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 fn(a, w, epilogue=epi, out=out, tile_hint=t)
