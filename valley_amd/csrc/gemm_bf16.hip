@@ -654,6 +654,10 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         case 84: return launch_tile<128, 256, 64, 64, 7>(VLY_TILE_ARGS);
         case 86: return launch_tile<192, 192, 96, 48, 7>(VLY_TILE_ARGS);
         case 56: return launch_tile<192, 192, 96, 48, 4>(VLY_TILE_ARGS);
+        // 128x192: 40 KB per stage, two 2-stage workgroups per CU (each covers the other's prologue / epilogue)
+        case 7: return launch_tile<128, 192, 64, 48, 0>(VLY_TILE_ARGS);
+        case 57: return launch_tile<128, 192, 64, 48, 4>(VLY_TILE_ARGS);
+        case 8: return launch_tile<192, 128, 96, 32, 0>(VLY_TILE_ARGS);
         case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);

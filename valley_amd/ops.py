@@ -21,7 +21,8 @@ POOL_MEAN, POOL_MAX, POOL_IMPORTANCE = 0, 1, 2
 # (kernel_label, algorithmic_flops, start_event, end_event, (M, N, K, epilogue)) for every MFMA GEMM launch.
 _RECORDER = None
 TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64", 4: "128, 256, 64, 64",
-              5: "192, 256, 96, 64", 6: "192, 192, 96, 48"}
+              5: "192, 256, 96, 64", 6: "192, 192, 96, 48", 7: "128, 192, 64, 48",
+              8: "192, 128, 96, 32"}
 
 
 def set_recorder(rec):
@@ -183,7 +184,7 @@ def _flush_caches(device):
     buf.zero_()
 
 
-CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 35, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86)] + \
+CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 51, 53, 54, 55, 57, 73, 74, 76, 83, 84, 86)] + \
              [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 _ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
