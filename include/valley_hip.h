@@ -58,13 +58,13 @@ const char *vly_last_error(void);
  *   mm_projector (valley_model.py:54-55,190), Llama q/k/v/o (hf:llama/modeling_llama.py:230-241),
  *   gate/up/down (:166-168), lm_head (valley_model.py:264,305).
  *   tile_hint: 0 = auto, 1 = 256x256, 2 = 128x128, 3 = 256x128, 4 = 128x256, 5 = 192x256, 6 = 192x192,
- *   7 = 128x192, 8 = 192x128 (BM x BN).  Tiles 7 and 8 use 80 KB of LDS so that TWO workgroups share a CU and
+ *   7 = 128x192, 8 = 192x128, 9 = 256x256 with 16 waves (BM x BN).  Tiles 7 and 8 use 80 KB of LDS so that TWO workgroups share a CU and
  *   cover each other's prologue and epilogue: the fastest choice for the K = 1024 ViT GEMMs.
  *   Loop variants (tuning / tests): +10 counted-vmcnt half-tile pipeline; +30 / +50 (8-wave tiles) role-split
  *   pipelines (the two waves of a SIMD run one phase apart; +50 keeps whole-K-tile staging with 128-byte LDS
  *   rows); +70 (tiles 3, 4, 6: stage <= 53 KB) THREE whole-K-tile stages, i.e. two K tiles of glds loads in
  *   flight (LDS-DMA issue -> landed is ~2600 clk, more than one K tile of MFMA work on these tiles); +80 =
- *   +70 with the role split of +50. */
+ *   +70 with the role split of +50; 93 / 94 = 256x128 / 128x256 with 16 waves and three stages. */
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);

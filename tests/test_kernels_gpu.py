@@ -29,7 +29,7 @@ def maxabs(got, ref):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 31, 33, 34, 35, 51, 53, 54, 55, 56, 57, 73, 74, 76, 83, 84, 86])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 31, 33, 34, 35, 51, 53, 54, 55, 56, 57, 73, 74, 76, 83, 84, 86, 93, 94])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (1028, 1024, 1024), (64, 512, 64), (513, 4096, 640)])
 def test_gemm_plain(M, N, K, tile):
     from valley_amd import ops
@@ -44,7 +44,7 @@ def test_gemm_plain(M, N, K, tile):
     assert relerr(out16, ref) < 4e-3
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 31, 33, 34, 35, 51, 53, 54, 55, 56, 57, 73, 74, 76, 83, 84, 86])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 31, 33, 34, 35, 51, 53, 54, 55, 56, 57, 73, 74, 76, 83, 84, 86, 93, 94])
 def test_gemm_epilogues(tile):
     from valley_amd import ops
     M, N, K = 771, 1024, 256

@@ -658,6 +658,10 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         case 7: return launch_tile<128, 192, 64, 48, 0>(VLY_TILE_ARGS);
         case 57: return launch_tile<128, 192, 64, 48, 4>(VLY_TILE_ARGS);
         case 8: return launch_tile<192, 128, 96, 32, 0>(VLY_TILE_ARGS);
+        // 16 waves (4 x 4): four waves per SIMD hide LDS / barrier latency without the role split
+        case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
+        case 93: return launch_tile<256, 128, 64, 32, 6>(VLY_TILE_ARGS);
+        case 94: return launch_tile<128, 256, 32, 64, 6>(VLY_TILE_ARGS);
         case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);

@@ -22,7 +22,8 @@ POOL_MEAN, POOL_MAX, POOL_IMPORTANCE = 0, 1, 2
 _RECORDER = None
 TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 64", 4: "128, 256, 64, 64",
               5: "192, 256, 96, 64", 6: "192, 192, 96, 48", 7: "128, 192, 64, 48",
-              8: "192, 128, 96, 32"}
+              8: "192, 128, 96, 32", 9: "256, 256, 64, 64"}
+TILE_SPECIAL = {93: ("256, 128, 64, 32", 6), 94: ("128, 256, 32, 64", 6)}      # 16-wave 3-stage variants
 
 
 def set_recorder(rec):
@@ -79,8 +80,12 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
     if rec is not None:
         e1.record()
-        name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}, {sk_loop}>" if sk else \
-            f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[tile // 10]}>"
+        if sk:
+            name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}, {sk_loop}>"
+        elif tile in TILE_SPECIAL:
+            name = f"gemm_kernel<{TILE_SPECIAL[tile][0]}, {epilogue}, {od}, {TILE_SPECIAL[tile][1]}>"
+        else:
+            name = f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[tile // 10]}>"
         rec.append((name, 2.0 * M * N * K, e0, e1, (M, N, K, epilogue)))
     _lib.check(rc, fn_name)
     return out
@@ -184,7 +189,7 @@ def _flush_caches(device):
     buf.zero_()
 
 
-CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 51, 53, 54, 55, 57, 73, 74, 76, 83, 84, 86)] + \
+CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94)] + \
              [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 _ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
