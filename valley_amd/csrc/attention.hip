@@ -36,7 +36,10 @@ constexpr int VLD = 3072;          // qkv row stride (elements)
 constexpr int VT_STRIDE = 296;     // V^T row stride in elements (592 B = 2*256 + 16*5)
 constexpr int VK_BYTES = VNT * 16 * 128;
 
-__global__ void __launch_bounds__(256, 2) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+constexpr int VNW = 8;             // waves per workgroup: 2 workgroups x 8 waves = 4 waves per SIMD hide the LDS / MFMA
+                                   // latency chains of a 16-query block (4 waves: 31.5 us per layer at 32 frames)
+
+__global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2];
     char* sK = smem;
     uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
@@ -47,40 +50,41 @@ __global__ void __launch_bounds__(256, 2) vit_attn_kernel(const uint16_t* __rest
     const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
 
     // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7 ------------------------------------
-    for (int s = tid; s < VNT * 16 * 8; s += 256) {
+    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
         const int row = s >> 3, c = s & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
         *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = v;
     }
-    // ---- V^T: [64 d][288 kv]; wave w transposes d = 16w..16w+15, lane <-> key pair ---------------
-#pragma unroll
-    for (int pg = 0; pg < 3; ++pg) {
+    // ---- V^T: [64 d][288 kv]; wave w transposes d = 16(w&3)..+15, lane <-> key pair; the key-pair groups
+    //      pg = 0,1,2 are dealt to the wave quads (w>>2) round-robin
+    const int dq = wave & 3;
+    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
         const int p = pg * 64 + lane;
         if (p < VNC * 16) {
             const int kv0 = 2 * p, kv1 = kv0 + 1;
             u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
             if (kv0 < VN) {
-                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + wave * 16;
+                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + dq * 16;
                 a0 = *(const u32x4*)r0;
                 a1 = *(const u32x4*)(r0 + 8);
             }
             if (kv1 < VN) {
-                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + wave * 16;
+                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + dq * 16;
                 b0 = *(const u32x4*)r1;
                 b1 = *(const u32x4*)(r1 + 8);
             }
 #pragma unroll
             for (int dd = 0; dd < 16; ++dd) {
                 const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
-                *(uint32_t*)(sVt + (wave * 16 + dd) * VT_STRIDE + kv0) = w;
+                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + kv0) = w;
             }
         }
     }
     __syncthreads();
 
     const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
-    for (int qt = wave; qt < VNT; qt += 4) {
+    for (int qt = wave; qt < VNT; qt += VNW) {
         const int q = qt * 16 + l15;
         const int qc = min(q, VN - 1);
         bf16x8 qf[2];
@@ -573,7 +577,7 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
-    hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
     return vly_check_launch("vly_vit_attention");
 }
 
