@@ -170,12 +170,16 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 
 // ---------------------------------------------------------------------------------------------
 // Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
-// grid = (ceil(S/64), heads, B); 4 waves x 16 query rows.
+// grid = (ceil(S/(16*LNW)), heads, B); LNW waves x 16 query rows.
 // ---------------------------------------------------------------------------------------------
 constexpr int LK_BYTES = 64 * 256;          // K tile: 64 keys x 128 d, 256-byte rows, chunk ^= row & 15
 constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row stride 144 B = 16*9
 
-__global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
+// LNW waves x 16 query rows per workgroup: with 8 waves a K/V tile staged into LDS serves 128 queries (half the
+// redundant tile loads and transposes of the 64-query version) and a CU holds 16 waves.
+constexpr int LNW = 8;
+
+__global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
                                                          const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
                                                          uint16_t* __restrict__ out, int S, int heads, int past,
                                                          const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
     if (past_dev) past = min(*past_dev, ctx_max - S);
     const int kv_len = past + S;
 
-    const int q = qb * 64 + wave * 16 + l15;             // query row inside this call
+    const int q = qb * (LNW * 16) + wave * 16 + l15;      // query row inside this call
     const int qc = min(q, S - 1);
     const int qpos = past + q;                            // absolute position: keys <= qpos are visible
     const uint16_t* qp = qkv + ((size_t)b * S + qc) * 3 * Hq + h * 128;
@@ -202,7 +206,8 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
     const uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
     const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
 
-    const int q_last = min(qb * 64 + 63, S - 1);
+    const int q_last = min(qb * (LNW * 16) + LNW * 16 - 1, S - 1);
+    const int wave_qpos_max = past + min(qb * (LNW * 16) + wave * 16 + 15, S - 1);   // tiles beyond it are fully masked for this wave
     const int kv_end = min(past + q_last + 1, kv_len);
     const int ntiles = (kv_end + 63) >> 6;
 
@@ -215,28 +220,30 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
     // Register-staged K/V tiles (async-stage split): the global loads of tile t+1 are issued right
     // before tile t's MFMAs and written to LDS after the next barrier, so HBM/L2 latency hides under
     // compute instead of sitting between two barriers.
-    const int p_v = tid & 31, dg_v = tid >> 5;              // V^T staging: thread <-> (key pair, group of 16 d)
-    u32x4 kreg[4], va0, va1, vb0, vb1;
+    constexpr int NT = LNW * 64, KCH = 1024 / NT;           // K chunks per thread; V^T: thread <-> (key pair, 4096/NT d)
+    constexpr int VD = 4096 / NT;                           // d elements per thread (16 at 4 waves, 8 at 8 waves)
+    const int p_v = tid & 31, dg_v = tid >> 5;
+    u32x4 kreg[KCH], va0, va1, vb0, vb1;
     bool okreg = false;
     auto load_tile = [&](int kt) {
         const int kv0 = kt * 64;
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = i * 256 + tid, row = s >> 4, c = s & 15;
+        for (int i = 0; i < KCH; ++i) {
+            const int s = i * NT + tid, row = s >> 4, c = s & 15;
             kreg[i] = (kv0 + row < kv_len) ? *(const u32x4*)(kbase + (size_t)(kv0 + row) * 128 + c * 8) : z;
         }
         const int r0 = kv0 + 2 * p_v, r1 = r0 + 1;
         va0 = va1 = vb0 = vb1 = z;
         if (r0 < kv_len) {
-            const uint16_t* x = vbase + (size_t)r0 * 128 + dg_v * 16;
+            const uint16_t* x = vbase + (size_t)r0 * 128 + dg_v * VD;
             va0 = *(const u32x4*)x;
-            va1 = *(const u32x4*)(x + 8);
+            if (VD == 16) va1 = *(const u32x4*)(x + 8);
         }
         if (r1 < kv_len) {
-            const uint16_t* x = vbase + (size_t)r1 * 128 + dg_v * 16;
+            const uint16_t* x = vbase + (size_t)r1 * 128 + dg_v * VD;
             vb0 = *(const u32x4*)x;
-            vb1 = *(const u32x4*)(x + 8);
+            if (VD == 16) vb1 = *(const u32x4*)(x + 8);
         }
         const int kvl = kv0 + lane;
         okreg = kvl < kv_len && (!kvld || kvld[kvl] != 0);
@@ -248,19 +255,20 @@ __global__ void __launch_bounds__(256) llama_attn_kernel(const uint16_t* __restr
         __syncthreads();                                  // previous tile fully consumed
         // ---- registers -> LDS: K row-major swizzled, V transposed ----------------------------------
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = i * 256 + tid, row = s >> 4, c = s & 15;
+        for (int i = 0; i < KCH; ++i) {
+            const int s = i * NT + tid, row = s >> 4, c = s & 15;
             *(u32x4*)(sK + row * 256 + ((c ^ (row & 15)) << 4)) = kreg[i];
         }
 #pragma unroll
-        for (int dd = 0; dd < 16; ++dd) {
+        for (int dd = 0; dd < VD; ++dd) {
             const uint32_t w = sel16(va0, va1, dd) | (sel16(vb0, vb1, dd) << 16);
-            *(uint32_t*)(sVt + (dg_v * 16 + dd) * LVT_STRIDE + 2 * p_v) = w;
+            *(uint32_t*)(sVt + (dg_v * VD + dd) * LVT_STRIDE + 2 * p_v) = w;
         }
         // key validity of this tile as a 64-bit wave mask (lane <-> key kv0 + lane)
         const unsigned long long vmask = __ballot(okreg);
         __syncthreads();
         if (kt + 1 < ntiles) load_tile(kt + 1);           // in flight while this tile is multiplied
+        if (kv0 > wave_qpos_max) continue;                // every key of this tile is in this wave's future (wave-uniform)
 
         // ---- S^T tile ---------------------------------------------------------------------------
         f32x4 s[4];
@@ -599,7 +607,7 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
                            past_len_dev, key_valid_stride, ctx_max);
         return vly_check_launch("vly_llama_attention(decode)");
     }
-    hipLaunchKernelGGL(llama_attn_kernel, dim3((S + 63) / 64, heads, B), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(llama_attn_kernel, dim3((S + 16 * LNW - 1) / (16 * LNW), heads, B), dim3(LNW * 64), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
                        S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
     return vly_check_launch("vly_llama_attention");
