@@ -273,7 +273,7 @@ def main():
             tp = torch.tensor([pend], device=dev, dtype=torch.int64)
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             pend = int(tp.item())
-        if pend == 0 or tune_passes >= 400:
+        if pend == 0 or tune_passes >= 600:
             break
     for _ in range(args.warmup):
         step(False)
