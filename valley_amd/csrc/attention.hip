@@ -480,9 +480,9 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
         const float q0 = bf16_to_f32(qp[tid]), q1 = bf16_to_f32(qp[tid + 64]);
         const float k0 = bf16_to_f32(qp[Hq + tid]), k1 = bf16_to_f32(qp[Hq + tid + 64]);
         const float scale = 0.08838834764831845f * LOG2E;
-        qs[tid] = bf16_to_f32(f32_to_bf16(q0 * cs - q1 * sn)) * scale;
-        qs[tid + 64] = bf16_to_f32(f32_to_bf16(q1 * cs + q0 * sn)) * scale;
-        const uint16_t r0 = f32_to_bf16(k0 * cs - k1 * sn), r1 = f32_to_bf16(k1 * cs + k0 * sn);
+        qs[tid] = bf16_to_f32(f32_to_bf16(rope_rot(q0, q1, cs, sn, -1.f))) * scale;
+        qs[tid + 64] = bf16_to_f32(f32_to_bf16(rope_rot(q1, q0, cs, sn, 1.f))) * scale;
+        const uint16_t r0 = f32_to_bf16(rope_rot(k0, k1, cs, sn, -1.f)), r1 = f32_to_bf16(rope_rot(k1, k0, cs, sn, 1.f));
         knew[tid] = bf16_to_f32(r0);
         knew[tid + 64] = bf16_to_f32(r1);
         kbase[(size_t)pos * 128 + tid] = r0;

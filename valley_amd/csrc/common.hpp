@@ -33,6 +33,13 @@ VLY_DEVICE float x_sigmoid(float x, float a) {
     return x * __builtin_amdgcn_rcpf(1.f + __expf(-a * x));
 }
 
+// Rotate-half RoPE of one element pair, written ONE way for every kernel that rotates (vly_rope_kv, the fused
+// prefill and decode attention kernels), so that the cached keys are bit-identical whichever path wrote them:
+//   low half  (d <  64): x*cos - partner*sin        high half (d >= 64): x*cos + partner*sin
+VLY_DEVICE float rope_rot(float x, float partner, float c, float s, float sign) {
+    return fmaf(x, c, sign * (partner * s));
+}
+
 // D(16x16) += A(16x32) * B(32x16).  Lane l supplies A[row = l&15][k = 8*(l>>4) .. +7] and
 // B[k = 8*(l>>4) .. +7][col = l&15]; it receives D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
 VLY_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {

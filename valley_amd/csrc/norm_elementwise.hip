@@ -374,8 +374,8 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv
         for (int i = 0; i < 4; ++i) {
             const float a0 = __uint_as_float(lo[i] << 16), a1 = __uint_as_float(lo[i] & 0xffff0000u);
             const float b0 = __uint_as_float(hi[i] << 16), b1 = __uint_as_float(hi[i] & 0xffff0000u);
-            olo[i] = pack_bf16x2(a0 * cs[2 * i] - b0 * sn[2 * i], a1 * cs[2 * i + 1] - b1 * sn[2 * i + 1]);
-            ohi[i] = pack_bf16x2(b0 * cs[2 * i] + a0 * sn[2 * i], b1 * cs[2 * i + 1] + a1 * sn[2 * i + 1]);
+            olo[i] = pack_bf16x2(rope_rot(a0, b0, cs[2 * i], sn[2 * i], -1.f), rope_rot(a1, b1, cs[2 * i + 1], sn[2 * i + 1], -1.f));
+            ohi[i] = pack_bf16x2(rope_rot(b0, a0, cs[2 * i], sn[2 * i], 1.f), rope_rot(b1, a1, cs[2 * i + 1], sn[2 * i + 1], 1.f));
         }
     };
     u32x4 olo, ohi;
