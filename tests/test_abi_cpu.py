@@ -52,3 +52,30 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_shipped_tuning_table_is_consistent():
+    """valley_amd/tuned/gfx950.json (decisions of the online GEMM tuner for the reference configurations) loads,
+    names only kernels the dispatcher knows, and covers every GEMM shape of configs[1]."""
+    import json
+    import os
+
+    from valley_amd import ops
+    path = os.path.join(os.path.dirname(ops.__file__), "tuned", "gfx950.json")
+    ents = json.load(open(path))
+    assert len(ents) >= 11
+    known = set(ops.CANDIDATES) | {("tile", 57), ("tile", 56)}
+    for e in ents:
+        assert (e["kind"], e["tile"]) in known, e
+        assert e["key"][4] in ("torch.bfloat16", "torch.float32")
+    keys = {tuple(e["key"][:4]) for e in ents}
+    for shape in [(1312, 12288, 4096, 0), (1312, 4096, 4096, 0), (1312, 22016, 4096, 2), (1312, 4096, 11008, 0),
+                  (8224, 3072, 1024, 0), (8224, 1024, 1024, 0), (8224, 4096, 1024, 1), (8224, 1024, 4096, 0)]:
+        assert shape in keys, shape
+    saved = dict(ops._TUNED)
+    try:
+        ops._TUNED.clear()
+        assert ops.load_tune_cache(path) == len(ents)
+    finally:
+        ops._TUNED.clear()
+        ops._TUNED.update(saved)
