@@ -18,14 +18,14 @@ VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {
     return s;
 }
 
-// KS = 1: every wave owns two weight rows.  KS = 4 (few rows: N/2 < 4096 waves could not keep enough loads in
-// flight to reach the HBM rate — o_proj / down_proj at 4.0-4.5 TB/s): the workgroup owns two rows and its four
-// waves split K, partial sums meet in LDS.
+// KS = 1: every wave owns two weight rows (short rows).  KS = 4 (K >= 2048, i.e. every decode projection): the
+// workgroup owns two rows and its four waves split K, partial sums meet in LDS — four times the waves, hence
+// four times the loads in flight: o/down 4.0-4.5 -> 4.9-5.5 TB/s, q|k|v 5.9 -> 6.4, gate/up 6.5 -> 6.8, lm_head 6.9.
 template <int MR, int EPI, int OUT, int KS>
 __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                    const float* __restrict__ bias, const float* __restrict__ R,
                                                    void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
-    __shared__ float red[KS == 1 ? 1 : 4 * 2 * MR];
+    __shared__ float red[KS == 1 ? 1 : KS * 2 * MR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = (KS == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * 2;
     if (n0 >= N) return;
@@ -56,9 +56,12 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {                       // fixed order: wave 0 + 1 + 2 + 3
-            acc0[m] = red[m * 2] + red[(MR + m) * 2] + red[(2 * MR + m) * 2] + red[(3 * MR + m) * 2];
-            acc1[m] = red[m * 2 + 1] + red[(MR + m) * 2 + 1] + red[(2 * MR + m) * 2 + 1] + red[(3 * MR + m) * 2 + 1];
+        for (int m = 0; m < MR; ++m) {                       // fixed order: wave 0 + 1 + 2 + ...
+            float s0 = red[m * 2], s1 = red[m * 2 + 1];
+#pragma unroll
+            for (int w = 1; w < KS; ++w) { s0 += red[(w * MR + m) * 2]; s1 += red[(w * MR + m) * 2 + 1]; }
+            acc0[m] = s0;
+            acc1[m] = s1;
         }
     }
     if (lane != 0) return;
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
 template <int MR>
 int launch_mr(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
               int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
-    const bool split = (N + 1) / 2 < 4096 && K >= 2048;     // few rows, long rows: 4 waves per row pair
+    const bool split = K >= 2048;                            // long rows: the workgroup's four waves split K
     dim3 grid(split ? (N + 1) / 2 : (N + 7) / 8), block(256);
 #define VLY_GEMV(E, O)                                                                                            \
     do {                                                                                                          \
