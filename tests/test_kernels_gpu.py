@@ -69,6 +69,35 @@ def test_gemm_epilogues(tile):
     assert relerr(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("tile", [1, 2, 5, 7, 8, 9, 51, 86, 94])
+def test_gemm_ragged_columns_through_lds_epilogue(tile):
+    """N % 8 == 4: the last 16-byte chunk of every output row is half valid (the LDS full-line epilogue writes
+    8 bytes there), with and without the SwiGLU halving; an output row stride that is not 16-byte aligned
+    (falls back to the fragment stores) gives the same values."""
+    from valley_amd import ops
+    M, K = 333, 192
+    for N, epi in ((260, ops.EPI_NONE), (520, ops.EPI_SWIGLU), (132, ops.EPI_QUICK_GELU)):
+        a = rnd((M, K), 61, dtype=torch.bfloat16).to(dev())
+        w = rnd((N, K), 62, 0.05, dtype=torch.bfloat16).to(dev())
+        base = a.float() @ w.float().t()
+        if epi == ops.EPI_SWIGLU:
+            ref = torch.nn.functional.silu(base[:, 0::2]) * base[:, 1::2]
+        elif epi == ops.EPI_QUICK_GELU:
+            ref = base * torch.sigmoid(1.702 * base)
+        else:
+            ref = base
+        No = ref.shape[1]
+        out = torch.full((M, No + 12), 7.0, dtype=torch.bfloat16, device=dev())         # guard columns
+        assert (No + 12) % 8 == 0 and No % 8 == 4
+        ops.gemm_mfma(a, w, epilogue=epi, out=out[:, :No], tile_hint=tile)              # ldc % 8 == 0: 16-byte aligned rows
+        assert relerr(out[:, :No], ref) < 4e-3
+        assert float((out[:, No:].float() - 7.0).abs().max()) == 0.0                   # nothing written past N
+        out2 = torch.full((M, No + 2), 7.0, dtype=torch.bfloat16, device=dev())         # ldc % 8 != 0: fragment-store path
+        ops.gemm_mfma(a, w, epilogue=epi, out=out2[:, :No], tile_hint=tile)
+        assert torch.equal(out2[:, :No], out[:, :No])
+        assert float((out2[:, No:].float() - 7.0).abs().max()) == 0.0
+
+
 def test_gemm_strided_a_and_asymmetric():
     """A with a row stride (a slice of a wider buffer) and a weight with one hot row/col: catches
     transposed fragments that symmetric data would hide."""
