@@ -319,6 +319,19 @@ def test_decode_attention_fused_equals_rope_then_attention(B, past, heads, pad, 
     assert torch.equal(got3, got) and torch.equal(k3, k2)
 
 
+def test_c_abi_smoke_binary():
+    """The C ABI from a host that is neither Python nor torch: tests/c_abi/abi_smoke.cpp dlopens libvalley_hip.so,
+    runs vly_gemm_bf16 (+bias, quick_gelu), an argument-error path and vly_rmsnorm on hipMalloc'ed buffers and
+    checks them against its own host arithmetic."""
+    import subprocess
+    from valley_amd import build as b
+    exe = b.build_abi_smoke(verbose=False)
+    r = subprocess.run([exe, b.LIB], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "C ABI smoke: OK" in r.stdout
+
+
 def test_argmax():
     from valley_amd import ops
     x = rnd((5, 32006), 40)

@@ -54,6 +54,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+ABI_SMOKE_SRC = os.path.join(HERE, "..", "tests", "c_abi", "abi_smoke.cpp")
+ABI_SMOKE = os.path.join(LIBDIR, "abi_smoke")
+
+
+def build_abi_smoke(verbose: bool = True) -> str:
+    """The torch-free C++ host program of tests/c_abi (dlopens the library; tests/test_kernels_gpu.py runs it)."""
+    if os.path.exists(ABI_SMOKE) and os.path.getmtime(ABI_SMOKE) >= os.path.getmtime(ABI_SMOKE_SRC):
+        return ABI_SMOKE
+    cmd = [hipcc(), "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", ABI_SMOKE_SRC, "-o", ABI_SMOKE, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return ABI_SMOKE
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
