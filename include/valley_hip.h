@@ -69,6 +69,14 @@ int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);
 
+/* Split-K by two in ONE launch:  C0 = A[:, :K/2] . W[:, :K/2]^T + bias,  C1 = A[:, K/2:] . W[:, K/2:]^T, both bf16
+ *   [M,N] with row stride ldc; the consumer adds them (vly_add2_rmsnorm).  The grid holds every tile twice, so a
+ *   projection with fewer tiles than CUs (Llama o_proj / down_proj at M = 1312: 176-224 tiles) fills the chip with
+ *   paired workgroups; the partial sums travel as bf16 (2 x 10.7 MB at c2), not as an fp32 round trip.
+ *   Same constraints as vly_gemm_bf16 (K >= 128); tile_hint as there (0 = 192x128). */
+int vly_gemm_bf16_splitk2(const void *A, const void *W, const float *bias, void *C0, void *C1,
+                          int M, int N, int K, int lda, int ldw, int ldc, int tile_hint, void *stream);
+
 /* Persistent stream-K variant of vly_gemm_bf16 (same math, epilogues and constraints): the
  *   (tile, k-tile) iteration space is cut into equal contiguous ranges over CUs x occupancy persistent
  *   workgroups, so small-M problems (configs[1]: M = 1312) keep every CU busy; partial tiles are
@@ -155,6 +163,10 @@ int vly_delta_finish(const float *delta_f32, const float *mean_f32, const float 
  *   its ValueErrors stay on the host, valley_amd/splice.py). */
 int vly_embed_splice(const int32_t *row_map, const void *embed_bf16, const void *visual_bf16,
                      float *out_f32, int R, int H, void *stream);
+
+/* vly_add_rmsnorm with two bf16 deltas (the split-K partials of vly_gemm_bf16_splitk2): h += d0 + d1; y = rmsnorm(h). */
+int vly_add2_rmsnorm(float *h, const void *delta0_bf16, const void *delta1_bf16, const float *gamma, void *y_bf16,
+                     int M, int D, float eps, void *stream);
 
 /* RoPE (rotate-half) on q and k of a fused qkv buffer + KV-cache append:
  *   qkv bf16 [B*S, 3*heads*128]; q rotated in place; rotated k and v written to

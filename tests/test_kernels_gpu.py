@@ -319,6 +319,34 @@ def test_decode_attention_fused_equals_rope_then_attention(B, past, heads, pad, 
     assert torch.equal(got3, got) and torch.equal(k3, k2)
 
 
+@pytest.mark.parametrize("tile", [0, 2, 7, 8, 84, 86, 9])
+@pytest.mark.parametrize("M,N,K", [(1312, 1024, 1024), (300, 264, 192), (77, 512, 128)])
+def test_gemm_splitk2_and_add2_rmsnorm(M, N, K, tile):
+    """vly_gemm_bf16_splitk2: the two bf16 partials are the two K halves (each checked on its own), and
+    vly_add2_rmsnorm consumes them like vly_add_rmsnorm consumes their sum."""
+    from valley_amd import ops
+    a = rnd((M, K), 71, dtype=torch.bfloat16).to(dev())
+    w = rnd((N, K), 72, 0.05, dtype=torch.bfloat16).to(dev())
+    bias = rnd((N,), 73, 0.3).to(dev())
+    o0 = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+    o1 = torch.empty_like(o0)
+    ops.gemm_mfma_splitk2(a, w, bias, o0, o1, tile)
+    h0 = (K // 64) // 2 * 64
+    r0 = a[:, :h0].float() @ w[:, :h0].float().t() + bias
+    r1 = a[:, h0:].float() @ w[:, h0:].float().t()
+    assert relerr(o0, r0) < 4e-3 and relerr(o1, r1) < 4e-3
+    if N % 4 == 0 and N >= 256:
+        D = N
+        h = rnd((M, D), 74).to(dev())
+        g = (1.0 + 0.1 * rnd((D,), 75)).to(dev())
+        h2 = h.clone()
+        y2 = ops.add_norm(h2, o0, g, None, 1e-5, rms=True, delta2=o1)
+        hs = h + o0.float() + o1.float()
+        ref = g * (hs * torch.rsqrt((hs * hs).mean(-1, keepdim=True) + 1e-5))
+        assert maxabs(h2, hs) < 1e-5
+        assert relerr(y2, ref) < 5e-3
+
+
 def test_c_abi_smoke_binary():
     """The C ABI from a host that is neither Python nor torch: tests/c_abi/abi_smoke.cpp dlopens libvalley_hip.so,
     runs vly_gemm_bf16 (+bias, quick_gelu), an argument-error path and vly_rmsnorm on hipMalloc'ed buffers and

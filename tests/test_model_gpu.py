@@ -393,3 +393,32 @@ def test_concurrent_requests_from_threads(own_streams):
     assert not errs, errs
     for i in range(len(variants)):
         assert torch.equal(got[i], want[i]), (i, float((got[i] - want[i]).abs().max()))
+
+
+def test_llama_prefill_tuned_dispatch_matches_whole_tiles(monkeypatch, tmp_path):
+    """The tuned GEMM dispatch (online tuner, incl. the split-K-by-two pairs that o_proj / down_proj hand to the
+    add+norm kernel as two bf16 partials) against the deterministic whole-tile dispatch on 7B layer shapes at the
+    configs[1] row count: every call while tuning, and the decided configuration, stays within bf16 noise."""
+    from valley_amd import ops
+    from valley_amd.llama import HipLlama
+    ll = HipLlama(4096, 32, 11008, 2, 32006, 1e-5).init_random(seed=3)
+    B, S = 4, 328
+    g = torch.Generator(device="cuda").manual_seed(9)
+    h = torch.randn((B * S, 4096), generator=g, device="cuda") * 0.02
+    ref = ll.logits(ll.forward(h.clone(), B, S, ll.new_cache(B, S))[-8:]).float()
+    monkeypatch.setattr(ops, "GEMM_MODE", "tuned")
+    monkeypatch.setattr(ops, "_TUNE_CACHE", str(tmp_path / "tune.json"))
+    monkeypatch.setattr(ops, "_TUNED", {})
+    monkeypatch.setattr(ops, "_ONLINE", {})
+    worst = 0.0
+    for it in range(200):
+        out = ll.logits(ll.forward(h.clone(), B, S, ll.new_cache(B, S))[-8:]).float()
+        torch.cuda.synchronize()
+        worst = max(worst, float((out - ref).norm() / ref.norm()))
+        if ops.tuning_pending() == 0 and it > 2:
+            break
+    assert ops.tuning_pending() == 0
+    print("tuned vs tiles worst rel-L2 over", it + 1, "passes:", worst,
+          {k[:4]: v for k, v in ops._TUNED.items() if k[3] == ops.EPI_PAIR})
+    assert worst < 1.5e-2
+    assert ops.sk_error_flag("cuda:0") == 0

@@ -36,7 +36,8 @@ template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
-            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int m_fast, int wide) {
+            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int m_fast, int wide,
+            int ksplit, void* __restrict__ Cv2) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -57,7 +58,14 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     const int l15 = lane & 15, g = lane >> 4;
 
     // ---- XCD-aware tile assignment (bijective for any grid size) ---------------------------
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    // ksplit == 2: the grid holds every tile twice; workgroups [0, tiles) reduce the first half of K into C,
+    // workgroups [tiles, 2*tiles) the second half into C2 (no bias / residual there) and the consumer adds the
+    // two bf16 partials (vly_add2_*norm).  For the N = 4096 Llama projections at M = 1312 this turns 176-224
+    // one-per-CU workgroups into 352-448 that pair up on the CUs.
+    const int nwg = ksplit == 2 ? (int)gridDim.x >> 1 : (int)gridDim.x;
+    const int part = (ksplit == 2 && (int)blockIdx.x >= nwg) ? 1 : 0;
+    const int bid = (int)blockIdx.x - part * nwg;
+    if (part) { Cv = Cv2; bias = nullptr; R = nullptr; }
     const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
     const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
     // tile order inside the XCD-contiguous run: n-fastest keeps an A row-panel in the XCD's L2 while the
@@ -72,7 +80,11 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = K / BK;
+    int nk = K / BK;
+    if (ksplit == 2) {
+        const int h0 = nk >> 1;
+        if (part) { A += (size_t)h0 * BK; W += (size_t)h0 * BK; nk -= h0; } else nk = h0;
+    }
 
     if constexpr (PIPE == 0) {
         // ================= 2-stage loop: whole K tiles, vmcnt(0) + one barrier per tile ================
@@ -569,17 +581,18 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 
 template <int BM, int BN, int WM, int WN, int PIPE>
 int launch_tile(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
-                int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
+                int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st, void* C2 = nullptr) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
     // full-line stores through LDS need 16-byte aligned output rows (VLY_EPILOGUE=frag: A/B switch for measurements)
     static const bool frag_only = getenv("VLY_EPILOGUE") && !strcmp(getenv("VLY_EPILOGUE"), "frag");
     const int wide = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !frag_only) ? 1 : 0;
-    dim3 grid(tm * tn), block(NT);
+    const int ksplit = C2 ? 2 : 1;
+    dim3 grid(tm * tn * ksplit), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O, PIPE>), grid, block, 0, st, (const uint16_t*)A,   \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, wide)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, wide, ksplit, C2)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
@@ -615,25 +628,10 @@ static int pick_tile(int M, int N) {
 
 extern "C" int vly_gemm_tile_for(int M, int N) { return pick_tile(M, N); }
 
-extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C,
-                             int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue,
-                             int out_dtype, int tile_hint, void* stream) {
-    if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16: empty problem"); return -22; }
-    if (K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
-        ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) ||
-        (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15))) {
-        vly_set_error("vly_gemm_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",
-                      M, N, K, lda, ldw, ldc, ldr);
-        return -22;
-    }
-    if ((size_t)M * lda >= (1ull << 31) || (size_t)N * ldw >= (1ull << 31)) {
-        vly_set_error("vly_gemm_bf16: operand exceeds 2^31 elements (32-bit byte offsets)");
-        return -22;
-    }
-    if (epilogue == VLY_EPI_SWIGLU && residual) { vly_set_error("vly_gemm_bf16: SWIGLU takes no residual"); return -22; }
-    hipStream_t st = (hipStream_t)stream;
-    const int t = tile_hint ? tile_hint : pick_tile(M, N);
-#define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st
+static int run_tile(int t, int tile_hint, const void* A, const void* W, const float* bias, const float* residual, void* C,
+                    int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, hipStream_t st,
+                    void* C2) {
+#define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2
     switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split over half tiles;
                                                           // 51..55: role-split over the full-tile 2-stage buffers
         case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
@@ -673,4 +671,41 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
         default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
     }
 #undef VLY_TILE_ARGS
+}
+
+extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C,
+                             int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue,
+                             int out_dtype, int tile_hint, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16: empty problem"); return -22; }
+    if (K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
+        ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) ||
+        (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15))) {
+        vly_set_error("vly_gemm_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",
+                      M, N, K, lda, ldw, ldc, ldr);
+        return -22;
+    }
+    if ((size_t)M * lda >= (1ull << 31) || (size_t)N * ldw >= (1ull << 31)) {
+        vly_set_error("vly_gemm_bf16: operand exceeds 2^31 elements (32-bit byte offsets)");
+        return -22;
+    }
+    if (epilogue == VLY_EPI_SWIGLU && residual) { vly_set_error("vly_gemm_bf16: SWIGLU takes no residual"); return -22; }
+    hipStream_t st = (hipStream_t)stream;
+    const int t = tile_hint ? tile_hint : pick_tile(M, N);
+    return run_tile(t, tile_hint, A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, nullptr);
+}
+
+extern "C" int vly_gemm_bf16_splitk2(const void* A, const void* W, const float* bias, void* C0, void* C1, int M, int N, int K,
+                                     int lda, int ldw, int ldc, int tile_hint, void* stream) {
+    if (M <= 0 || N <= 0 || K < 2 * BK || K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || !C0 || !C1 || C0 == C1 ||
+        ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C0 & 7) || ((uintptr_t)C1 & 7) || (bias && ((uintptr_t)bias & 15))) {
+        vly_set_error("vly_gemm_bf16_splitk2: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
+        return -22;
+    }
+    if ((size_t)M * lda >= (1ull << 31) || (size_t)N * ldw >= (1ull << 31)) {
+        vly_set_error("vly_gemm_bf16_splitk2: operand exceeds 2^31 elements (32-bit byte offsets)");
+        return -22;
+    }
+    const int t = tile_hint ? tile_hint : 8;
+    return run_tile(t, tile_hint, A, W, bias, nullptr, C0, M, N, K, lda, ldw, ldc, 0, VLY_EPI_NONE, VLY_OUT_BF16,
+                    (hipStream_t)stream, C1);
 }

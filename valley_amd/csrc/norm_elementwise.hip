@@ -19,7 +19,7 @@ constexpr int ROWS_PER_BLOCK = 2;           // 2 waves per block, one row each (
 // streaming norm kernel (5-6 TB/s) instead of the GEMM epilogue (64-byte row pieces, exposed).
 template <int NV, bool RMS, bool ADD>
 __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const uint16_t* __restrict__ delta,
-                                                   const float* __restrict__ gamma,
+                                                   const uint16_t* __restrict__ delta2, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, uint16_t* __restrict__ y16,
                                                    float* __restrict__ y32, int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -38,6 +38,11 @@ __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const 
                 const u32x2 dk = *(const u32x2*)(delta + (size_t)row * D + 4 * c);
                 v[i].x += __uint_as_float(dk[0] << 16); v[i].y += __uint_as_float(dk[0] & 0xffff0000u);
                 v[i].z += __uint_as_float(dk[1] << 16); v[i].w += __uint_as_float(dk[1] & 0xffff0000u);
+                if (delta2) {                                   // second split-K partial of the sub-layer GEMM
+                    const u32x2 d2 = *(const u32x2*)(delta2 + (size_t)row * D + 4 * c);
+                    v[i].x += __uint_as_float(d2[0] << 16); v[i].y += __uint_as_float(d2[0] & 0xffff0000u);
+                    v[i].z += __uint_as_float(d2[1] << 16); v[i].w += __uint_as_float(d2[1] & 0xffff0000u);
+                }
                 xr[c] = v[i];
             }
         }
@@ -92,7 +97,7 @@ __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const 
 // of queued in one; block reduction through LDS.  Same ADD semantics as norm_kernel.
 template <bool RMS, bool ADD>
 __global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, const uint16_t* __restrict__ delta,
-                                                       const float* __restrict__ gamma,
+                                                       const uint16_t* __restrict__ delta2, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, uint16_t* __restrict__ y16,
                                                        float* __restrict__ y32, int D, float eps) {
     __shared__ float red[8];
@@ -111,6 +116,11 @@ __global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, co
                 const u32x2 dk = *(const u32x2*)(delta + (size_t)row * D + 4 * c);
                 v[i].x += __uint_as_float(dk[0] << 16); v[i].y += __uint_as_float(dk[0] & 0xffff0000u);
                 v[i].z += __uint_as_float(dk[1] << 16); v[i].w += __uint_as_float(dk[1] & 0xffff0000u);
+                if (delta2) {
+                    const u32x2 d2 = *(const u32x2*)(delta2 + (size_t)row * D + 4 * c);
+                    v[i].x += __uint_as_float(d2[0] << 16); v[i].y += __uint_as_float(d2[0] & 0xffff0000u);
+                    v[i].z += __uint_as_float(d2[1] << 16); v[i].w += __uint_as_float(d2[1] & 0xffff0000u);
+                }
                 xr[c] = v[i];
             }
         }
@@ -167,8 +177,8 @@ __global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, co
 
 template <bool RMS>
 int launch_norm(const float* x, const void* delta, const float* gamma, const float* beta, void* y16, float* y32, int M, int D,
-                float eps, hipStream_t st, const char* name) {
-    if (M <= 0 || D <= 0 || D % 4 || D > 8192 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)delta & 7) ||
+                float eps, hipStream_t st, const char* name, const void* delta2 = nullptr) {
+    if (M <= 0 || D <= 0 || D % 4 || D > 8192 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)delta & 7) || ((uintptr_t)delta2 & 7) ||
         (beta && ((uintptr_t)beta & 15)) || ((uintptr_t)y16 & 7) || ((uintptr_t)y32 & 15)) {
         vly_set_error("%s: unsupported shape/alignment M=%d D=%d", name, M, D);
         return -22;
@@ -177,9 +187,9 @@ int launch_norm(const float* x, const void* delta, const float* gamma, const flo
     // Llama residual stream at M = B*S ~ 1-3 k rows of 16-20 KB: 5 waves per CU could not cover HBM latency)
     if (M <= 64 || (D >= 2048 && M <= 4096)) {
         if (delta) hipLaunchKernelGGL((norm_row_kernel<RMS, true>), dim3(M), dim3(256), 0, st, (float*)x, (const uint16_t*)delta,
-                                      gamma, beta, (uint16_t*)y16, y32, D, eps);
+                                      (const uint16_t*)delta2, gamma, beta, (uint16_t*)y16, y32, D, eps);
         else hipLaunchKernelGGL((norm_row_kernel<RMS, false>), dim3(M), dim3(256), 0, st, (float*)x, (const uint16_t*)nullptr,
-                                gamma, beta, (uint16_t*)y16, y32, D, eps);
+                                (const uint16_t*)nullptr, gamma, beta, (uint16_t*)y16, y32, D, eps);
         return vly_check_launch(name);
     }
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
@@ -187,9 +197,9 @@ int launch_norm(const float* x, const void* delta, const float* gamma, const flo
 #define VLY_NORM(NV)                                                                                              \
     do {                                                                                                          \
         if (delta) hipLaunchKernelGGL((norm_kernel<NV, RMS, true>), grid, block, 0, st, (float*)x, (const uint16_t*)delta, \
-                                      gamma, beta, (uint16_t*)y16, y32, M, D, eps);                               \
+                                      (const uint16_t*)delta2, gamma, beta, (uint16_t*)y16, y32, M, D, eps);      \
         else hipLaunchKernelGGL((norm_kernel<NV, RMS, false>), grid, block, 0, st, (float*)x, (const uint16_t*)nullptr,   \
-                                gamma, beta, (uint16_t*)y16, y32, M, D, eps);                                     \
+                                (const uint16_t*)nullptr, gamma, beta, (uint16_t*)y16, y32, M, D, eps);           \
     } while (0)
     if (nv <= 4) VLY_NORM(4);
     else if (nv <= 8) VLY_NORM(8);
@@ -549,6 +559,13 @@ extern "C" int vly_rope_kv(void* qkv, void* kcache, void* vcache, const float* c
     hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)((units * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, B, S, heads, past_len, past_len_dev, ctx_max);
     return vly_check_launch("vly_rope_kv");
+}
+
+extern "C" int vly_add2_rmsnorm(float* h, const void* delta0_bf16, const void* delta1_bf16, const float* gamma, void* y_bf16,
+                                int M, int D, float eps, void* stream) {
+    if (!delta0_bf16 || !delta1_bf16) { vly_set_error("vly_add2_rmsnorm: two deltas required"); return -22; }
+    return launch_norm<true>(h, delta0_bf16, gamma, nullptr, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_add2_rmsnorm",
+                             delta1_bf16);
 }
 
 extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, int ld, void* stream) {

@@ -42,6 +42,8 @@ _SIGS = {
     "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_decode_attention": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "vly_gemm_bf16_splitk2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_add2_rmsnorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
 }

@@ -128,7 +128,7 @@ class HipLlama:
             d, bf = self.device, torch.bfloat16
             ws = dict(x=torch.empty((M, self.H), dtype=bf, device=d), qkv=torch.empty((M, 3 * self.H), dtype=bf, device=d),
                       att=torch.empty((M, self.H), dtype=bf, device=d), mlp=torch.empty((M, self.I), dtype=bf, device=d),
-                      delta=torch.empty((M, self.H), dtype=bf, device=d))
+                      delta=torch.empty((M, self.H), dtype=bf, device=d), delta2=torch.empty((M, self.H), dtype=bf, device=d))
             if len(self._ws) > 8:
                 self._ws.clear()
             self._ws[key] = ws
@@ -153,10 +153,11 @@ class HipLlama:
         kv = cache.key_valid                                # uint8 [B, ctx_max] or None (row stride = ctx_max)
         nl = self.L if n_layers is None else n_layers
         fused = M > 8            # prefill: residual adds ride on the norm kernels; decode keeps the GEMV epilogue
+        d2 = None                  # second split-K partial of the pending sub-layer output (ops.gemm2), if any
         for li in range(nl):
             L = self.layers[li]
             if fused and li > 0:
-                ops.add_norm(h, ws["delta"], L["ln1"], None, self.eps, out=ws["x"], rms=True)
+                ops.add_norm(h, ws["delta"], L["ln1"], None, self.eps, out=ws["x"], rms=True, delta2=d2)
             else:
                 ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
             ops.gemm(ws["x"], L["w_qkv"], out=ws["qkv"])
@@ -167,19 +168,21 @@ class HipLlama:
                 ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
                 ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
             if fused:
-                ops.gemm(ws["att"], L["w_o"], out=ws["delta"])
-                ops.add_norm(h, ws["delta"], L["ln2"], None, self.eps, out=ws["x"], rms=True)
+                # o_proj / down_proj have fewer output tiles than the chip has CUs at prefill sizes: the tuner may
+                # answer with a split-K pair whose two bf16 partials the add+norm kernel sums
+                d2 = ws["delta2"] if ops.gemm2(ws["att"], L["w_o"], ws["delta"], ws["delta2"]) == 2 else None
+                ops.add_norm(h, ws["delta"], L["ln2"], None, self.eps, out=ws["x"], rms=True, delta2=d2)
             else:
                 ops.gemm(ws["att"], L["w_o"], residual=h, out=h)
                 ops.rmsnorm(h, L["ln2"], self.eps, out=ws["x"])
             ops.gemm(ws["x"], L["w_gu"], epilogue=ops.EPI_SWIGLU, out=ws["mlp"])
             if fused:
-                ops.gemm(ws["mlp"], L["w_down"], out=ws["delta"])
+                d2 = ws["delta2"] if ops.gemm2(ws["mlp"], L["w_down"], ws["delta"], ws["delta2"]) == 2 else None
             else:
                 ops.gemm(ws["mlp"], L["w_down"], residual=h, out=h)
         cache.seq_len = past + S
         if fused and nl > 0:
-            return ops.add_norm(h, ws["delta"], self.norm, None, self.eps, out=ws["x"], rms=True)
+            return ops.add_norm(h, ws["delta"], self.norm, None, self.eps, out=ws["x"], rms=True, delta2=d2)
         return ops.rmsnorm(h, self.norm, self.eps, out=ws["x"])
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:

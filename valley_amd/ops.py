@@ -201,10 +201,68 @@ def tuning_pending() -> int:
     return len(_ONLINE)
 
 
-def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out):
+def gemm_mfma_splitk2(a, w, bias, out, out2, tile_hint=0):
+    """One launch, two bf16 partial products: out = a[:, :K/2] @ w[:, :K/2]^T + bias, out2 = the other half of K."""
+    _chk(a, torch.bfloat16, "a", contiguous=False)
+    _chk(w, torch.bfloat16, "w")
+    _chk(out, torch.bfloat16, "out", contiguous=False)
+    _chk(out2, torch.bfloat16, "out2", contiguous=False)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and tuple(out.shape) == (M, N) == tuple(out2.shape) and out.stride() == out2.stride()
+    rec = _RECORDER
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.load().vly_gemm_bf16_splitk2(a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), out2.data_ptr(), M, N, K,
+                                           a.stride(0), w.stride(0), out.stride(0), tile_hint, _stream())
+    if rec is not None:
+        e1.record()
+        t = tile_hint or 8
+        loop = ({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[t // 10] if t not in TILE_SPECIAL else TILE_SPECIAL[t][1]
+        nm = TILE_SPECIAL[t][0] if t in TILE_SPECIAL else TILE_NAMES[t % 10]
+        rec.append((f"gemm_kernel<{nm}, 0, 0, {loop}>", 2.0 * M * N * K, e0, e1, (M, N, K, EPI_PAIR)))
+    _lib.check(rc, "vly_gemm_bf16_splitk2")
+    return out
+
+
+EPI_PAIR = 100       # tuner key marker: plain GEMM whose consumer accepts two bf16 partials (gemm2)
+SPLIT_CANDIDATES = [("tile2k", t) for t in (2, 6, 7, 8, 76, 84, 86)]
+
+
+def gemm2(a, w, out, out2, bias=None) -> int:
+    """out (+ out2) = a @ w^T (+ bias) for a consumer that adds two bf16 partials (add_norm(..., delta2=)): the tuner
+    may pick a split-K-by-two launch (returns 2: both buffers hold partial sums) or any ordinary kernel (returns 1:
+    out holds the product, out2 is untouched).  For projections with fewer output tiles than CUs."""
+    _chk(a, torch.bfloat16, "a", contiguous=False)
+    M = a.shape[0]
+    if M <= 8 or GEMM_MODE in ("tiles", "streamk") or torch.cuda.is_current_stream_capturing():
+        gemm(a, w, bias, out=out)
+        return 1
+    N, K = w.shape
+    key = (M, N, K, EPI_PAIR, out.dtype, bias is not None, False)
+    choice = _TUNED.get(key)
+    if choice is None:
+        return _online_trial(key, a, w, bias, None, EPI_NONE, out.dtype, out, out2, CANDIDATES + SPLIT_CANDIDATES)[1]
+    return _run_candidate(choice, a, w, bias, None, EPI_NONE, out.dtype, out, out2)[1]
+
+
+def _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2=None):
+    """-> (result tensor, number of partial outputs)."""
+    kind, t = cand
+    if kind == "tile2k":
+        return gemm_mfma_splitk2(a, w, bias, out, out2, t), 2
+    if kind == "tile":
+        return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t), 1
+    return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, t), 1
+
+
+def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out, out2=None, candidates=None):
+    """One call while `key` is undecided; returns (result, number of partial outputs)."""
     st = _ONLINE.get(key)
     if st is None:
-        st = _ONLINE[key] = {"cands": list(CANDIDATES), "times": {c: [] for c in CANDIDATES}, "pending": [],
+        cl = list(candidates if candidates is not None else CANDIDATES)
+        st = _ONLINE[key] = {"cands": cl, "times": {c: [] for c in cl}, "pending": [],
                              "need": TUNE_TRIALS, "final": False}
     still = []
     for c, e0, e1 in st["pending"]:                       # harvest finished trials without blocking
@@ -239,11 +297,10 @@ def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out):
                 save_tune_cache(_TUNE_CACHE)
             cand = best
             break
-        fn = gemm_mfma if cand[0] == "tile" else gemm_streamk
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         try:
-            res = fn(a, w, bias, residual, epilogue, out_dtype, out, cand[1])
+            res = _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2)
         except _lib.ValleyHipError:                       # configuration not available for this shape
             st["cands"].remove(cand)
             del st["times"][cand]
@@ -253,8 +310,7 @@ def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out):
         return res
     else:
         raise _lib.ValleyHipError("gemm: no kernel configuration accepts this problem")
-    fn = gemm_mfma if cand[0] == "tile" else gemm_streamk
-    return fn(a, w, bias, residual, epilogue, out_dtype, out, cand[1])
+    return _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2)
 
 
 def _tune(key, a, w, bias, residual, epilogue, out):
@@ -316,7 +372,7 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
             finally:
                 set_recorder(rec)
         else:
-            return _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out)
+            return _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out)[0]
     kind, t = choice
     if kind == "tile":
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t)
@@ -347,8 +403,9 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: Optional[torc
 
 
 def add_norm(h: torch.Tensor, delta: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
-             out: Optional[torch.Tensor] = None, rms: bool = False) -> Optional[torch.Tensor]:
-    """h (fp32, in place) += delta (bf16); returns norm(h) as bf16 (None when gamma is None: add only)."""
+             out: Optional[torch.Tensor] = None, rms: bool = False, delta2: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """h (fp32, in place) += delta (bf16) [+ delta2: the second split-K partial of gemm2]; returns norm(h) as bf16
+    (None when gamma is None: add only)."""
     _chk(h, torch.float32, "h")
     _chk(delta, torch.bfloat16, "delta")
     M, D = h.shape
@@ -357,6 +414,12 @@ def add_norm(h: torch.Tensor, delta: torch.Tensor, gamma: Optional[torch.Tensor]
     if gamma is not None:
         y = out if out is not None else torch.empty((M, D), dtype=torch.bfloat16, device=h.device)
     L = _lib.load()
+    if delta2 is not None:
+        _chk(delta2, torch.bfloat16, "delta2")
+        assert rms and tuple(delta2.shape) == (M, D)
+        rc = L.vly_add2_rmsnorm(h.data_ptr(), delta.data_ptr(), delta2.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())
+        _lib.check(rc, "vly_add2_rmsnorm")
+        return y
     if rms:
         rc = L.vly_add_rmsnorm(h.data_ptr(), delta.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())
     else:
