@@ -167,6 +167,9 @@ int vly_embed_splice(const int32_t *row_map, const void *embed_bf16, const void 
 /* vly_add_rmsnorm with two bf16 deltas (the split-K partials of vly_gemm_bf16_splitk2): h += d0 + d1; y = rmsnorm(h). */
 int vly_add2_rmsnorm(float *h, const void *delta0_bf16, const void *delta1_bf16, const float *gamma, void *y_bf16,
                      int M, int D, float eps, void *stream);
+/* vly_add_layernorm with two bf16 deltas (CLIP out_proj / fc2 split-K partials); gamma NULL = add only. */
+int vly_add2_layernorm(float *h, const void *delta0_bf16, const void *delta1_bf16, const float *gamma, const float *beta,
+                       void *y_bf16, int M, int D, float eps, void *stream);
 
 /* RoPE (rotate-half) on q and k of a fused qkv buffer + KV-cache append:
  *   qkv bf16 [B*S, 3*heads*128]; q rotated in place; rotated k and v written to

@@ -345,6 +345,13 @@ def test_gemm_splitk2_and_add2_rmsnorm(M, N, K, tile):
         ref = g * (hs * torch.rsqrt((hs * hs).mean(-1, keepdim=True) + 1e-5))
         assert maxabs(h2, hs) < 1e-5
         assert relerr(y2, ref) < 5e-3
+        be = rnd((D,), 76, 0.1).to(dev())                  # the CLIP form: two deltas + LayerNorm, and add-only
+        h3 = h.clone()
+        y3 = ops.add_norm(h3, o0, g, be, 1e-5, delta2=o1)
+        assert maxabs(h3, hs) < 1e-5
+        assert relerr(y3, torch.nn.functional.layer_norm(hs, (D,), g, be, 1e-5)) < 5e-3
+        h4 = h.clone()
+        assert ops.add_norm(h4, o0, None, None, 1e-5, delta2=o1) is None and maxabs(h4, hs) < 1e-5
 
 
 def test_c_abi_smoke_binary():

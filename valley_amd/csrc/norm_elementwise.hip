@@ -568,6 +568,15 @@ extern "C" int vly_add2_rmsnorm(float* h, const void* delta0_bf16, const void* d
                              delta1_bf16);
 }
 
+extern "C" int vly_add2_layernorm(float* h, const void* delta0_bf16, const void* delta1_bf16, const float* gamma,
+                                  const float* beta, void* y_bf16, int M, int D, float eps, void* stream) {
+    if (!delta0_bf16 || !delta1_bf16 || (gamma && !beta)) {
+        vly_set_error("vly_add2_layernorm: two deltas (and beta with gamma) required"); return -22;
+    }
+    return launch_norm<false>(h, delta0_bf16, gamma, beta, y_bf16, nullptr, M, D, eps, (hipStream_t)stream, "vly_add2_layernorm",
+                              delta1_bf16);
+}
+
 extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, int ld, void* stream) {
     if (M <= 0 || N <= 0 || ld < N) { vly_set_error("vly_argmax: bad args"); return -22; }
     hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, x, idx, N, ld);

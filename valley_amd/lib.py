@@ -44,6 +44,7 @@ _SIGS = {
     "vly_decode_attention": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_gemm_bf16_splitk2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_add2_rmsnorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "vly_add2_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
 }

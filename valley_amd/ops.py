@@ -416,9 +416,13 @@ def add_norm(h: torch.Tensor, delta: torch.Tensor, gamma: Optional[torch.Tensor]
     L = _lib.load()
     if delta2 is not None:
         _chk(delta2, torch.bfloat16, "delta2")
-        assert rms and tuple(delta2.shape) == (M, D)
-        rc = L.vly_add2_rmsnorm(h.data_ptr(), delta.data_ptr(), delta2.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())
-        _lib.check(rc, "vly_add2_rmsnorm")
+        assert tuple(delta2.shape) == (M, D)
+        if rms:
+            rc = L.vly_add2_rmsnorm(h.data_ptr(), delta.data_ptr(), delta2.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())
+        else:
+            rc = L.vly_add2_layernorm(h.data_ptr(), delta.data_ptr(), delta2.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(y), M, D,
+                                      eps, _stream())
+        _lib.check(rc, "vly_add2_norm")
         return y
     if rms:
         rc = L.vly_add_rmsnorm(h.data_ptr(), delta.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())

@@ -131,6 +131,7 @@ class HipCLIPVisionTower:
                       qkv=torch.empty((M, 3072), dtype=torch.bfloat16, device=d),
                       att=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
                       delta=torch.empty((M, 1024), dtype=torch.bfloat16, device=d),
+                      delta2=torch.empty((M, 1024), dtype=torch.bfloat16, device=d), split=False,
                       mlp=torch.empty((M, I), dtype=torch.bfloat16, device=d))
             if len(self._ws) > 6:
                 self._ws.clear()
@@ -159,18 +160,20 @@ class HipCLIPVisionTower:
         output, to be added by the next layer's first norm — or by the caller (``nxt`` is None)."""
         ws = self._workspace(F)
         eps = self.config.layer_norm_eps
+        d2 = ws["delta2"] if pending and ws["split"] else None           # previous fc2 came as two split-K partials
         if pending:
-            ops.add_norm(h, ws["delta"], L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
+            ops.add_norm(h, ws["delta"], L["ln1_g"], L["ln1_b"], eps, out=ws["x"], delta2=d2)
         else:
             ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
         ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
-        ops.gemm(ws["att"], L["w_o"], L["b_o"], out=ws["delta"])
-        ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"])
+        d2 = ws["delta2"] if ops.gemm2(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
+        ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"], delta2=d2)
         ops.gemm(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
-        ops.gemm(ws["mlp"], L["w_fc2"], L["b_fc2"], out=ws["delta"])
+        ws["split"] = ops.gemm2(ws["mlp"], L["w_fc2"], ws["delta"], ws["delta2"], L["b_fc2"]) == 2
         if nxt is None:
-            ops.add_norm(h, ws["delta"], None, None, eps)               # last residual update of the stack
+            ops.add_norm(h, ws["delta"], None, None, eps,                # last residual update of the stack
+                         delta2=ws["delta2"] if ws["split"] else None)
 
     def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: int = 256,
                keep_all: bool = False):
