@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""In-process A/B of GEMM kernels from several builds of libvalley_hip.so (cdna_hip_programming: any claim < 5 %
+needs an interleaved A/B inside one probe).
+
+  build (CPU):  python tools/ab_lib.py build NAME -DVLY_FRAG_ORDER=1 ...   -> valley_amd/lib/variants/libvalley_hip_NAME.so
+  run   (GPU):  python tools/ab_lib.py run base,NAME[,NAME2] [shape ...]
+
+A shape is M,N,K,epi,tile ("1312,22016,4096,2,8"); defaults = the hot-path shapes with their shipped tiles.  Every
+library is called through the C ABI directly (ctypes), round-robin per repetition, on operands that rotate through
+four weight copies (every call reads weights that left the Infinity Cache) with a rotating order of the libraries;
+every library's result on the same operands is checked against the first library's.
+"""
+import ctypes
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARDIR = os.path.join(ROOT, "valley_amd", "lib", "variants")
+
+DEFAULT_SHAPES = ["1312,22016,4096,2,8", "1312,12288,4096,0,86", "8224,4096,1024,1,8", "8224,3072,1024,0,9",
+                  "2688,27648,5120,2,9", "1312,4096,11008,0,7", "1312,12288,4096,0,76"]
+
+
+def build(name, flags):
+    from valley_amd import build as b
+    os.makedirs(VARDIR, exist_ok=True)
+    b.build(verbose=False)
+    obj = os.path.join(VARDIR, f"gemm_bf16_{name}.o")
+    subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c",
+                           os.path.join(b.CSRC, "gemm_bf16.hip"), "-o", obj])
+    objs = [obj if s == "gemm_bf16.hip" else os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES]
+    out = os.path.join(VARDIR, f"libvalley_hip_{name}.so")
+    subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    print(out)
+
+
+def run(names, shapes, reps=40):
+    import torch
+    from valley_amd import build as b
+    P, I = ctypes.c_void_p, ctypes.c_int
+    libs = []
+    for n in names:
+        L = ctypes.CDLL(b.LIB if n == "base" else os.path.join(VARDIR, f"libvalley_hip_{n}.so"))
+        L.vly_gemm_bf16.restype = I
+        L.vly_gemm_bf16.argtypes = [P] * 5 + [I] * 10 + [P]
+        libs.append(L)
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for sh in shapes:
+        M, N, K, epi, tile = (int(x) for x in sh.split(","))
+        a = torch.randn((M, K), device=d).to(torch.bfloat16)
+        ws = [(torch.randn((N, K), device=d) * 0.05).to(torch.bfloat16) for _ in range(4)]
+        No = N // 2 if epi == 2 else N
+        outs = [torch.empty((M, No), device=d, dtype=torch.bfloat16) for _ in libs]
+        times = [[] for _ in libs]
+        call = 0
+        for r in range(reps + 3):
+            for li in [(r + i) % len(libs) for i in range(len(libs))]:     # rotate who goes first
+                L = libs[li]
+                w = ws[call % 4]                                           # last touched four calls ago: out of the MALL
+                call += 1
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.vly_gemm_bf16(a.data_ptr(), w.data_ptr(), None, None, outs[li].data_ptr(), M, N, K, K, K, No, 0, epi,
+                                     0, tile, st)
+                e1.record()
+                assert rc == 0, (names[li], rc)
+                torch.cuda.synchronize()
+                if r >= 3:
+                    times[li].append(e0.elapsed_time(e1) * 1e3)
+        for li, L in enumerate(libs):                                      # same operands: same result
+            rc = L.vly_gemm_bf16(a.data_ptr(), ws[0].data_ptr(), None, None, outs[li].data_ptr(), M, N, K, K, K, No, 0, epi, 0,
+                                 tile, st)
+            assert rc == 0
+        torch.cuda.synchronize()
+        for li in range(1, len(libs)):
+            err = float((outs[li].float() - outs[0].float()).norm() / outs[0].float().norm())
+            assert err < 2e-3, (names[li], sh, err)
+        fl = 2.0 * M * N * K
+        row = {"shape": sh}
+        for n, t in zip(names, times):
+            med = statistics.median(t)
+            row[n] = {"us": round(med, 1), "TFLOPs": round(fl / med / 1e6, 1), "min_us": round(min(t), 1)}
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2], sys.argv[3:])
+    else:
+        run(sys.argv[2].split(","), sys.argv[3:] or DEFAULT_SHAPES)

@@ -32,6 +32,91 @@ namespace {
 
 constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 chunks of 16 B
 
+// One K tile (BK = 64 = two MFMA K steps) of a wave's MI x NI fragments from a 128-byte-row LDS stage.
+// VLY_FRAG_ORDER (kept switchable for tools/ab_lib.py A/B builds):
+//   0  reads and MFMAs in source order, scheduled by the compiler — it settles on {2 reads, lgkmcnt(0), 4 MFMAs} x 6
+//      per K tile: six exposed LDS round trips per wave and K tile;
+//   1  all reads of a K step, then its MFMAs: two exposed round trips;
+//   2  the reads of both K steps first: one round trip but 64 fragment VGPRs (the 2-per-CU tiles lose their second
+//      workgroup, the 16-wave tile spills);
+//   3  (default) K step 1's fragments are requested BETWEEN K step 0's MFMAs, each into the registers the finished
+//      MFMAs freed: one exposed round trip, +8..11 VGPRs.  Interleaved A/B against 0 on cold weights (tools/ab_lib.py):
+//      +1.0..2.7 % on the 2-stage loops, +5.9 % on the 3-stage 192x192 loop; 1 is within noise of 0.
+#ifndef VLY_FRAG_ORDER
+#define VLY_FRAG_ORDER 3
+#endif
+template <int MI, int NI>
+VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, int sw0, int sw1) {
+#if VLY_FRAG_ORDER == 3
+    bf16x8 a0[MI], w0[NI], a1[MI], w1[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) w0[j] = *(const bf16x8*)(pw + j * 2048 + sw0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(pa + i * 2048 + sw0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(w0[j], a0[i], acc[i][j]);
+        if (i == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) w1[j] = *(const bf16x8*)(pw + j * 2048 + sw1);
+        }
+        a1[i] = *(const bf16x8*)(pa + i * 2048 + sw1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(w1[j], a1[i], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+#elif VLY_FRAG_ORDER == 2
+    bf16x8 af[2][MI], wf[2][NI];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = kk ? sw1 : sw0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) wf[kk][j] = *(const bf16x8*)(pw + j * 2048 + sw);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[kk][i] = *(const bf16x8*)(pa + i * 2048 + sw);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[kk][j], af[kk][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = kk ? sw1 : sw0;
+        bf16x8 af[MI], wf[NI];
+#if VLY_FRAG_ORDER == 1
+#pragma unroll
+        for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(pw + j * 2048 + sw);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(pa + i * 2048 + sw);
+        __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(pa + i * 2048 + sw);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(pw + j * 2048 + sw);
+#endif
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+#if VLY_FRAG_ORDER == 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#endif
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
@@ -120,19 +205,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sW = sA + A_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int sw = kk ? sw1 : sw0;
-                bf16x8 af[MI], wf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + rdA + i * 2048 + sw);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(sW + rdW + j * 2048 + sw);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-            }
+            mma_ktile<MI, NI>(acc, sA + rdA, sW + rdW, sw0, sw1);
         }
     } else if constexpr (PIPE == 3) {
         // ================= role-split half-tile pipeline (8 waves) ==========================================
@@ -318,19 +391,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);                           // (kt+2) % 3
             const char* cur = smem + buf * STAGE;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int sw = kk ? sw1 : sw0;
-                bf16x8 af[MI], wf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-            }
+            mma_ktile<MI, NI>(acc, cur + rdA, cur + rdW, sw0, sw1);
             buf = buf == 2 ? 0 : buf + 1;
         }
     } else if constexpr (PIPE == 7) {
