@@ -5,9 +5,10 @@ needs an interleaved A/B inside one probe).
   build (CPU):  python tools/ab_lib.py build NAME -DVLY_FRAG_ORDER=1 ...   -> valley_amd/lib/variants/libvalley_hip_NAME.so
   run   (GPU):  python tools/ab_lib.py run base,NAME[,NAME2] [shape ...]
 
-A shape is M,N,K,epi,tile ("1312,22016,4096,2,8"); defaults = the hot-path shapes with their shipped tiles.  Every
+A shape is M,N,K,epi,tile[|tile...] ("1312,22016,4096,2,8|105"); every (library, tile) pair is an arm; defaults = the
+hot-path shapes with their shipped tiles.  Every
 library is called through the C ABI directly (ctypes), round-robin per repetition, on operands that rotate through
-four weight copies (every call reads weights that left the Infinity Cache) with a rotating order of the libraries;
+four weight copies (every call reads weights that left the Infinity Cache), arms in a fresh random order per repetition;
 every library's result on the same operands is checked against the first library's.
 """
 import ctypes
@@ -50,41 +51,54 @@ def run(names, shapes, reps=40):
         libs.append(L)
     d = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
+    import random
+    rng = random.Random(0)
     for sh in shapes:
-        M, N, K, epi, tile = (int(x) for x in sh.split(","))
+        M, N, K, epi, tiles = sh.split(",")
+        M, N, K, epi = int(M), int(N), int(K), int(epi)
+        arms = [(li, int(t)) for li in range(len(libs)) for t in tiles.split("|")]      # an arm = (library, tile hint)
         a = torch.randn((M, K), device=d).to(torch.bfloat16)
         ws = [(torch.randn((N, K), device=d) * 0.05).to(torch.bfloat16) for _ in range(4)]
+        # libraries named packed*: built with -DVLY_W_PACKED=1, weights as [K/64][N/64][64][64] blocks
+        wp = [w.view(N // 64, 64, K // 64, 64).permute(2, 0, 1, 3).contiguous() for w in ws] \
+            if any(n.startswith("packed") for n in names) and N % 64 == 0 else None
         No = N // 2 if epi == 2 else N
-        outs = [torch.empty((M, No), device=d, dtype=torch.bfloat16) for _ in libs]
-        times = [[] for _ in libs]
-        call = 0
+        outs = [torch.empty((M, No), device=d, dtype=torch.bfloat16) for _ in arms]
+        times = [[] for _ in arms]
+
+        def call(ai, wi):
+            li, t = arms[ai]
+            w = wp[wi] if names[li].startswith("packed") else ws[wi]
+            rc = libs[li].vly_gemm_bf16(a.data_ptr(), w.data_ptr(), None, None, outs[ai].data_ptr(), M, N, K, K, K, No, 0, epi,
+                                        0, t, st)
+            assert rc == 0, (names[li], t, rc)
+
+        for ai in range(len(arms)):                                        # same operands: same result
+            call(ai, 0)
+        torch.cuda.synchronize()
+        for ai in range(1, len(arms)):
+            err = float((outs[ai].float() - outs[0].float()).norm() / outs[0].float().norm())
+            assert err < 2e-3, (names[arms[ai][0]], arms[ai][1], sh, err)
+        ncall = 0
         for r in range(reps + 3):
-            for li in [(r + i) % len(libs) for i in range(len(libs))]:     # rotate who goes first
-                L = libs[li]
-                w = ws[call % 4]                                           # last touched four calls ago: out of the MALL
-                call += 1
+            order = list(range(len(arms)))
+            rng.shuffle(order)                                             # no arm keeps the same predecessor
+            for ai in order:
+                wi = ncall % 4                                             # last touched >= 4 calls ago: out of the MALL
+                ncall += 1
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rc = L.vly_gemm_bf16(a.data_ptr(), w.data_ptr(), None, None, outs[li].data_ptr(), M, N, K, K, K, No, 0, epi,
-                                     0, tile, st)
+                call(ai, wi)
                 e1.record()
-                assert rc == 0, (names[li], rc)
                 torch.cuda.synchronize()
                 if r >= 3:
-                    times[li].append(e0.elapsed_time(e1) * 1e3)
-        for li, L in enumerate(libs):                                      # same operands: same result
-            rc = L.vly_gemm_bf16(a.data_ptr(), ws[0].data_ptr(), None, None, outs[li].data_ptr(), M, N, K, K, K, No, 0, epi, 0,
-                                 tile, st)
-            assert rc == 0
-        torch.cuda.synchronize()
-        for li in range(1, len(libs)):
-            err = float((outs[li].float() - outs[0].float()).norm() / outs[0].float().norm())
-            assert err < 2e-3, (names[li], sh, err)
+                    times[ai].append(e0.elapsed_time(e1) * 1e3)
         fl = 2.0 * M * N * K
-        row = {"shape": sh}
-        for n, t in zip(names, times):
-            med = statistics.median(t)
-            row[n] = {"us": round(med, 1), "TFLOPs": round(fl / med / 1e6, 1), "min_us": round(min(t), 1)}
+        row = {"shape": f"{M}x{N}x{K}/e{epi}"}
+        base = statistics.median(times[0])
+        for (li, t), tm in zip(arms, times):
+            med = statistics.median(tm)
+            row[f"{names[li]}:{t}"] = f"{med:.1f}us {fl / med / 1e6:.0f}TF {100 * (base / med - 1):+.1f}%"
         print(json.dumps(row), flush=True)
 
 

@@ -63,6 +63,13 @@ VLY_DEVICE void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same with a cache-policy immediate (gfx942+: 1 = sc0, 2 = nt, 16 = sc1) — for A/B builds of the staging loads
+template <int CPOL>
+VLY_DEVICE void glds16_cp(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, CPOL);
+}
+
 void vly_set_error(const char* fmt, ...);
 int vly_check_launch(const char* what);
 int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n);

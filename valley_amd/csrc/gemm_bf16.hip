@@ -42,6 +42,21 @@ constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 c
 //   3  (default) K step 1's fragments are requested BETWEEN K step 0's MFMAs, each into the registers the finished
 //      MFMAs freed: one exposed round trip, +8..11 VGPRs.  Interleaved A/B against 0 on cold weights (tools/ab_lib.py):
 //      +1.0..2.7 % on the 2-stage loops, +5.9 % on the 3-stage 192x192 loop; 1 is within noise of 0.
+#ifndef VLY_A_CPOL
+#define VLY_A_CPOL 0      // cache policy of the activation / weight staging loads (glds16_cp)
+#endif
+#ifndef VLY_W_CPOL
+#define VLY_W_CPOL 0
+#endif
+#ifndef VLY_MMA_PRIO
+#define VLY_MMA_PRIO 0    // 1: s_setprio 1 over the MFMAs of mma_ktile (the role-split loops always do)
+#endif
+#ifndef VLY_W_PACKED
+#define VLY_W_PACKED 0
+#endif
+VLY_DEVICE uint32_t w_row_off(int n, int ldw) {
+    return VLY_W_PACKED ? (uint32_t)(n >> 6) * 4096u + (uint32_t)(n & 63) * 64u : (uint32_t)n * (uint32_t)ldw;
+}
 #ifndef VLY_FRAG_ORDER
 #define VLY_FRAG_ORDER 3
 #endif
@@ -54,6 +69,7 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 #pragma unroll
     for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(pa + i * 2048 + sw0);
     __builtin_amdgcn_sched_barrier(0);
+    if (VLY_MMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -69,6 +85,7 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(w1[j], a1[i], acc[i][j]);
+    if (VLY_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
 #elif VLY_FRAG_ORDER == 2
     bf16x8 af[2][MI], wf[2][NI];
@@ -166,9 +183,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int nk = K / BK;
+    // VLY_W_PACKED (A/B builds): W is stored [K/64][ceil(N/64)][64 rows][64 k] — every K tile of a weight panel is one
+    // contiguous run in HBM instead of one 128-byte line out of each 2*K-byte row
+    const uint32_t wk = VLY_W_PACKED ? (uint32_t)((N + 63) >> 6) * 4096u : (uint32_t)BK;     // W elements per K tile
     if (ksplit == 2) {
         const int h0 = nk >> 1;
-        if (part) { A += (size_t)h0 * BK; W += (size_t)h0 * BK; nk -= h0; } else nk = h0;
+        if (part) { A += (size_t)h0 * BK; W += (size_t)h0 * wk; nk -= h0; } else nk = h0;
     }
 
     if constexpr (PIPE == 0) {
@@ -184,16 +204,16 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
             const int gr = min(n0 + row, N - 1);
-            offW[p] = (uint32_t)gr * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(gr, ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         // row & 7 == l15 & 7 for every fragment row (all bases are multiples of 16)
         const int rdA = (wm0 + l15) * 128, rdW = (wn0 + l15) * 128;
@@ -241,9 +261,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             char* reg = smem + (p & 3) * REGION;
             const int k0 = p * 32;
 #pragma unroll
-            for (int q = 0; q < PAH; ++q) glds16(A + offA[q] + k0, reg + dstA[q]);
+            for (int q = 0; q < PAH; ++q) glds16_cp<VLY_A_CPOL>(A + offA[q] + k0, reg + dstA[q]);
 #pragma unroll
-            for (int q = 0; q < PWH; ++q) glds16(W + offW[q] + k0, reg + dstW[q]);
+            for (int q = 0; q < PWH; ++q) glds16_cp<VLY_W_CPOL>(W + offW[q] + k0, reg + dstW[q]);
         };
         auto wait_ahead = [&](int ahead) {                       // leave `ahead` half tiles of my loads in flight
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPH) : "memory");
@@ -303,16 +323,16 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
         const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
@@ -367,16 +387,16 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
         const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
@@ -407,16 +427,16 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + k0, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         auto wait_next = [&](int kt) {                              // my loads of tile kt+1 landed; kt+2 may fly
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PA + PW) : "memory");
@@ -497,9 +517,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             char* reg = smem + (p & 3) * REGION;
             const int k0 = p * 32;
 #pragma unroll
-            for (int q = 0; q < PAH; ++q) glds16(A + offA[q] + k0, reg + dstA[q]);
+            for (int q = 0; q < PAH; ++q) glds16_cp<VLY_A_CPOL>(A + offA[q] + k0, reg + dstA[q]);
 #pragma unroll
-            for (int q = 0; q < PWH; ++q) glds16(W + offW[q] + k0, reg + dstW[q]);
+            for (int q = 0; q < PWH; ++q) glds16_cp<VLY_W_CPOL>(W + offW[q] + k0, reg + dstW[q]);
         };
         const int swz = (g ^ ((l15 >> 2) & 2)) << 4;
         const int rdA = (wm0 + l15) * 64 + swz, rdW = HA + (wn0 + l15) * 64 + swz;
