@@ -3,7 +3,9 @@
 needs an interleaved A/B inside one probe).
 
   build (CPU):  python tools/ab_lib.py build NAME -DVLY_FRAG_ORDER=1 ...   -> valley_amd/lib/variants/libvalley_hip_NAME.so
+                python tools/ab_lib.py build NAME --src attention.hip -DVLY_ATTN_ORDER=0
   run   (GPU):  python tools/ab_lib.py run base,NAME[,NAME2] [shape ...]
+                python tools/ab_lib.py run-attn base,NAME [B,S,heads ...]
 
 A shape is M,N,K,epi,tile[|tile...] ("1312,22016,4096,2,8|105"); every (library, tile) pair is an arm; defaults = the
 hot-path shapes with their shipped tiles.  Every
@@ -30,10 +32,13 @@ def build(name, flags):
     from valley_amd import build as b
     os.makedirs(VARDIR, exist_ok=True)
     b.build(verbose=False)
-    obj = os.path.join(VARDIR, f"gemm_bf16_{name}.o")
+    src = "gemm_bf16.hip"
+    if flags and flags[0] == "--src":                       # the one source file the flags apply to
+        src, flags = flags[1], flags[2:]
+    obj = os.path.join(VARDIR, f"{src[:-4]}_{name}.o")
     subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c",
-                           os.path.join(b.CSRC, "gemm_bf16.hip"), "-o", obj])
-    objs = [obj if s == "gemm_bf16.hip" else os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES]
+                           os.path.join(b.CSRC, src), "-o", obj])
+    objs = [obj if s == src else os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES]
     out = os.path.join(VARDIR, f"libvalley_hip_{name}.so")
     subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     print(out)
@@ -102,8 +107,50 @@ def run(names, shapes, reps=40):
         print(json.dumps(row), flush=True)
 
 
+def run_attn(names, shapes, reps=60):
+    """Prefill attention (vly_llama_attention) A/B: shape = B,S,heads."""
+    import random
+    import torch
+    from valley_amd import build as b
+    P, I = ctypes.c_void_p, ctypes.c_int
+    libs = []
+    for n in names:
+        L = ctypes.CDLL(b.LIB if n == "base" else os.path.join(VARDIR, f"libvalley_hip_{n}.so"))
+        L.vly_llama_attention.restype = I
+        L.vly_llama_attention.argtypes = [P, P, P, P, I, P, I, I, I, I, P, I, P]
+        libs.append(L)
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rng = random.Random(0)
+    for sh in shapes:
+        B, S, heads = (int(x) for x in sh.split(","))
+        qkv = torch.randn((B * S, 3 * heads * 128), device=d).to(torch.bfloat16)
+        kc = torch.randn((B, heads, S, 128), device=d).to(torch.bfloat16)
+        vc = torch.randn((B, heads, S, 128), device=d).to(torch.bfloat16)
+        outs = [torch.empty((B * S, heads * 128), device=d, dtype=torch.bfloat16) for _ in libs]
+        times = [[] for _ in libs]
+        for r in range(reps + 3):
+            order = list(range(len(libs)))
+            rng.shuffle(order)
+            for li in order:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = libs[li].vly_llama_attention(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), None, 0, outs[li].data_ptr(), B, S,
+                                                  heads, 0, None, S, st)
+                e1.record()
+                assert rc == 0
+                torch.cuda.synchronize()
+                if r >= 3:
+                    times[li].append(e0.elapsed_time(e1) * 1e3)
+        for li in range(1, len(libs)):
+            assert torch.equal(outs[li], outs[0]), names[li]
+        print(json.dumps({"attn": sh, **{n: round(statistics.median(t), 1) for n, t in zip(names, times)}, "unit": "us"}), flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "run-attn":
+        run_attn(sys.argv[2].split(","), sys.argv[3:] or ["4,328,32", "8,336,40", "8,352,40"])
     else:
         run(sys.argv[2].split(","), sys.argv[3:] or DEFAULT_SHAPES)

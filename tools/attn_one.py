@@ -25,4 +25,13 @@ else:
     for _ in range(8):
         ops.rope_kv(qkv, kc, vc, cos, sin, B, S, heads, 0)
         ops.llama_attention(qkv, kc, vc, None, B, S, heads, 0)
+    ts = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.llama_attention(qkv, kc, vc, None, B, S, heads, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    print(f"llama_attention B={B} S={S} heads={heads}: median {sorted(ts)[len(ts) // 2]:.1f} us, min {min(ts):.1f} us")
 torch.cuda.synchronize()

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 
 // ---------------------------------------------------------------------------------------------
 // Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
-// grid = (ceil(S/(16*LNW)), heads, B); LNW waves x 16 query rows.
+// grid = (heads, B, ceil(S/(16*LNW))), last query block first; LNW waves x 16 query rows.
 // ---------------------------------------------------------------------------------------------
 constexpr int LK_BYTES = 64 * 256;          // K tile: 64 keys x 128 d, 256-byte rows, chunk ^= row & 15
 constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row stride 144 B = 16*9
@@ -189,7 +189,13 @@ __global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // Longest-first dispatch: causal query blocks cost ~(qb + 1) key tiles each, so the grid is (heads, B, blocks) with
+    // the LAST query block in z = 0 — the heavy workgroups start first and the light ones fill the tail (c2: 2 / 4 / 6
+    // key tiles per block, 384 workgroups on 256 CUs: the makespan drops from ~light + heavy to the 6-tile bound).
+#ifndef VLY_ATTN_ORDER
+#define VLY_ATTN_ORDER 1      // 0: first query block first (A/B builds, tools/ab_lib.py)
+#endif
+    const int h = blockIdx.x, b = blockIdx.y, qb = VLY_ATTN_ORDER ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z;
     const int Hq = heads * 128;
     if (past_dev) past = min(*past_dev, ctx_max - S);
     const int kv_len = past + S;
@@ -607,7 +613,7 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
                            past_len_dev, key_valid_stride, ctx_max);
         return vly_check_launch("vly_llama_attention(decode)");
     }
-    hipLaunchKernelGGL(llama_attn_kernel, dim3((S + 16 * LNW - 1) / (16 * LNW), heads, B), dim3(LNW * 64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(llama_attn_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
                        S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
     return vly_check_launch("vly_llama_attention");
