@@ -115,9 +115,12 @@ def main():
                     help="instead of the prefill step: prefill once, then time N greedy hipGraph decode steps (configs[4])")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VALLEY_BENCH_STREAMS", "1")),
                     help="run the batch as this many independent sub-batches on separate HIP streams (tail filling)")
+    ap.add_argument("--pack-weights", type=int, default=int(os.environ.get("VALLEY_PACK_WEIGHTS", "1")), choices=[0, 1],
+                    help="1 (default): the Llama prefill GEMMs read a second, block-ordered copy of the weights (ops.PackedWeight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (rocprof runs)")
     args = ap.parse_args()
+    os.environ["VALLEY_PACK_WEIGHTS"] = str(args.pack_weights)      # read by the engines when they load their weights
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -317,7 +320,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": cfg["label"] + f", S={S}, end-to-end hot path (encode+pool+project+splice+prefill+lm_head)",
                        "name": args.config, "clips_per_gpu": B, "frames_per_clip": T, "prefill_batch_per_gpu": Bp,
-                       "seq_len": S, "tune_passes": tune_passes, "streams": NS, "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},
+                       "seq_len": S, "tune_passes": tune_passes, "streams": NS, "weights": "row-major + packed64" if args.pack_weights else "row-major", "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},
             "stages": {"vit_frames_per_s_per_gpu": round(vit_fps, 1), "vit_ms": round(vit_ms, 3),
                        "vit_TFLOPs": round(vit_tf, 1), "vit_frac_of_bf16_peak": round(vit_tf / PEAK_BF16_TFLOPS, 4),
                        "prefill_tokens_per_s_per_gpu": round(pre_tps, 1), "prefill_ms": round(pre_ms, 3),

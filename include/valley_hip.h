@@ -46,6 +46,9 @@ extern "C" {
 #define VLY_POOL_MAX  1
 #define VLY_POOL_IMPORTANCE 2   /* v2: softmax over frames of Linear(256*H -> 1) scores, weighted sum (:113-121) */
 
+/* ldw value meaning "W is in the block layout of vly_pack_weight_bf16" (vly_gemm_bf16, vly_gemm_bf16_splitk2) */
+#define VLY_LDW_PACKED64 (-64)
+
 int         vly_abi_version(void);
 const char *vly_last_error(void);
 
@@ -64,7 +67,9 @@ const char *vly_last_error(void);
  *   pipelines (the two waves of a SIMD run one phase apart; +50 keeps whole-K-tile staging with 128-byte LDS
  *   rows); +70 (tiles 3, 4, 6: stage <= 53 KB) THREE whole-K-tile stages, i.e. two K tiles of glds loads in
  *   flight (LDS-DMA issue -> landed is ~2600 clk, more than one K tile of MFMA work on these tiles); +80 =
- *   +70 with the role split of +50; 93 / 94 = 256x128 / 128x256 with 16 waves and three stages. */
+ *   +70 with the role split of +50; 93 / 94 = 256x128 / 128x256 with 16 waves and three stages.
+ *   ldw = VLY_LDW_PACKED64: W points to the block layout written by vly_pack_weight_bf16 (not with the +10 / +30
+ *   half-tile loops). */
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);
@@ -76,6 +81,14 @@ int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *
  *   Same constraints as vly_gemm_bf16 (K >= 128); tile_hint as there (0 = 192x128). */
 int vly_gemm_bf16_splitk2(const void *A, const void *W, const float *bias, void *C0, void *C1,
                           int M, int N, int K, int lda, int ldw, int ldc, int tile_hint, void *stream);
+
+/* Weight repack for the prefill GEMMs (done once at load, like the q|k|v fusion): W [N,K] row-major bf16 ->
+ *   packed [K/64][ceil(N/64)][64 rows][64 k], rows >= N zero-filled; ceil(N/64)*64*K elements.  In this layout the
+ *   K tile of a weight panel that a workgroup stages per iteration is ONE contiguous run in HBM (8 KB per 64 rows)
+ *   instead of one 128-byte line out of each 2*K-byte row: +1..3 % on the large GEMMs, +6..12 % on the N = 4096
+ *   projections at M = 1312 (profiles/r01_ab_lib_v17.jsonl).  The GEMV (decode) and stream-K kernels read row-major
+ *   weights only, so a model that decodes keeps both copies (valley_amd.ops.PackedWeight). */
+int vly_pack_weight_bf16(const void *W, void *packed, int N, int K, int ldw, void *stream);
 
 /* Persistent stream-K variant of vly_gemm_bf16 (same math, epilogues and constraints): the
  *   (tile, k-tile) iteration space is cut into equal contiguous ranges over CUs x occupancy persistent

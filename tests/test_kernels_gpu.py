@@ -466,3 +466,51 @@ def test_gemm_online_tuner_decides_and_stays_correct(monkeypatch, tmp_path):
     assert ops.load_tune_cache(str(tmp_path / "tune.json")) == 1 and ops._TUNED == saved
     assert maxabs(ops.gemm(a, w, bias, out_dtype=torch.float32), ref) < 2e-4 * math.sqrt(K) + 1e-3
     assert ops.sk_error_flag(dev()) == 0
+
+
+@pytest.mark.parametrize("N,K", [(264, 128), (4096, 1024), (1000, 640)])
+def test_pack_weight_layout(N, K):
+    """vly_pack_weight_bf16: [N,K] -> [K/64][ceil(N/64)][64][64], rows past N zero."""
+    from valley_amd import ops
+    w = rnd((N, K), 81, dtype=torch.bfloat16).to(dev())
+    pw = ops.PackedWeight(w)
+    nb = (N + 63) // 64
+    ref = torch.zeros((nb * 64, K), dtype=torch.bfloat16, device=dev())
+    ref[:N] = w
+    ref = ref.view(nb, 64, K // 64, 64).permute(2, 0, 1, 3).contiguous()
+    assert tuple(pw.blocks.shape) == (K // 64, nb, 64, 64) and torch.equal(pw.blocks, ref)
+    assert pw.plain is w and tuple(pw.shape) == (N, K)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 56, 57, 73, 74, 76, 83, 84, 86, 93, 94])
+def test_gemm_packed_weights_bit_identical(tile):
+    """The block-ordered weight copy changes addresses, not arithmetic: every tile / loop variant returns the same
+    bits as with the row-major weights (ragged N included), through every epilogue; so does the split-K pair."""
+    from valley_amd import ops
+    M, N, K = 771, 1000, 256
+    a = rnd((M, K), 82, dtype=torch.bfloat16).to(dev())
+    w = rnd((N, K), 83, 0.05, dtype=torch.bfloat16).to(dev())
+    bias = rnd((N,), 84, 0.5).to(dev())
+    res = rnd((M, N), 85).to(dev())
+    pw = ops.PackedWeight(w)
+    for kw in (dict(), dict(bias=bias, residual=res, out_dtype=torch.float32), dict(bias=bias, epilogue=ops.EPI_QUICK_GELU),
+               dict(epilogue=ops.EPI_SWIGLU)):
+        assert torch.equal(ops.gemm_mfma(a, pw, tile_hint=tile, **kw), ops.gemm_mfma(a, w, tile_hint=tile, **kw)), kw
+    if tile in (0, 2, 6, 7, 8, 76, 84, 86):
+        o = [torch.empty((M, N), dtype=torch.bfloat16, device=dev()) for _ in range(4)]
+        ops.gemm_mfma_splitk2(a, pw, bias, o[0], o[1], tile)
+        ops.gemm_mfma_splitk2(a, w, bias, o[2], o[3], tile)
+        assert torch.equal(o[0], o[2]) and torch.equal(o[1], o[3])
+    # the kernels that read row-major weights take the plain copy
+    assert torch.equal(ops.gemm_streamk(a, pw), ops.gemm_streamk(a, w))
+    assert torch.equal(ops.gemv(a[:4], pw), ops.gemv(a[:4], w))
+
+
+def test_gemm_packed_rejects_half_tile_loops():
+    from valley_amd import ops
+    from valley_amd.lib import ValleyHipError
+    a = rnd((256, 128), 86, dtype=torch.bfloat16).to(dev())
+    pw = ops.PackedWeight(rnd((256, 128), 87, dtype=torch.bfloat16).to(dev()))
+    for t in (11, 33):
+        with pytest.raises(ValleyHipError):
+            ops.gemm_mfma(a, pw, tile_hint=t)

@@ -422,3 +422,23 @@ def test_llama_prefill_tuned_dispatch_matches_whole_tiles(monkeypatch, tmp_path)
           {k[:4]: v for k, v in ops._TUNED.items() if k[3] == ops.EPI_PAIR})
     assert worst < 1.5e-2
     assert ops.sk_error_flag("cuda:0") == 0
+
+
+def test_llama_packed_weights_match_row_major():
+    """pack_weights=True: prefill reads the block-ordered copies, decode the row-major ones — same logits bit for bit
+    as the row-major engine (the deterministic whole-tile dispatch picks the same kernels for both)."""
+    from valley_amd.llama import HipLlama
+    B, S = 2, 200
+    g = torch.Generator(device="cuda").manual_seed(11)
+    h = torch.randn((B * S, 1024), generator=g, device="cuda") * 0.02
+    outs = []
+    for pack in (False, True):
+        ll = HipLlama(1024, 8, 2752, 2, 32006, 1e-5, pack_weights=pack).init_random(seed=5)
+        assert bool(ll.packed) == pack
+        cache = ll.new_cache(B, S + 4)
+        x = ll.forward(h.clone(), B, S, cache)
+        lg = ll.logits(x[-4:]).clone()
+        h1 = torch.randn((B, 1024), generator=torch.Generator(device="cuda").manual_seed(12), device="cuda") * 0.02
+        x1 = ll.forward(h1.clone(), B, 1, cache)                      # one decode step on the same cache
+        outs.append((lg, ll.logits(x1).clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

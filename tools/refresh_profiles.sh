@@ -9,6 +9,8 @@ python bench.py --config tiny --no-cpu-baseline > gpurun_out/f_tune_tiny.json 2>
 export VALLEY_TUNE_TRIALS=3
 else
 : > gpurun_out/f.err
+export VALLEY_TUNE_CACHE=$PWD/gpurun_out/tune_final.json      # shipped table + whatever had to be decided online
+rm -f $VALLEY_TUNE_CACHE
 fi
 python bench.py > gpurun_out/f_bench_c2.json 2>> gpurun_out/f.err
 python bench.py --config c3 --no-cpu-baseline > gpurun_out/f_bench_c3.json 2>> gpurun_out/f.err

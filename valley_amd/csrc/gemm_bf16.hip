@@ -51,11 +51,10 @@ constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 c
 #ifndef VLY_MMA_PRIO
 #define VLY_MMA_PRIO 0    // 1: s_setprio 1 over the MFMAs of mma_ktile (the role-split loops always do)
 #endif
-#ifndef VLY_W_PACKED
-#define VLY_W_PACKED 0
-#endif
+// ldw == VLY_LDW_PACKED64: W is stored as [K/64][ceil(N/64)][64 rows][64 k] blocks (vly_pack_weight_bf16) — every K
+// tile of a weight panel is one contiguous run in HBM instead of one 128-byte line out of each 2*K-byte row
 VLY_DEVICE uint32_t w_row_off(int n, int ldw) {
-    return VLY_W_PACKED ? (uint32_t)(n >> 6) * 4096u + (uint32_t)(n & 63) * 64u : (uint32_t)n * (uint32_t)ldw;
+    return ldw < 0 ? (uint32_t)(n >> 6) * 4096u + (uint32_t)(n & 63) * 64u : (uint32_t)n * (uint32_t)ldw;
 }
 #ifndef VLY_FRAG_ORDER
 #define VLY_FRAG_ORDER 3
@@ -183,9 +182,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int nk = K / BK;
-    // VLY_W_PACKED (A/B builds): W is stored [K/64][ceil(N/64)][64 rows][64 k] — every K tile of a weight panel is one
-    // contiguous run in HBM instead of one 128-byte line out of each 2*K-byte row
-    const uint32_t wk = VLY_W_PACKED ? (uint32_t)((N + 63) >> 6) * 4096u : (uint32_t)BK;     // W elements per K tile
+    const uint32_t wk = ldw < 0 ? (uint32_t)((N + 63) >> 6) * 4096u : (uint32_t)BK;           // W elements per K tile
     if (ksplit == 2) {
         const int h0 = nk >> 1;
         if (part) { A += (size_t)h0 * BK; W += (size_t)h0 * wk; nk -= h0; } else nk = h0;
@@ -713,6 +710,10 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
                     int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, hipStream_t st,
                     void* C2) {
 #define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2
+    if (ldw < 0 && ((t >= 11 && t <= 15) || (t >= 31 && t <= 35))) {
+        vly_set_error("vly_gemm_bf16: the half-tile loops (tile_hint %d) read row-major weights only", tile_hint);
+        return -22;
+    }
     switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split over half tiles;
                                                           // 51..55: role-split over the full-tile 2-stage buffers
         case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
@@ -758,14 +759,15 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
                              int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue,
                              int out_dtype, int tile_hint, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16: empty problem"); return -22; }
-    if (K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
+    const bool wpacked = ldw == VLY_LDW_PACKED64;
+    if (K % BK || lda % 8 || (ldw % 8 || (ldw <= 0 && !wpacked)) || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
         ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) ||
         (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15))) {
         vly_set_error("vly_gemm_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",
                       M, N, K, lda, ldw, ldc, ldr);
         return -22;
     }
-    if ((size_t)M * lda >= (1ull << 31) || (size_t)N * ldw >= (1ull << 31)) {
+    if ((size_t)M * lda >= (1ull << 31) || (wpacked ? (size_t)((N + 63) / 64 * 64) * K : (size_t)N * ldw) >= (1ull << 31)) {
         vly_set_error("vly_gemm_bf16: operand exceeds 2^31 elements (32-bit byte offsets)");
         return -22;
     }
@@ -777,12 +779,14 @@ extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, co
 
 extern "C" int vly_gemm_bf16_splitk2(const void* A, const void* W, const float* bias, void* C0, void* C1, int M, int N, int K,
                                      int lda, int ldw, int ldc, int tile_hint, void* stream) {
-    if (M <= 0 || N <= 0 || K < 2 * BK || K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || !C0 || !C1 || C0 == C1 ||
+    const bool wpacked = ldw == VLY_LDW_PACKED64;
+    if (M <= 0 || N <= 0 || K < 2 * BK || K % BK || lda % 8 || ldw % 8 || (ldw <= 0 && !wpacked) || N % 4 || ldc % 2 || !C0 ||
+        !C1 || C0 == C1 ||
         ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C0 & 7) || ((uintptr_t)C1 & 7) || (bias && ((uintptr_t)bias & 15))) {
         vly_set_error("vly_gemm_bf16_splitk2: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
         return -22;
     }
-    if ((size_t)M * lda >= (1ull << 31) || (size_t)N * ldw >= (1ull << 31)) {
+    if ((size_t)M * lda >= (1ull << 31) || (wpacked ? (size_t)((N + 63) / 64 * 64) * K : (size_t)N * ldw) >= (1ull << 31)) {
         vly_set_error("vly_gemm_bf16_splitk2: operand exceeds 2^31 elements (32-bit byte offsets)");
         return -22;
     }

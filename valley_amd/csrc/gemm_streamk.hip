@@ -408,7 +408,7 @@ extern "C" int vly_gemm_bf16_streamk(const void* A, const void* W, const float* 
                                      int out_dtype, int tile_hint, void* workspace, size_t workspace_bytes,
                                      unsigned epoch, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16_streamk: empty problem"); return -22; }
-    if (K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
+    if (K % BK || lda % 8 || ldw % 8 || ldw <= 0 /* row-major weights only: no VLY_LDW_PACKED64 */ || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
         ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || ((uintptr_t)workspace & 15) ||
         (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15)) || epoch == 0) {
         vly_set_error("vly_gemm_bf16_streamk: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",

@@ -125,7 +125,7 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
 
 extern "C" int vly_gemv_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C, int M,
                              int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, void* stream) {
-    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 8 || lda % 8 || ldw % 8 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||
+    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 8 || lda % 8 || ldw % 8 || ldw <= 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||
         (epilogue == VLY_EPI_SWIGLU && (N % 2 || residual))) {
         vly_set_error("vly_gemv_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d", M, N, K, lda, ldw);
         return -22;

@@ -577,6 +577,32 @@ extern "C" int vly_add2_layernorm(float* h, const void* delta0_bf16, const void*
                               delta1_bf16);
 }
 
+// W [N,K] row-major (row stride ldw) -> [K/64][ceil(N/64)][64][64] blocks, rows >= N zero: one 16-byte chunk per thread
+__global__ void __launch_bounds__(256) pack_weight_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ P, int N, int K,
+                                                         int ldw, int nblk, size_t chunks) {
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= chunks) return;
+    const int c8 = (int)(c & 7), r = (int)((c >> 3) & 63);
+    const size_t blk = c >> 9;
+    const int nb = (int)(blk % nblk), kt = (int)(blk / nblk);
+    const int n = nb * 64 + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N) v = *(const u32x4*)(W + (size_t)n * ldw + kt * 64 + c8 * 8);
+    *(u32x4*)(P + c * 8) = v;
+}
+
+extern "C" int vly_pack_weight_bf16(const void* W, void* packed, int N, int K, int ldw, void* stream) {
+    if (N <= 0 || K <= 0 || K % 64 || ldw < K || ldw % 8 || ((uintptr_t)W & 15) || ((uintptr_t)packed & 15) || W == packed) {
+        vly_set_error("vly_pack_weight_bf16: bad args N=%d K=%d ldw=%d", N, K, ldw);
+        return -22;
+    }
+    const int nblk = (N + 63) / 64;
+    const size_t chunks = (size_t)nblk * (K / 64) * 512;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)W, (uint16_t*)packed, N, K, ldw, nblk, chunks);
+    return vly_check_launch("vly_pack_weight_bf16");
+}
+
 extern "C" int vly_argmax(const float* x, int32_t* idx, int M, int N, int ld, void* stream) {
     if (M <= 0 || N <= 0 || ld < N) { vly_set_error("vly_argmax: bad args"); return -22; }
     hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, x, idx, N, ld);

@@ -48,10 +48,41 @@ def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
         raise ValueError(f"{name}: must be contiguous")
 
 
+LDW_PACKED64 = -64      # include/valley_hip.h: VLY_LDW_PACKED64
+
+
+class PackedWeight:
+    """An nn.Linear weight [N,K] (bf16) kept twice: ``plain`` row-major for the weight-streaming GEMV (decode) and the
+    stream-K kernel, ``blocks`` = [K/64][ceil(N/64)][64][64] (vly_pack_weight_bf16) for the MFMA tile kernels, whose
+    per-iteration weight tile is then one contiguous run in HBM.  Spends HBM capacity (2x the weight bytes; 288 GB
+    per GPU) for DRAM page locality on the prefill weight stream.  The two copies are made once, at load; do not
+    write to ``plain`` afterwards."""
+
+    def __init__(self, plain: torch.Tensor):
+        _chk(plain, torch.bfloat16, "weight")
+        N, K = plain.shape
+        if K % 64:
+            raise ValueError("PackedWeight: K must be a multiple of 64")
+        self.plain = plain
+        self.shape = plain.shape
+        self.device = plain.device
+        self.blocks = torch.empty((K // 64, (N + 63) // 64, 64, 64), dtype=torch.bfloat16, device=plain.device)
+        rc = _lib.load().vly_pack_weight_bf16(plain.data_ptr(), self.blocks.data_ptr(), N, K, plain.stride(0), _stream())
+        _lib.check(rc, "vly_pack_weight_bf16")
+
+
+def _w_args(w, tile_kernel: bool):
+    """-> (tensor whose pointer is passed, ldw) for a plain tensor or a PackedWeight."""
+    if isinstance(w, PackedWeight):
+        return (w.blocks, LDW_PACKED64) if tile_kernel else (w.plain, w.plain.stride(0))
+    _chk(w, torch.bfloat16, "w")
+    return w, w.stride(0)
+
+
 def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra):
     _chk(a, torch.bfloat16, "a", contiguous=False)
-    _chk(w, torch.bfloat16, "w")
-    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    wt, ldw = _w_args(w, fn_name == "vly_gemm_bf16")
+    assert a.dim() == 2 and len(w.shape) == 2 and a.stride(1) == 1 and a.shape[1] == w.shape[1], (a.shape, w.shape)
     M, K = a.shape
     N = w.shape[0]
     No = N // 2 if epilogue == EPI_SWIGLU else N
@@ -76,7 +107,7 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
             tile %= 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
+    rc = fn(a.data_ptr(), wt.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), ldw,
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
     if rec is not None:
         e1.record()
@@ -152,14 +183,14 @@ def load_tune_cache(path: str) -> int:
     with open(path) as f:
         ents = json.load(f)
     for e in ents:
-        M, N, K, epi, dt, hb, hr = e["key"]
-        _TUNED[(M, N, K, epi, _DT[dt], bool(hb), bool(hr))] = (e["kind"], e["tile"])
+        M, N, K, epi, dt, hb, hr = e["key"][:7]
+        _TUNED[(M, N, K, epi, _DT[dt], bool(hb), bool(hr)) + tuple(e["key"][7:])] = (e["kind"], e["tile"])
     return len(ents)
 
 
 def save_tune_cache(path: str) -> None:
     import json
-    ents = [{"key": [k[0], k[1], k[2], k[3], str(k[4]), k[5], k[6]], "kind": v[0], "tile": v[1]} for k, v in _TUNED.items()]
+    ents = [{"key": [k[0], k[1], k[2], k[3], str(k[4]), k[5], k[6], *k[7:]], "kind": v[0], "tile": v[1]} for k, v in _TUNED.items()]
     tmp = f"{path}.{os.getpid()}.tmp"
     with open(tmp, "w") as f:
         json.dump(ents, f, indent=0)
@@ -196,6 +227,12 @@ TUNE_FINALISTS = 4   # after TUNE_TRIALS calls per candidate the best few are re
 _ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
 
 
+def _tune_key(M, N, K, epi, dtype, has_bias, has_res, w):
+    """Tuner key; weights in the block layout are tuned on their own (8th element "p64")."""
+    k = (M, N, K, epi, dtype, has_bias, has_res)
+    return k + ("p64",) if isinstance(w, PackedWeight) else k
+
+
 def tuning_pending() -> int:
     """Number of GEMM shapes the online tuner has seen but not decided yet."""
     return len(_ONLINE)
@@ -204,7 +241,7 @@ def tuning_pending() -> int:
 def gemm_mfma_splitk2(a, w, bias, out, out2, tile_hint=0):
     """One launch, two bf16 partial products: out = a[:, :K/2] @ w[:, :K/2]^T + bias, out2 = the other half of K."""
     _chk(a, torch.bfloat16, "a", contiguous=False)
-    _chk(w, torch.bfloat16, "w")
+    wt, ldw = _w_args(w, True)
     _chk(out, torch.bfloat16, "out", contiguous=False)
     _chk(out2, torch.bfloat16, "out2", contiguous=False)
     M, K = a.shape
@@ -214,8 +251,8 @@ def gemm_mfma_splitk2(a, w, bias, out, out2, tile_hint=0):
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _lib.load().vly_gemm_bf16_splitk2(a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), out2.data_ptr(), M, N, K,
-                                           a.stride(0), w.stride(0), out.stride(0), tile_hint, _stream())
+    rc = _lib.load().vly_gemm_bf16_splitk2(a.data_ptr(), wt.data_ptr(), _ptr(bias), out.data_ptr(), out2.data_ptr(), M, N, K,
+                                           a.stride(0), ldw, out.stride(0), tile_hint, _stream())
     if rec is not None:
         e1.record()
         t = tile_hint or 8
@@ -240,7 +277,7 @@ def gemm2(a, w, out, out2, bias=None) -> int:
         gemm(a, w, bias, out=out)
         return 1
     N, K = w.shape
-    key = (M, N, K, EPI_PAIR, out.dtype, bias is not None, False)
+    key = _tune_key(M, N, K, EPI_PAIR, out.dtype, bias is not None, False, w)
     choice = _TUNED.get(key)
     if choice is None:
         return _online_trial(key, a, w, bias, None, EPI_NONE, out.dtype, out, out2, CANDIDATES + SPLIT_CANDIDATES)[1]
@@ -359,7 +396,7 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
     N, K = w.shape
     if out is None:
         out = torch.empty((M, N // 2 if epilogue == EPI_SWIGLU else N), dtype=out_dtype, device=a.device)
-    key = (M, N, K, epilogue, out.dtype, bias is not None, residual is not None)
+    key = _tune_key(M, N, K, epilogue, out.dtype, bias is not None, residual is not None, w)
     choice = _TUNED.get(key)
     if choice is None:
         if torch.cuda.is_current_stream_capturing():
