@@ -339,8 +339,10 @@ def main():
                 d[0] += dt
                 d[1] += flop
                 d[2] += 1
-            dom = max(agg.items(), key=lambda kv: kv[1][0])
-            name, (tsum, fsum, n) = dom
+            # the dominant kernel = the GEMM call site (shape) with the largest share of the step; an instantiation
+            # that serves several shapes (e.g. the plain 192x128 tile: ViT out-proj / fc2 and the Llama o-proj / down-proj
+            # split-K pairs) is not one workload, its per-name average in rocprofv3 mixes them (kernel_all_shapes below)
+            dshape, (tsum, fsum, n, name) = max(shapes.items(), key=lambda kv: kv[1][0])
             ach = fsum / tsum / 1e12
             traffic = None                                      # HBM bytes per launch from a committed PMC run
             tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.config}.json")
@@ -350,7 +352,10 @@ def main():
                 for k, v in tk.items():
                     if k.replace(" ", "") == key:
                         traffic = v["hbm_bytes_per_launch"]
-            result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+            result["roofline"] = {"bound": "mfma", "kernel": name, "shape": dshape,
+                                  "kernel_all_shapes": {"launches": agg[name][2], "avg_launch_us": round(agg[name][0] / agg[name][2] * 1e6, 2),
+                                                        "note": "what rocprofv3 --stats lists under this kernel name"},
+                                  "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                   "traffic_source": "profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
                                                     "x1024, separate passes; tools/pmc_traffic.sh)" % args.config if traffic else None,
