@@ -45,6 +45,12 @@ def test_ops_reject_cpu_tensors():
         ops.rmsnorm(torch.zeros((4, 256)), torch.ones(256), 1e-5)
 
 
+def test_packed_weight_needs_a_device_tensor():
+    from valley_amd import lib, ops
+    with pytest.raises(lib.ValleyHipError):
+        ops.PackedWeight(torch.zeros((128, 64), dtype=torch.bfloat16))
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "valley_amd")
     for dp, _, fs in os.walk(pkg):
@@ -72,10 +78,16 @@ def test_shipped_tuning_table_is_consistent():
     for shape in [(1312, 12288, 4096, 0), (1312, 4096, 4096, 0), (1312, 22016, 4096, 2), (1312, 4096, 11008, 0),
                   (8224, 3072, 1024, 0), (8224, 1024, 1024, 0), (8224, 4096, 1024, 1), (8224, 1024, 4096, 0)]:
         assert shape in keys, shape
+    # the default engine reads the Llama projections from the block-ordered copy: configs[1]'s four prefill GEMMs are
+    # decided for that layout too (8th key element), so that the default bench run does not start by tuning
+    packed = {tuple(e["key"][:4]) for e in ents if e["key"][7:] == ["p64"]}
+    for shape in [(1312, 12288, 4096, 0), (1312, 4096, 4096, 100), (1312, 22016, 4096, 2), (1312, 4096, 11008, 100)]:
+        assert shape in packed, shape
     saved = dict(ops._TUNED)
     try:
         ops._TUNED.clear()
         assert ops.load_tune_cache(path) == len(ents)
+        assert (1312, 22016, 4096, 2, torch.bfloat16, False, False, "p64") in ops._TUNED
     finally:
         ops._TUNED.clear()
         ops._TUNED.update(saved)
