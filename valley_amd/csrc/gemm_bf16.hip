@@ -133,6 +133,51 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 #endif
 }
 
+// VLY_MFMA32=1 (A/B builds, tools/ab_lib.py; written at the end of round 1 and NOT yet validated on hardware — the
+// default build does not contain a single token of it): wave tiles that are multiples of 32 in both dimensions run
+// on v_mfma_f32_32x32x16_bf16 — half the operand-register reads per flop, 1.9 instead of 1.5 PFLOP/s sustained on
+// random operands (tools/probes/mfma_shapes.hip).  Fragment = 32 rows x 16 k: lane <-> row (lane & 31) and K group
+// (lane >> 5) of 8 elements; four K steps per 64-wide K tile, chunk = 2*step + (lane >> 5).  Result block: register
+// r of the 16 holds C[m = lane & 31][n = 8*(r/4) + 4*(lane >> 5) + r % 4] (operands swapped as in the 16x16 path:
+// the W fragment is the MFMA's first operand).
+#ifndef VLY_MFMA32
+#define VLY_MFMA32 0
+#endif
+#if VLY_MFMA32
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+VLY_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// One K tile of a wave's MI2 x NI2 blocks of 32x32; sw[s] = swizzled byte offset of K step s inside a 128-byte row.
+// Step s+1's fragments are requested between step s's MFMAs (as in mma_ktile).
+template <int MI2, int NI2>
+VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char* pw, const int (&sw)[4]) {
+    bf16x8 af[2][MI2], wf[2][NI2];
+#pragma unroll
+    for (int j = 0; j < NI2; ++j) wf[0][j] = *(const bf16x8*)(pw + j * 4096 + sw[0]);
+#pragma unroll
+    for (int i = 0; i < MI2; ++i) af[0][i] = *(const bf16x8*)(pa + i * 4096 + sw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int i = 0; i < MI2; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI2; ++j) acc[i][j] = mfma32(wf[cur][j], af[cur][i], acc[i][j]);
+            if (s < 3) {
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < NI2; ++j) wf[nxt][j] = *(const bf16x8*)(pw + j * 4096 + sw[s + 1]);
+                }
+                af[nxt][i] = *(const bf16x8*)(pa + i * 4096 + sw[s + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+#endif
+
 template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
@@ -176,6 +221,24 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     const int n0 = (m_fast ? swz / tiles_m : swz % tiles_n) * BN;
 
     const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+#if VLY_MFMA32
+    // 32x32x16 path: whole-K-tile loops only, wave tile a multiple of 32 both ways
+    constexpr bool M32 = WM % 32 == 0 && WN % 32 == 0 && (PIPE == 0 || PIPE == 4 || PIPE == 6 || PIPE == 7);
+    constexpr int MI2 = M32 ? WM / 32 : 1, NI2 = M32 ? WN / 32 : 1;
+    const int l31 = lane & 31, hk = lane >> 5;
+    [[maybe_unused]] f32x16 acc32[MI2][NI2];
+    [[maybe_unused]] int sw32[4];
+    if constexpr (M32) {
+#pragma unroll
+        for (int i = 0; i < MI2; ++i)
+#pragma unroll
+            for (int j = 0; j < NI2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) sw32[st] = ((2 * st + hk) ^ (l31 & 7)) << 4;
+    }
+#endif
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -222,6 +285,10 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sW = sA + A_BYTES;
+#if VLY_MFMA32
+            if constexpr (M32) mma_ktile32<MI2, NI2>(acc32, sA + (wm0 + l31) * 128, sW + (wn0 + l31) * 128, sw32);
+            else
+#endif
             mma_ktile<MI, NI>(acc, sA + rdA, sW + rdW, sw0, sw1);
         }
     } else if constexpr (PIPE == 3) {
@@ -347,20 +414,48 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 if (kk == 0 && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
                 const int sw = kk ? sw1 : sw0;
                 bf16x8 af[MI], wf[NI];
+#if VLY_MFMA32
+                [[maybe_unused]] bf16x8 af2[2][MI2], wf2[2][NI2];           // two K steps of 16 per phase
+                if constexpr (M32) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                        for (int j = 0; j < NI2; ++j)
+                            wf2[st][j] = *(const bf16x8*)(cur + A_BYTES + (wn0 + l31) * 128 + j * 4096 + sw32[2 * kk + st]);
+#pragma unroll
+                        for (int i = 0; i < MI2; ++i)
+                            af2[st][i] = *(const bf16x8*)(cur + (wm0 + l31) * 128 + i * 4096 + sw32[2 * kk + st]);
+                    }
+                } else
+#endif
+                {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
+                }
                 if (kk == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my loads of tile kt+1
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 // ---------------- M phase
                 __builtin_amdgcn_s_setprio(1);
+#if VLY_MFMA32
+                if constexpr (M32) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int i = 0; i < MI2; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI2; ++j) acc32[i][j] = mfma32(wf2[st][j], af2[st][i], acc32[i][j]);
+                } else
+#endif
+                {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -408,6 +503,10 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);                           // (kt+2) % 3
             const char* cur = smem + buf * STAGE;
+#if VLY_MFMA32
+            if constexpr (M32) mma_ktile32<MI2, NI2>(acc32, cur + (wm0 + l31) * 128, cur + A_BYTES + (wn0 + l31) * 128, sw32);
+            else
+#endif
             mma_ktile<MI, NI>(acc, cur + rdA, cur + rdW, sw0, sw1);
             buf = buf == 2 ? 0 : buf + 1;
         }
@@ -457,20 +556,48 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 if (kk == 0 && kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);
                 const int sw = kk ? sw1 : sw0;
                 bf16x8 af[MI], wf[NI];
+#if VLY_MFMA32
+                [[maybe_unused]] bf16x8 af2[2][MI2], wf2[2][NI2];           // two K steps of 16 per phase
+                if constexpr (M32) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                        for (int j = 0; j < NI2; ++j)
+                            wf2[st][j] = *(const bf16x8*)(cur + A_BYTES + (wn0 + l31) * 128 + j * 4096 + sw32[2 * kk + st]);
+#pragma unroll
+                        for (int i = 0; i < MI2; ++i)
+                            af2[st][i] = *(const bf16x8*)(cur + (wm0 + l31) * 128 + i * 4096 + sw32[2 * kk + st]);
+                    }
+                } else
+#endif
+                {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
+                }
                 if (kk == 1 && grp == 1) wait_next(kt);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 // ---------------- M phase
                 __builtin_amdgcn_s_setprio(1);
+#if VLY_MFMA32
+                if constexpr (M32) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int i = 0; i < MI2; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI2; ++j) acc32[i][j] = mfma32(wf2[st][j], af2[st][i], acc32[i][j]);
+                } else
+#endif
+                {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 if (kk == 1 && grp == 0) wait_next(kt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -551,24 +678,49 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     // 128-byte line per instruction; tools/probes/store_pattern.hip: 3.0 TB/s for the 67 MB ViT fc1 output),
     // so the tile is first assembled in LDS and then written as full lines, 16 bytes per lane with
     // consecutive lanes along the row (4.6 TB/s).  The fused bias / activation / residual math is unchanged.
+#if VLY_MFMA32
+    // hand the 32x32 result blocks to the epilogue as the f32x4 groups it works on — group q of block (I, J) becomes
+    // acc[2I + (q >> 1)][2J + (q & 1)]; its row is lane & 31 of block I, its 4 columns start at 8q + 4*(lane >> 5)
+    if constexpr (M32) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int q = ((i & 1) << 1) | (j & 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][4 * q + r];
+            }
+    }
+    auto frag_row = [&](int i) { return M32 ? wm0 + (i >> 1) * 32 + l31 : wm0 + i * 16 + l15; };
+    auto frag_col = [&](int i, int j) {
+        return M32 ? wn0 + (j >> 1) * 32 + ((((i & 1) << 1) | (j & 1)) << 3) + (hk << 2) : wn0 + j * 16 + g * 4;
+    };
+    constexpr int EPI_NH = (M32 && MI % 4 != 0) ? 1 : 2;      // an odd number of 32-row blocks leaves in one pass
+#define VLY_FRAG_ROW(i) frag_row(i)
+#define VLY_FRAG_COL(i, j) frag_col(i, j)
+#else
+#define EPI_NH 2
+#define VLY_FRAG_ROW(i) wm0 + i * 16 + l15
+#define VLY_FRAG_COL(i, j) wn0 + j * 16 + g * 4
+#endif
     if constexpr (OUT == VLY_OUT_BF16) {
         if (wide) {
             __syncthreads();                                  // every wave is done with the K-loop stages
             // two halves of every wave's fragment rows: the stores of the first half are in flight while the
             // second half's bias / activation math runs (the exp of quick_gelu / SiLU is not free)
-            static_assert(MI % 2 == 0, "epilogue halves");
-            constexpr int HR = (MI / 2) * 16;                     // rows per wave-row block and half
+            static_assert(MI % EPI_NH == 0, "epilogue halves");
+            constexpr int HR = (MI / EPI_NH) * 16;                // rows per wave-row block and half
             constexpr int CPR = BNO / 8;                          // 16-byte chunks per tile row
             const int n0o = EPI == VLY_EPI_SWIGLU ? n0 >> 1 : n0, No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < EPI_NH; ++half) {
 #pragma unroll
-                for (int ii = 0; ii < MI / 2; ++ii) {
-                    const int i = half * (MI / 2) + ii;
-                    const int row = wm0 + i * 16 + l15, m = m0 + row;
+                for (int ii = 0; ii < MI / EPI_NH; ++ii) {
+                    const int i = half * (MI / EPI_NH) + ii;
+                    const int row = VLY_FRAG_ROW(i), m = m0 + row;
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        const int col = wn0 + j * 16 + g * 4, n = n0 + col;
+                        const int col = VLY_FRAG_COL(i, j), n = n0 + col;
                         f32x4 v = acc[i][j];
                         const bool in = m < M && n < N;
                         if (bias && in) v += *(const f32x4*)(bias + n);
@@ -594,7 +746,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                     }
                 }
                 __syncthreads();
-                for (int c = tid; c < (BM / 2) * CPR; c += NT) {
+                for (int c = tid; c < (BM / EPI_NH) * CPR; c += NT) {
                     const int hr = c / CPR, q = c - hr * CPR;     // hr: row index inside this half's row set
                     const int row = (hr / HR) * WM + half * HR + hr % HR;
                     const int m = m0 + row, n = n0o + q * 8;
@@ -610,11 +762,11 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm0 + i * 16 + l15;
+        const int m = m0 + VLY_FRAG_ROW(i);
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn0 + j * 16 + g * 4;
+            const int n = n0 + VLY_FRAG_COL(i, j);
             if (n >= N) continue;
             f32x4 v = acc[i][j];
             if (bias) {
@@ -656,6 +808,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         }
     }
 }
+
+#undef VLY_FRAG_ROW
+#undef VLY_FRAG_COL
+#if !VLY_MFMA32
+#undef EPI_NH
+#endif
 
 template <int BM, int BN, int WM, int WN, int PIPE>
 int launch_tile(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
