@@ -133,8 +133,8 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 #endif
 }
 
-// VLY_MFMA32=1 (A/B builds, tools/ab_lib.py; written at the end of round 1 and NOT yet validated on hardware — the
-// default build does not contain a single token of it): wave tiles that are multiples of 32 in both dimensions run
+// VLY_MFMA32=1 (A/B builds, tools/ab_lib.py; written at the end of round 1, one hardware run: correct, 9-14 % slower
+// than the 16x16x32 loops — see VLY_SWZ_KEY below; the default build does not contain a single token of it): wave tiles that are multiples of 32 in both dimensions run
 // on v_mfma_f32_32x32x16_bf16 — half the operand-register reads per flop, 1.9 instead of 1.5 PFLOP/s sustained on
 // random operands (tools/probes/mfma_shapes.hip).  Fragment = 32 rows x 16 k: lane <-> row (lane & 31) and K group
 // (lane >> 5) of 8 elements; four K steps per 64-wide K tile, chunk = 2*step + (lane >> 5).  Result block: register
@@ -142,6 +142,17 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 // the W fragment is the MFMA's first operand).
 #ifndef VLY_MFMA32
 #define VLY_MFMA32 0
+#endif
+// Chunk swizzle key of the LDS stage rows (applied to the staging SOURCE address and to the fragment reads).  row & 7 is
+// conflict-free for the 16-row fragments; the 32-row fragments of the 32x32x16 path see 2-way bank conflicts with it
+// (ds_read_b128 serves lanes {0-3, 12-15, 20-27} together: rows 12 and 20 share row & 7 and row parity) — first
+// hardware run of VLY_MFMA32=1: bit-compatible results, but 9-14 % SLOWER than the 16x16x32 kernels
+// (profiles/r01_ab_lib_v17.jsonl).  VLY_MFMA32=2 switches those instantiations to (row >> 1) & 7, which is distinct
+// over every lane group of the 32-row read; that variant has not run on hardware yet.
+#if VLY_MFMA32 == 2
+#define VLY_SWZ_KEY(row) (M32 ? ((row) >> 1) & 7 : (row) & 7)
+#else
+#define VLY_SWZ_KEY(row) (row & 7)
 #endif
 #if VLY_MFMA32
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
@@ -236,7 +247,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) sw32[st] = ((2 * st + hk) ^ (l31 & 7)) << 4;
+        for (int st = 0; st < 4; ++st) sw32[st] = ((2 * st + hk) ^ (VLY_MFMA32 == 2 ? (l31 >> 1) & 7 : l31 & 7)) << 4;
     }
 #endif
     f32x4 acc[MI][NI];
@@ -258,13 +269,13 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
             const int gr = min(m0 + row, M - 1);
-            offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+            offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
             const int gr = min(n0 + row, N - 1);
-            offW[p] = w_row_off(gr, ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(gr, ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -382,12 +393,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -474,12 +485,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -518,12 +529,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -811,6 +822,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 
 #undef VLY_FRAG_ROW
 #undef VLY_FRAG_COL
+#undef VLY_SWZ_KEY
 #if !VLY_MFMA32
 #undef EPI_NH
 #endif
