@@ -45,3 +45,24 @@ def test_build_inputs_errors_match_reference():
 
 def test_process_response_matches_reference():
     assert M.process_response(None, G["process_response"]["inputs"]) == G["process_response"]["outputs"]
+
+
+def test_cli_surface_matches_the_reference_entry_point():
+    """valley/inference/run_valley.py keeps the reference's names (init_vision_token, main, DEFAULT_SYSTEM) and its five
+    options; init_vision_token binds the six token ids where the splice reads them (reference run_valley.py:13-18)."""
+    from types import SimpleNamespace
+
+    import valley.inference.run_valley as rv
+    from tests.fake_tokenizer import SPECIALS, FakeTokenizer
+    tok = FakeTokenizer()
+    tok.add_tokens(SPECIALS, special_tokens=True)
+    cfg = SimpleNamespace()
+    model = SimpleNamespace(get_model=lambda: SimpleNamespace(vision_tower=SimpleNamespace(config=cfg)))
+    rv.init_vision_token(model, tok)
+    want = dict(zip(("im_patch_token", "vi_frame_token", "im_start_token", "im_end_token", "vi_start_token", "vi_end_token"),
+                    tok.convert_tokens_to_ids(SPECIALS)))
+    assert vars(cfg) == want
+    args = rv.parse_args([])
+    assert args.query == "Describe this video concisely.\n<video>" and args.system_prompt == "" and args.vision_tower is None
+    assert args.model_name.endswith("stable-valley-13b-v1") and args.video_file.endswith(".mp4")
+    assert rv.DEFAULT_SYSTEM.startswith("You are Valley, a large language and vision assistant") and callable(rv.main)
