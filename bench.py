@@ -6,8 +6,9 @@ A "step" is ONE pass of the hot path over one batch of synthetic clips resident 
     -> temporal mean pool + per-frame CLS -> (N>1: RCCL all-gather of pooled tokens, 1024-wide)
     -> mm_projector -> token-embedding gather + visual splice -> Llama prefill over [visual || text]
     -> lm_head on all positions.
-Default workload = BASELINE.json configs[1] "Valley2-7b: 8 frames x batch 4, ViT-L/14 + Llama-2-7B
-prefill, bf16, 1xMI355X" (S = 320 + T = 328 per SURVEY.md §8d).  `--config c3` runs the 13B case.
+Default workload = BASELINE.json configs[2] "Valley-13b-v1: 16 frames x batch 8, ViT-L/14 + Vicuna-13B
+prefill, bf16, 1xMI355X" (S = 320 + T = 336 per SURVEY.md §8d) — the configuration BASELINE.json's metric
+("prefill tokens/sec (13B)") is quoted on; it fits one GPU.  `--config c2` runs the 7B case (configs[1]).
 
 Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): frames shard by whole
 clips (every rank encodes its own B clips: weak scaling), ONE all-gather reassembles the pooled
@@ -54,13 +55,62 @@ def prefill_flop(S, H, I, L, V):
     return S * (L * (8 * H * H + 6 * H * I) + 2 * H * V) + L * 2 * S * (S + 1) * H
 
 
-def cpu_baseline(cfg, threads):
-    """Oracle (kind "port") on a bounded sample (~10 s of CPU work): 3 clips x T frames through ViT-L/14
-    (23 layers) and, twice, 4 of the L Llama layers on 3 sequences of S = 320+T, scaled by L/4; fp32.  Threads: the host GEMM rate of the
-    256-core GPU box peaks at 16 threads (tools/cpu_threads_probe.py: 830 GFLOP/s at 16, 111 at 128)."""
+def _host_info():
+    """CPU model, physical cores and logical CPUs of this host (Linux /proc)."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip() and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return model, (len(phys) or logical), logical
+
+
+def _pick_threads(physical):
+    """torch's CPU GEMM does not scale to every core of a big host (round 1: 830 GFLOP/s at 16 threads, 111 at 128 on
+    the 256-core GPU box): time one ViT-fc1-shaped GEMM at a few thread counts, keep the fastest."""
+    a, w = torch.randn(2056, 1024), torch.randn(4096, 1024)
+    best, rates = 1, {}
+    for th in sorted({t for t in (8, 16, 32, 64, physical) if t <= physical} or {physical}):
+        torch.set_num_threads(th)
+        torch.nn.functional.linear(a, w)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            torch.nn.functional.linear(a, w)
+        rates[th] = round(4 * 2 * 2056 * 1024 * 4096 / (time.perf_counter() - t0) / 1e9, 1)
+        if rates[th] > rates.get(best, 0):
+            best = th
+    return best, rates
+
+
+def cpu_baseline():
+    """the oracle (kind "port", oracle/valley_oracle.py) on configs[0] EXACTLY — 1 clip x 8 frames
+    (224^2) -> ViT-L/14 (23 contributing layers) -> mean pool + mm_projector -> splice -> Llama-2-7B-shape prefill
+    (32 layers, S = 328) -> lm_head on all positions; random weights, fp32 (bf16 weights if the host cannot hold
+    27 GB); 1 warm-up-free pass per stage timed (the pass itself is the bounded sample: ~10-30 s); thread count =
+    the fastest of a short GEMM calibration, reported with the CPU model, the physical core count and the torch
+    version.  The 32 decoder layers alias ONE random layer's weight buffers (0.81 GB fp32 per layer — larger than any
+    host L3, so every layer still streams its weights from DRAM; identical arithmetic; allocating and faulting in 27 GB
+    took 2.5 min of setup on the authoring host and bought nothing)."""
     from oracle import valley_oracle as O
+    model, physical, logical = _host_info()
+    threads, rates = _pick_threads(physical)
     torch.set_num_threads(threads)
-    T, H, I, L = cfg["T"], cfg["H"], cfg["I"], cfg["L"]
+    T, H, I, L, heads, V = 8, 4096, 11008, 32, 32, VOCAB_TEXT + 6
     S = 320 + T
     g = torch.Generator().manual_seed(0)
     rn = lambda *s, std=0.02: torch.randn(*s, generator=g) * std  # noqa: E731
@@ -75,33 +125,82 @@ def cpu_baseline(cfg, threads):
             vw[p + n + ".weight"], vw[p + n + ".bias"] = torch.ones(1024), torch.zeros(1024)
         vw[p + "mlp.fc1.weight"], vw[p + "mlp.fc1.bias"] = rn(4096, 1024), rn(4096)
         vw[p + "mlp.fc2.weight"], vw[p + "mlp.fc2.bias"] = rn(1024, 4096), rn(1024)
-    nl = 4
-    lw = {"model.norm.weight": torch.ones(H)}
-    for i in range(nl):
+    base = {"q": rn(H, H), "k": rn(H, H), "v": rn(H, H), "o": rn(H, H), "gate": rn(I, H), "up": rn(I, H), "down": rn(H, I)}
+    lw = {"model.norm.weight": torch.ones(H), "model.embed_tokens.weight": rn(V, H), "lm_head.weight": rn(V, H),
+          "model.mm_projector.weight": rn(H, 1024), "model.mm_projector.bias": torch.zeros(H)}
+    for i in range(L):
         p = f"model.layers.{i}."
-        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            lw[p + f"self_attn.{n}.weight"] = rn(H, H)
-        lw[p + "mlp.gate_proj.weight"], lw[p + "mlp.up_proj.weight"], lw[p + "mlp.down_proj.weight"] = rn(I, H), rn(I, H), rn(H, I)
+        for n in "qkvo":
+            lw[p + f"self_attn.{n}_proj.weight"] = base[n]
+        for n in ("gate", "up", "down"):
+            lw[p + f"mlp.{n}_proj.weight"] = base[n]
         lw[p + "input_layernorm.weight"], lw[p + "post_attention_layernorm.weight"] = torch.ones(H), torch.ones(H)
-    nc, reps = 3, 2
-    px = torch.randn((nc * T, 3, 224, 224), generator=g)
-    emb = rn(nc, S, H, std=1.0)
+    from valley_amd import weights as W
+    tok = O.TokenIds(**W.SPECIAL_IDS(VOCAB_TEXT))
+    ids = torch.from_numpy(W.synthetic_prompt(7, T, VOCAB_TEXT)).view(1, S)
+    px = torch.randn((1, T, 3, 224, 224), generator=g)
     vcfg = O.VisionCfg(layers=24)
-    lcfg = O.LlamaCfg(hidden=H, heads=cfg["heads"], intermediate=I, layers=nl, eps=cfg["eps"])
+    lcfg = O.LlamaCfg(hidden=H, heads=heads, intermediate=I, layers=L, vocab=V, eps=1e-5)
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.vit_select(px, vw, vcfg, -2)
+        feats = O.vit_select(px[0], vw, vcfg, -2)
+        proj = O.mm_project(feats, lw)
         t_vit = time.perf_counter() - t0
         t0 = time.perf_counter()
-        for _ in range(reps):
-            O.llama_forward(emb, lw, lcfg, n_layers=nl)
+        emb = torch.nn.functional.embedding(ids, lw["model.embed_tokens.weight"])
+        emb = O.splice_visual_tokens(ids, emb, [proj], tok, "mean", lw)
+        hidden, _ = O.llama_forward(emb, lw, lcfg)
+        logits = torch.nn.functional.linear(hidden, lw["lm_head.weight"])
         t_l = time.perf_counter() - t0
-    t_clip = t_vit / nc + t_l / (nc * reps) * (L / nl)           # seconds per clip (T frames + one sequence)
-    return {"value": round(T / t_clip, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32: {nc} clips x {T} frames ViT-L/14 23 layers ({t_vit:.2f}s) + {reps} x {nl} of {L} Llama "
-                      f"layers on {nc} sequences of S={S} ({t_l:.2f}s, scaled x{L // nl}); lm_head excluded",
-            "vit_frames_per_s": round(nc * T / t_vit, 3),
-            "prefill_tokens_per_s": round(nc * S / (t_l / reps * L / nl), 2)}
+    assert torch.isfinite(logits).all()
+    return {"value": round(T / (t_vit + t_l), 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"configs[0] exactly: 1 clip x {T} frames ViT-L/14 23 layers + projector ({t_vit:.2f}s), then splice + "
+                      f"7B-shape prefill L={L} S={S} + lm_head on all positions ({t_l:.2f}s); oracle fp32, one pass, "
+                      f"the {L} layers alias one layer's 0.81 GB of weights",
+            "vit_frames_per_s": round(T / t_vit, 3), "prefill_tokens_per_s": round(S / t_l, 2),
+            "cpu_model": model, "physical_cores": physical, "logical_cpus": logical, "threads": threads,
+            "thread_calibration_GFLOPs": rates, "torch": torch.__version__}
+
+
+def live_traffic(args, kernel_name):
+    """HBM-side bytes per launch of `kernel_name`, measured now: two `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE
+    do not fit the TCC slot budget together — MI355X_MICROARCH.md §rocprofv3 PMC slots — and nothing but --kernel-trace
+    rides along) over a short child run of this same bench, corrected as the guide's HBM section prescribes: both
+    counters x1024, FETCH_SIZE x2 on gfx950 (128-byte requests tallied at 64 B), WRITE_SIZE as is.
+    -> (bytes per launch | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="vly_pmc_", dir="/tmp")
+    key = kernel_name.replace(" ", "")
+    per = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", c, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--config", args.config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+               "--no-kernel-events", "--traffic", "none", "--pack-weights", str(args.pack_weights)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, timeout=900)
+        except Exception as e:  # noqa: BLE001
+            return None, f"rocprofv3 --pmc {c} failed: {e!r}"
+        files = glob.glob(os.path.join(out, "**", f"{c}_counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, f"rocprofv3 --pmc {c}: rc={r.returncode}, no counter file ({r.stderr.decode(errors='replace')[-200:]})"
+        vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                if row["Counter_Name"] == c and key in row["Kernel_Name"].replace(" ", "")]
+        if not vals:
+            return None, f"{kernel_name} not in the {c} pass"
+        per[c] = (sum(vals) / len(vals), len(vals))
+    shutil.rmtree(out, ignore_errors=True)
+    b = 2 * 1024 * per["FETCH_SIZE"][0] + 1024 * per["WRITE_SIZE"][0]
+    return int(b), (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two passes of `bench.py --config {args.config} --steps 2` on this "
+                    f"box ({per['FETCH_SIZE'][1]} launches), x1024, FETCH_SIZE x2 (gfx950); fetch {2 * 1024 * per['FETCH_SIZE'][0] / 1e6:.1f} MB "
+                    f"+ write {1024 * per['WRITE_SIZE'][0] / 1e6:.1f} MB per launch")
 
 
 def main():
@@ -109,7 +208,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=list(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=list(CONFIGS))
     ap.add_argument("--prefill", default="sharded", choices=["sharded", "replicated"])
     ap.add_argument("--decode", type=int, default=0, metavar="N",
                     help="instead of the prefill step: prefill once, then time N greedy hipGraph decode steps (configs[4])")
@@ -118,6 +217,9 @@ def main():
     ap.add_argument("--pack-weights", type=int, default=int(os.environ.get("VALLEY_PACK_WEIGHTS", "1")), choices=[0, 1],
                     help="1 (default): the Llama prefill GEMMs read a second, block-ordered copy of the weights (ops.PackedWeight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
+                    help="roofline.traffic of the dominant kernel: measured now by two rocprofv3 --pmc child passes (live, N=1 "
+                         "only), read from the newest profiles/r*_traffic_<config>.json (file), or null (none)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (rocprof runs)")
     args = ap.parse_args()
     os.environ["VALLEY_PACK_WEIGHTS"] = str(args.pack_weights)      # read by the engines when they load their weights
@@ -314,7 +416,7 @@ def main():
         vit_tf = vit_fps * VIT_GFLOP_PER_FRAME / 1e3
         pre_tf = prefill_flop(S, H, I, L, V) * Bp / (pre_ms * 1e-3) / 1e12
         result = {
-            "metric": "frames/sec ViT-L/14 encode + prefill tokens/sec",
+            "metric": "frames/sec ViT-L/14 encode + prefill tokens/sec" + (" (13B)" if H == 5120 else " (7B)" if H == 4096 else ""),
             "value": round(frames_total / (elapsed / args.steps), 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -344,21 +446,29 @@ def main():
             # split-K pairs) is not one workload, its per-name average in rocprofv3 mixes them (kernel_all_shapes below)
             dshape, (tsum, fsum, n, name) = max(shapes.items(), key=lambda kv: kv[1][0])
             ach = fsum / tsum / 1e12
-            traffic = None                                      # HBM bytes per launch from a committed PMC run
-            tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.config}.json")
-            if os.path.exists(tpath):
-                tk = json.load(open(tpath)).get("kernels", {})
-                key = name.replace(" ", "")
-                for k, v in tk.items():
-                    if k.replace(" ", "") == key:
-                        traffic = v["hbm_bytes_per_launch"]
+            traffic, traffic_src = None, None
+            if args.traffic == "live" and world == 1:
+                traffic, traffic_src = live_traffic(args, name)
+            if traffic is None and args.traffic != "none":           # newest committed PMC run of this config
+                import glob
+                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{args.config}.json")), reverse=True):
+                    tk = json.load(open(tpath)).get("kernels", {})
+                    hit = [v for k, v in tk.items() if k.replace(" ", "") == name.replace(" ", "")]
+                    if hit:
+                        traffic = hit[0]["hbm_bytes_per_launch"]
+                        traffic_src = (f"{os.path.relpath(tpath, ROOT)} (another box; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, x1024, "
+                                       f"separate passes; tools/pmc_traffic.sh)" + (f"; live attempt: {traffic_src}" if traffic_src else ""))
+                        break
+            M_, N_, K_ = (int(x) for x in dshape.split("/")[0].split("x"))
+            e_ = int(dshape.split("/e")[1])
+            algo_bytes = 2 * (M_ * K_ + N_ * K_) + 2 * M_ * (N_ // 2 if e_ == 2 else N_)
             result["roofline"] = {"bound": "mfma", "kernel": name, "shape": dshape,
                                   "kernel_all_shapes": {"launches": agg[name][2], "avg_launch_us": round(agg[name][0] / agg[name][2] * 1e6, 2),
                                                         "note": "what rocprofv3 --stats lists under this kernel name"},
                                   "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                                  "traffic_source": "profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                                    "x1024, separate passes; tools/pmc_traffic.sh)" % args.config if traffic else None,
+                                  "traffic_source": traffic_src, "algorithmic_bytes": algo_bytes,
+                                  "traffic_over_algorithmic": round(traffic / algo_bytes, 2) if traffic else None,
                                   "launches": n, "avg_launch_us": round(tsum / n * 1e6, 2),
                                   "avg_flop_per_launch": round(fsum / n / 1e9, 3),
                                   "share_of_step_time": round(tsum / rec_steps / (ms_step * 1e-3), 3),
@@ -371,7 +481,7 @@ def main():
                                                   for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(cfg, min(16, os.cpu_count() or 1))
+                result["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)

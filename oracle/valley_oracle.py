@@ -117,15 +117,18 @@ def clip_attention(x: torch.Tensor, w: Dict, p: str, heads: int) -> torch.Tensor
     return F.linear(o, _t(w, p + "out_proj.weight"), _t(w, p + "out_proj.bias"))
 
 
+def clip_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
+    """hf:clip/modeling_clip.py:338-350: fc2(quick_gelu(fc1(x))); p ends in 'mlp.'."""
+    h = F.linear(h, _t(w, p + "fc1.weight"), _t(w, p + "fc1.bias"))
+    return F.linear(quick_gelu(h), _t(w, p + "fc2.weight"), _t(w, p + "fc2.bias"))
+
+
 def clip_layer(x: torch.Tensor, w: Dict, p: str, cfg: VisionCfg) -> torch.Tensor:
     """hf:clip/modeling_clip.py:353-383 (pre-LN encoder layer)."""
     h = F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm1.weight"), _t(w, p + "layer_norm1.bias"), cfg.eps)
     x = x + clip_attention(h, w, p + "self_attn.", cfg.heads)
     h = F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm2.weight"), _t(w, p + "layer_norm2.bias"), cfg.eps)
-    h = F.linear(h, _t(w, p + "mlp.fc1.weight"), _t(w, p + "mlp.fc1.bias"))
-    h = quick_gelu(h)
-    h = F.linear(h, _t(w, p + "mlp.fc2.weight"), _t(w, p + "mlp.fc2.bias"))
-    return x + h
+    return x + clip_mlp(h, w, p + "mlp.")
 
 
 def clip_hidden_states(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, n_layers: Optional[int] = None,
@@ -302,15 +305,15 @@ def build_additive_mask(attention_mask: Optional[torch.Tensor], B: int, q_len: i
     return torch.where(allowed, 0.0, torch.finfo(torch.float32).min)
 
 
-def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
-                past: Optional[Tuple[torch.Tensor, torch.Tensor]]):
-    """hf:llama/modeling_llama.py:292-332 + 217-289."""
-    B, S, H = x.shape
+def llama_attention_block(h: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
+                          past: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """hf:llama/modeling_llama.py:217-289 (LlamaAttention.forward, eager): q/k/v projections, RoPE, KV concat,
+    softmax(QK^T * hd^-0.5 + mask) V in fp32, o_proj.  h [B,S,H] is the NORMED hidden state; p ends in 'self_attn.'."""
+    B, S, H = h.shape
     hd = H // cfg.heads
-    h = rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps)
-    q = F.linear(h, _t(w, p + "self_attn.q_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
-    k = F.linear(h, _t(w, p + "self_attn.k_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
-    v = F.linear(h, _t(w, p + "self_attn.v_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
+    q = F.linear(h, _t(w, p + "q_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
+    k = F.linear(h, _t(w, p + "k_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
+    v = F.linear(h, _t(w, p + "v_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
     q = apply_rope(q, cos, sin)
     k = apply_rope(k, cos, sin)
     if past is not None:
@@ -319,12 +322,24 @@ def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
     s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5) + mask
     a = torch.softmax(s, dim=-1, dtype=torch.float32)
     o = torch.matmul(a, v).transpose(1, 2).reshape(B, S, H)
-    x = x + F.linear(o, _t(w, p + "self_attn.o_proj.weight"))
+    return F.linear(o, _t(w, p + "o_proj.weight")), (k, v)
+
+
+def llama_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
+    """hf:llama/modeling_llama.py:160-173: down(silu(gate(x)) * up(x)); p ends in 'mlp.'."""
+    g = F.linear(h, _t(w, p + "gate_proj.weight"))
+    u = F.linear(h, _t(w, p + "up_proj.weight"))
+    return F.linear(F.silu(g) * u, _t(w, p + "down_proj.weight"))
+
+
+def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
+                past: Optional[Tuple[torch.Tensor, torch.Tensor]]):
+    """hf:llama/modeling_llama.py:292-332 (pre-norm decoder layer)."""
+    h = rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps)
+    o, kv = llama_attention_block(h, w, p + "self_attn.", cfg, cos, sin, mask, past)
+    x = x + o
     h = rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps)
-    g = F.linear(h, _t(w, p + "mlp.gate_proj.weight"))
-    u = F.linear(h, _t(w, p + "mlp.up_proj.weight"))
-    x = x + F.linear(F.silu(g) * u, _t(w, p + "mlp.down_proj.weight"))
-    return x, (k, v)
+    return x + llama_mlp(h, w, p + "mlp."), kv
 
 
 def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,

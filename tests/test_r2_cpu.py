@@ -1,0 +1,247 @@
+"""CPU tests of round 2: the oracle against the op-level / decode fixtures captured from HF + the reference
+(tools/gen_goldens_r2.py), the weight tools (apply_delta vs the reference function's own output, LoRA merge), the
+conversation templates, the extra entry-point surfaces, Auto* registration and the Pillow-exact host preprocessing."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import valley_oracle as O
+from tests import golden_cfg as G
+from tests.golden_r2_cfg import OPS, delta_states, op_input, op_weights
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 2e-5          # fp32 restatement vs fp32 HF modules: summation-order noise only
+
+
+def mx(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ---- G6: op-level fixtures -----------------------------------------------------------------------------------------
+def test_oracle_ops_vs_hf_submodules():
+    g = np.load(os.path.join(GOLD, "g6_ops.npz"))
+    o = OPS
+    with torch.no_grad():
+        x = t(op_input("rms.x", (5, o["H"])))
+        wn = t(op_weights("rms.w", (o["H"],), 0.1, 1.0))
+        for eps in (1e-5, 1e-6):                               # 1e-6 = the LLaMA-1 / Vicuna-13B setting
+            assert mx(O.rms_norm(x, wn, eps), g[f"rmsnorm_eps{eps:g}"]) < TOL
+        assert mx(g["rmsnorm_eps1e-05"], g["rmsnorm_eps1e-06"]) > 0       # the two settings are distinguishable
+        pos = torch.tensor([o["rope_positions"]])                          # {0, 1, 327, 2047}
+        cos, sin = O.rope_cos_sin(pos, 128, 10000.0)
+        assert mx(cos, g["rope_cos"]) < 1e-6 and mx(sin, g["rope_sin"]) < 1e-6
+        q, k = t(op_input("rope.q", (1, o["heads"], 4, 128))), t(op_input("rope.k", (1, o["heads"], 4, 128)))
+        assert mx(O.apply_rope(q, cos, sin), g["rope_q"]) < TOL and mx(O.apply_rope(k, cos, sin), g["rope_k"]) < TOL
+        # attention block, causal + left padding, head_dim 128
+        cfg = O.LlamaCfg(hidden=o["H"], heads=o["heads"], intermediate=o["I"], layers=1, eps=1e-6)
+        w = {f"a.{n}.weight": op_weights(f"att.{n}", (o["H"], o["H"]), 0.05) for n in ("q_proj", "k_proj", "v_proj", "o_proj")}
+        B, S = 2, o["S"]
+        h = t(op_input("att.h", (B, S, o["H"])))
+        am = torch.ones((B, S), dtype=torch.long)
+        am[1, :o["pad"]] = 0
+        cos, sin = O.rope_cos_sin(torch.arange(S)[None].expand(B, S), 128, 10000.0)
+        y, _ = O.llama_attention_block(h, w, "a.", cfg, cos, sin, O.build_additive_mask(am, B, S, S))
+        valid = am.bool().numpy()
+        assert mx(y.numpy()[valid], g["llama_attention"][valid]) < TOL
+        mw = {"m.gate_proj.weight": op_weights("mlp.gate", (o["I"], o["H"]), 0.05),
+              "m.up_proj.weight": op_weights("mlp.up", (o["I"], o["H"]), 0.05),
+              "m.down_proj.weight": op_weights("mlp.down", (o["H"], o["I"]), 0.05)}
+        assert mx(O.llama_mlp(t(op_input("mlp.x", (7, o["H"]))), mw, "m."), g["llama_mlp"]) < TOL
+        ln = torch.nn.functional.layer_norm(t(op_input("ln.x", (5, 1024))), (1024,), t(op_weights("ln.w", (1024,), 0.1, 1.0)),
+                                            t(op_weights("ln.b", (1024,), 0.1)), 1e-5)
+        assert mx(ln, g["layernorm"]) < TOL
+        cw = {"c.fc1.weight": op_weights("cmlp.fc1.w", (o["VI"], 1024), 0.03), "c.fc1.bias": op_weights("cmlp.fc1.b", (o["VI"],), 0.1),
+              "c.fc2.weight": op_weights("cmlp.fc2.w", (1024, o["VI"]), 0.03), "c.fc2.bias": op_weights("cmlp.fc2.b", (1024,), 0.1)}
+        assert mx(O.clip_mlp(t(op_input("cmlp.x", (9, 1024))), cw, "c."), g["clip_mlp"]) < TOL
+        aw = {}
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            aw[f"s.{n}.weight"], aw[f"s.{n}.bias"] = op_weights(f"catt.{n}.w", (1024, 1024), 0.03), op_weights(f"catt.{n}.b", (1024,), 0.1)
+        y = O.clip_attention(t(op_input("catt.x", (2, 257, 1024))), aw, "s.", 16)
+        assert mx(y.numpy()[:, ::4], g["clip_attention"]) < TOL
+
+
+def test_oracle_greedy_decode_vs_reference_loop():
+    """8 greedy KV steps (valley/serve/model_worker.py:371-394) on the prompt with unambiguous tokens."""
+    g = np.load(os.path.join(GOLD, "g5_decode2.npz"))
+    c = G.GCFG
+    lcfg = O.LlamaCfg(hidden=c["H"], heads=c["heads"], intermediate=c["I"], layers=c["L"], vocab=c["vocab"], eps=c["eps"])
+    vcfg = O.VisionCfg(intermediate=c["VI"], layers=c["VL"])
+    ids, _ = G.golden_ids("decode2")
+    assert np.array_equal(ids, g["ids"])
+    px = t(G.golden_pixels(c["T"], "mixed")).view(1, c["T"], 3, 224, 224)
+    with torch.no_grad():
+        toks, lasts = O.greedy_decode(t(ids), px, G.llama_state(), G.vision_state(), lcfg, vcfg, O.TokenIds(**G.special()), 8)
+    assert toks.tolist() == g["tokens"].tolist()
+    assert len(set(g["tokens"][0].tolist())) >= 4                         # not a repeat of one token
+    srt = np.sort(g["last_logits"][0], -1)
+    assert float((srt[:, -1] - srt[:, -2]).min()) > 0.2                   # unambiguous argmax at every step
+    assert mx(lasts, g["last_logits"]) < 5e-5
+
+
+# ---- weight tools ---------------------------------------------------------------------------------------------------
+def test_apply_delta_matches_reference_function():
+    from valley_amd.checkpoint import apply_delta, make_delta
+    g = np.load(os.path.join(GOLD, "g8_apply_delta.npz"))
+    base, delta, dims = delta_states()
+    delta = dict(delta)
+    delta["model.vision_tower.vision_model.pre_layrnorm.weight"] = np.ones(4, np.float32)   # a tower key: passes through
+    out = apply_delta({k: t(v) for k, v in base.items()}, {k: t(v) for k, v in delta.items()})
+    for k in g.files:
+        assert mx(out[k], g[k]) == 0.0, k                                  # fp32 adds: bit-exact vs the reference function
+    assert out["model.embed_tokens.weight"].shape[0] == dims["vocab"]
+    assert torch.equal(out["model.embed_tokens.weight"][dims["vocab_base"]:], t(delta["model.embed_tokens.weight"])[dims["vocab_base"]:])
+    assert torch.equal(out["model.mm_projector.weight"], t(delta["model.mm_projector.weight"]))
+    # round trip through make_delta
+    back = make_delta({k: t(v) for k, v in base.items()}, out)
+    for k, v in delta.items():
+        assert mx(back[k], v) < 1e-6, k
+    # the reference's assertions
+    bad = {k: t(v) for k, v in delta.items()}
+    bad["model.surprise.weight"] = torch.zeros(2)
+    with pytest.raises(AssertionError, match="model.surprise.weight not in base model"):
+        apply_delta({k: t(v) for k, v in base.items()}, bad)
+    bad = {k: t(v) for k, v in delta.items()}
+    bad["model.norm.weight"] = torch.zeros(dims["H"] + 1)
+    with pytest.raises(AssertionError, match="model.norm.weight dimension mismatch"):
+        apply_delta({k: t(v) for k, v in base.items()}, bad)
+
+
+def test_merge_lora_adapter(tmp_path):
+    """W <- W + (alpha / r) B A on the adapted projections (peft's merge rule, what run_valley.py:33-34 executes),
+    through the adapter-directory reader."""
+    from safetensors.torch import save_file
+    from valley_amd.checkpoint import merge_lora, read_lora_adapter
+    base, _, dims = delta_states()
+    sd = {k: t(v).clone() for k, v in base.items()}
+    H, r, alpha = dims["H"], 4, 8
+    gen = torch.Generator().manual_seed(3)
+    ad = {}
+    for n in ("q_proj", "v_proj"):
+        pre = f"base_model.model.model.layers.0.self_attn.{n}"
+        ad[pre + ".lora_A.weight"] = torch.randn(r, H, generator=gen) * 0.1
+        ad[pre + ".lora_B.weight"] = torch.randn(H, r, generator=gen) * 0.1
+    save_file(ad, str(tmp_path / "adapter_model.safetensors"))
+    (tmp_path / "adapter_config.json").write_text(json.dumps(dict(r=r, lora_alpha=alpha, target_modules=["q_proj", "v_proj"],
+                                                                   base_model_name_or_path="unused", fan_in_fan_out=False)))
+    cfg, asd = read_lora_adapter(str(tmp_path))
+    out = merge_lora(sd, cfg, asd)
+    for n in ("q_proj", "v_proj"):
+        k = f"model.layers.0.self_attn.{n}.weight"
+        pre = f"base_model.model.model.layers.0.self_attn.{n}"
+        want = sd[k] + (alpha / r) * ad[pre + ".lora_B.weight"] @ ad[pre + ".lora_A.weight"]
+        assert mx(out[k], want) < 1e-6
+    untouched = "model.layers.0.self_attn.k_proj.weight"
+    assert torch.equal(out[untouched], sd[untouched])
+    with pytest.raises(KeyError):
+        merge_lora(sd, cfg, {"base_model.model.model.layers.9.self_attn.q_proj.lora_A.weight": torch.zeros(r, H),
+                             "base_model.model.model.layers.9.self_attn.q_proj.lora_B.weight": torch.zeros(H, r)})
+
+
+# ---- prompt / entry-point surfaces ----------------------------------------------------------------------------------
+def test_conversation_templates_match_reference():
+    from valley.conversation import SeparatorStyle, conv_templates
+    g = json.load(open(os.path.join(GOLD, "g9_conversation.json")))
+    for name, want in g.items():
+        conv = conv_templates[name].copy()
+        got = [conv.get_prompt()]
+        conv.append_message(conv.roles[0], "what happens?\n<im_start><im_patch><im_end>")
+        got.append(conv.get_prompt())
+        conv.append_message(conv.roles[1], None)
+        got.append(conv.get_prompt())
+        conv.messages[-1][1] = "a dog runs\n"
+        conv.append_message(conv.roles[0], ("and then?", "/tmp/x.mp4", "Crop"))
+        got.append(conv.get_prompt())
+        assert got == want["prompts"], name
+        assert conv.sep == want["sep"] and list(conv.roles) == want["roles"] and conv.offset == want["offset"]
+        assert conv.sep_style == SeparatorStyle.SINGLE
+        assert conv_templates[name].messages == conv_templates[name].copy().messages and not conv_templates[name].has_video
+
+
+def test_v2_and_conv_entry_surfaces():
+    from types import SimpleNamespace
+
+    import valley.inference.run_valley_conv as rc
+    import valley.inference.run_valley_llamma_v2 as r2
+    from tests.fake_tokenizer import FakeTokenizer
+    from valley_amd import cli
+    m = r2.v2_message()
+    assert [x["role"] for x in m] == ["system", "user", "assistent", "user"]              # the reference's spelling (:67)
+    assert m[3]["content"] == "<video> Describe the video concisely." and m[0]["content"] == r2.system_prompt
+    assert r2.gen_kwargs == dict(do_sample=True, temperature=0.2, max_new_tokens=1024) and r2.VALLEY2_7B == "luoruipu1/Valley2-7b"
+    assert callable(r2.main_v2) and callable(r2.init_vision_token)
+    # run_valley_conv: token binding with and without mm_use_im_start_end, the first-turn visual block, the clean-up
+    for use_se in (False, True):
+        tok = FakeTokenizer()
+        if use_se:
+            tok.add_tokens(["<vi_frame>", "<vi_start>", "<vi_end>"], special_tokens=True)   # added at training time
+        vc = SimpleNamespace(image_size=224, patch_size=14)
+        model = SimpleNamespace(config=SimpleNamespace(mm_use_im_start_end=use_se),
+                                get_model=lambda vc=vc: SimpleNamespace(vision_tower=SimpleNamespace(config=vc)))
+        assert cli.conv_bind_tokens(model, tok) == 256
+        assert vc.im_patch_token == tok.special["<im_patch>"] and vc.use_im_start_end == use_se
+        assert hasattr(vc, "vi_frame_token") == use_se
+    turn = cli.conv_user_turn("what is this", 8, 256, True)
+    assert turn == "what is this\n<im_start>" + "<im_patch>" * 256 + "<im_end><vi_start>" + "<vi_frame>" * 8 + "<vi_end>"
+    assert cli.conv_user_turn("q", 8, 256, False) == "q\n" + "<im_patch>" * 256
+    assert cli.conv_clean("### Assistant: a dog\nruns ### Human: next") == "a dogruns\n"
+    assert cli.conv_clean("LLaVA: hi") == "hi\n"
+    a = rc.conv_parse_args([])
+    assert a.conv_mode == "v1" and a.model_name.endswith("stable-valley-13b-v1/") and callable(rc.inference) and callable(rc.assistant_out)
+
+
+def test_auto_registration():
+    """valley_model.py:441-442."""
+    from transformers import AutoConfig, AutoModelForCausalLM
+    from valley.model.valley_model import ValleyConfig, ValleyLlamaForCausalLM
+    cfg = AutoConfig.for_model("valley", hidden_size=256, num_attention_heads=2, num_hidden_layers=1, intermediate_size=512)
+    assert type(cfg) is ValleyConfig and cfg.model_type == "valley"
+    assert AutoModelForCausalLM._model_mapping[ValleyConfig] is ValleyLlamaForCausalLM
+
+
+def test_lora_model_names_take_the_adapter_branch(monkeypatch):
+    """run_valley.py:26: 'lora' in the model name selects the adapter branch (merge, tokenizer from the base path)."""
+    from valley_amd import cli
+    seen = {}
+    monkeypatch.setattr(cli, "_require_gpu", lambda: torch.device("cpu"))
+    def fake_load_lora(path, device):
+        seen["path"] = path
+        return _Dummy(), "tok"
+    monkeypatch.setattr(cli, "load_lora", fake_load_lora)
+    monkeypatch.setattr(cli, "init_vision_token", lambda m, tk: seen.setdefault("bound", tk))
+    model, tok = cli.load("/ckpt/valley-7b-lora-v2")
+    assert seen == {"path": "/ckpt/valley-7b-lora-v2", "bound": "tok"} and tok == "tok"
+
+
+class _Dummy:
+    def to(self, *_):
+        return self
+
+    def eval(self):
+        return self
+
+
+# ---- host preprocessing ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 360, 480), (2, 480, 270), (2, 256, 341), (1, 719, 1279)])
+def test_load_video_host_path_is_pillow_exact(shape):
+    """valley_amd.video.preprocess_frames (the CPU leg of load_video: PIL does the resample, as in the reference chain)
+    equals the preprocessing oracle — itself bit-exact vs PIL and pinned to the reference's transform classes — and so
+    agrees with the GPU kernels the same oracle checks (test_preprocess_frames_gpu_vs_oracle)."""
+    from oracle import preprocess_oracle as P
+    from valley_amd import video
+    if torch.cuda.is_available():
+        pytest.skip("with a GPU preprocess_frames routes through the HIP kernels (covered by the -m gpu test)")
+    T, H, W = shape
+    frames = np.random.default_rng(H * 7 + W).integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+    got = video.preprocess_frames(frames)
+    ref = P.preprocess_frames(frames)
+    assert tuple(got.shape) == (3, T, 224, 224)
+    assert mx(got, ref) < 1e-6
+    lv = video.load_video(frames, fixed_frame_number=T)
+    assert mx(lv, ref) < 1e-6

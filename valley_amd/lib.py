@@ -6,11 +6,13 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 from . import build as _build
 
 _LIB = None
+_LOAD_LOCK = threading.Lock()
 
 _P = c_void_p
 _SIGS = {
@@ -63,6 +65,14 @@ def lib_path() -> str:
 
 def load():
     """Load (once) and type the shared library.  Raises if it is absent or stale."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOAD_LOCK:
+        return _load_locked()
+
+
+def _load_locked():
     global _LIB
     if _LIB is not None:
         return _LIB

@@ -158,8 +158,12 @@ class HipLlama:
             raise ValueError(f"KV cache overflow: {past}+{S} > {cache.ctx_max}")
         if cache.batch != B:
             raise ValueError("cache batch mismatch")
+        ops.sk_check_polled(self.device)                   # a stream-K hand-off failure of an earlier call surfaces here
         with runtime.stream_lock():                        # launch sequences on one stream must not interleave
-            return self._forward_locked(h, B, S, cache, past, n_layers)
+            out = self._forward_locked(h, B, S, cache, past, n_layers)
+            if S > 1:
+                ops.sk_poll_async(self.device)
+            return out
 
     def _forward_locked(self, h, B, S, cache, past, n_layers):
         M = B * S

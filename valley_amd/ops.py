@@ -6,6 +6,7 @@ error codes."""
 from __future__ import annotations
 
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -127,11 +128,14 @@ def gemm_mfma(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch
     return _gemm_common("vly_gemm_bf16", a, w, bias, residual, epilogue, out_dtype, out, (tile_hint,))
 
 
-_SK_WS = {}          # device index -> [workspace tensor, epoch]
+_SK_WS = {}          # (device index, stream) -> [workspace tensor, epoch]
+_SK_OWNER = {}       # device index -> the ONE stream allowed to launch the persistent stream-K kernel
+_SK_POLL = {}        # device index -> [pinned int32 host copy of the error flag, copy issued?]
+_SK_LOCK = threading.Lock()
 
 
 def _sk_workspace(device):
-    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))   # launches on different streams overlap
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
     ent = _SK_WS.get(key)
     if ent is None:
         nbytes = _lib.load().vly_gemm_streamk_workspace_bytes()
@@ -141,14 +145,52 @@ def _sk_workspace(device):
     return ent[0], ent[1]
 
 
+def sk_stream_allowed(device) -> bool:
+    """The stream-K kernel is only correct if every workgroup of its grid (CUs x PER_CU) becomes resident while its
+    owners spin: two such kernels on different HIP streams can each hold CUs the other's contributors need.  So the
+    first stream that launches it on a device owns it; launch sequences on any other stream get the whole-tile kernel
+    (same result up to fp32 summation order)."""
+    sid = int(torch.cuda.current_stream(device).cuda_stream)
+    with _SK_LOCK:
+        return _SK_OWNER.setdefault(device.index, sid) == sid
+
+
 def sk_error_flag(device) -> int:
-    """Non-zero if a stream-K owner ever gave up waiting for a contributor (should never happen)."""
+    """Non-zero if a stream-K owner ever gave up waiting for a contributor (should never happen).  Synchronises."""
     idx = torch.device(device).index or 0
     return max([int(ent[0][4000].item()) for key, ent in list(_SK_WS.items()) if key[0] == idx] or [0])
 
 
+def sk_poll_async(device) -> None:
+    """Queue a copy of the stream-K error flag into pinned host memory behind the work already on the current stream
+    (called by the engines at the end of a launch sequence that used stream-K: one 4-byte copy per forward)."""
+    idx = torch.device(device).index or 0
+    ent = _SK_WS.get((idx, int(torch.cuda.current_stream(device).cuda_stream)))
+    if ent is None or ent[1] == 0:
+        return
+    poll = _SK_POLL.get(idx)
+    if poll is None:
+        poll = _SK_POLL[idx] = [torch.zeros(1, dtype=torch.int32, pin_memory=True), False]
+    poll[0].copy_(ent[0][4000:4001], non_blocking=True)
+    poll[1] = True
+
+
+def sk_check_polled(device) -> None:
+    """Raise if a previously polled error flag came back non-zero (no synchronisation: reads what has landed; the
+    engines call this at the start of every forward and generate() after its last token, so a wrong tile is reported at
+    the latest one call after it was produced)."""
+    poll = _SK_POLL.get(torch.device(device).index or 0)
+    if poll is not None and poll[1] and int(poll[0][0]) != 0:
+        raise _lib.ValleyHipError("stream-K GEMM: an owner workgroup gave up waiting for a contributor (error flag 0x%X): "
+                                  "results of that launch are invalid" % int(poll[0][0]))
+
+
 def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None, tile_hint=0):
-    """Persistent stream-K MFMA kernel: same contract as gemm_mfma, balanced over all CUs."""
+    """Persistent stream-K MFMA kernel: same contract as gemm_mfma, balanced over all CUs.  One stream per device
+    may use it (sk_stream_allowed)."""
+    if not sk_stream_allowed(a.device):
+        raise _lib.ValleyHipError("vly_gemm_bf16_streamk: the persistent kernel is owned by another HIP stream of this device "
+                                  "(two concurrent stream-K grids can starve each other's contributors); use gemm_mfma here")
     ws, epoch = _sk_workspace(a.device)
     return _gemm_common("vly_gemm_bf16_streamk", a, w, bias, residual, epilogue, out_dtype, out,
                         (tile_hint, ws.data_ptr(), ws.numel() * 4, epoch))
@@ -225,6 +267,16 @@ CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 7
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 TUNE_FINALISTS = 4   # after TUNE_TRIALS calls per candidate the best few are re-timed to 3 x TUNE_TRIALS calls each
 _ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
+_TUNE_LOCK = threading.RLock()       # _ONLINE / _TUNED / the cache file are shared by every thread that calls gemm()
+_STREAMS_SEEN = set()                # HIP streams that ever issued a tuned GEMM in this process
+
+
+def _multi_stream() -> bool:
+    """True once GEMMs have been issued on more than one HIP stream: timings taken while another stream runs are
+    polluted (a bad kernel could be fixed for good via VALLEY_TUNE_CACHE), so undecided shapes then take the static
+    whole-tile choice instead of a timing trial."""
+    _STREAMS_SEEN.add(int(torch.cuda.current_stream().cuda_stream))
+    return len(_STREAMS_SEEN) > 1
 
 
 def _tune_key(M, N, K, epi, dtype, has_bias, has_res, w):
@@ -279,8 +331,15 @@ def gemm2(a, w, out, out2, bias=None) -> int:
     N, K = w.shape
     key = _tune_key(M, N, K, EPI_PAIR, out.dtype, bias is not None, False, w)
     choice = _TUNED.get(key)
+    multi = _multi_stream()
     if choice is None:
+        if multi:
+            gemm_mfma(a, w, bias, out=out)
+            return 1
         return _online_trial(key, a, w, bias, None, EPI_NONE, out.dtype, out, out2, CANDIDATES + SPLIT_CANDIDATES)[1]
+    if choice[0] == "sk" and not sk_stream_allowed(a.device):
+        gemm_mfma(a, w, bias, out=out)
+        return 1
     return _run_candidate(choice, a, w, bias, None, EPI_NONE, out.dtype, out, out2)[1]
 
 
@@ -296,6 +355,11 @@ def _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2=No
 
 def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out, out2=None, candidates=None):
     """One call while `key` is undecided; returns (result, number of partial outputs)."""
+    with _TUNE_LOCK:
+        return _online_trial_locked(key, a, w, bias, residual, epilogue, out_dtype, out, out2, candidates)
+
+
+def _online_trial_locked(key, a, w, bias, residual, epilogue, out_dtype, out, out2, candidates):
     st = _ONLINE.get(key)
     if st is None:
         cl = list(candidates if candidates is not None else CANDIDATES)
@@ -337,6 +401,8 @@ def _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out, out2=None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         try:
+            if cand[0] == "sk" and not sk_stream_allowed(a.device):
+                raise _lib.ValleyHipError("stream-K belongs to another stream")
             res = _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2)
         except _lib.ValleyHipError:                       # configuration not available for this shape
             st["cands"].remove(cand)
@@ -376,9 +442,10 @@ def _tune(key, a, w, bias, residual, epilogue, out):
             continue
         if dt < best_t:
             best, best_t = (kind, t), dt
-    _TUNED[key] = best
-    if _TUNE_CACHE:
-        save_tune_cache(_TUNE_CACHE)
+    with _TUNE_LOCK:
+        _TUNED[key] = best
+        if _TUNE_CACHE:
+            save_tune_cache(_TUNE_CACHE)
     return best
 
 
@@ -391,8 +458,10 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
         return gemv(a, w, bias, residual, epilogue, out_dtype, out)
     if GEMM_MODE == "tiles" or tile_hint:
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, tile_hint)
-    if GEMM_MODE == "streamk":
+    if GEMM_MODE == "streamk" and sk_stream_allowed(a.device):
         return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, 0)
+    if GEMM_MODE == "streamk":
+        return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, 0)
     N, K = w.shape
     if out is None:
         out = torch.empty((M, N // 2 if epilogue == EPI_SWIGLU else N), dtype=out_dtype, device=a.device)
@@ -408,12 +477,15 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
                 choice = _tune(key, a, w, bias, residual, epilogue, out)
             finally:
                 set_recorder(rec)
+        elif _multi_stream():
+            choice = ("tile", 0)
         else:
             return _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out)[0]
     kind, t = choice
     if kind == "tile":
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t)
-    if torch.cuda.is_current_stream_capturing():           # the stream-K workspace is per stream: none inside a capture
+    # the stream-K workspace is per stream (none inside a capture) and the kernel itself belongs to one stream
+    if torch.cuda.is_current_stream_capturing() or not sk_stream_allowed(a.device):
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, 0)
     return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, t)
 

@@ -16,7 +16,7 @@ latency-, not bandwidth-bound, and a single call per step is the right granulari
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -52,10 +52,14 @@ def all_gather_rows(local: torch.Tensor, rows_per_rank: Sequence[int], group=Non
 
 
 def encode_clips_dp(encode_pool: Callable[[list], Tuple[torch.Tensor, List[int]]], clips: Sequence[torch.Tensor],
-                    group=None) -> Tuple[torch.Tensor, List[int]]:
+                    group=None, width: Optional[int] = None, device=None) -> Tuple[torch.Tensor, List[int]]:
     """``clips`` mode.  ``encode_pool(list_of_clips) -> (pooled [sum(256+T_i), W], Ts)`` is the local
     encoder (``ValleyLlamaModel.encode_clips``).  Every rank passes the SAME full clip list (or at
-    least agrees on the frame counts); returns pooled tokens of ALL clips in order, on every rank."""
+    least agrees on the frame counts); returns pooled tokens of ALL clips in order, on every rank.
+    W is 1024 for mean pooling and H for the variants that project before pooling; a rank without clips (more ranks
+    than clips) contributes an empty [0, W] shard — W and the device come from ``width`` / ``device`` when given, else W
+    is agreed with one tiny MAX all-reduce (taken by every rank, only when some rank is idle) and the device is the
+    rank's current accelerator (CPU tensors for CPU clips under gloo)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     Ts = [int(c.shape[0]) for c in clips]
     s, e = shard_range(len(clips), rank, world)
@@ -63,11 +67,18 @@ def encode_clips_dp(encode_pool: Callable[[list], Tuple[torch.Tensor, List[int]]
     for r in range(world):
         a, b = shard_range(len(clips), r, world)
         rows.append(sum(256 + t for t in Ts[a:b]))
-    if e > s:
-        local, _ = encode_pool(list(clips[s:e]))
-    else:
-        ref = clips[0]
-        local = torch.empty((0, 1024), dtype=torch.bfloat16, device=ref.device)
+    local = encode_pool(list(clips[s:e]))[0] if e > s else None
+    if min(rows) == 0:                                       # every rank sees the same `rows`: same branch everywhere
+        if device is None:
+            device = local.device if local is not None else \
+                (torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and clips[0].is_cuda or
+                                                                        dist.get_backend(group) == "nccl") else torch.device("cpu"))
+        if width is None:
+            wt = torch.tensor([0 if local is None else local.shape[1]], dtype=torch.int64, device=device)
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX, group=group)
+            width = int(wt.item())
+        if local is None:
+            local = torch.empty((0, width), dtype=torch.bfloat16, device=device)
     return all_gather_rows(local, rows, group), Ts
 
 

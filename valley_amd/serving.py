@@ -19,7 +19,7 @@ from .valley_model import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT
                            DEFAULT_VI_START_TOKEN, DEFAULT_VIDEO_FRAME_TOKEN, DEFAULT_VIDEO_TOKEN)
 
 
-def expand_video_prompt(prompt: str, n_frames: int, use_im_start_end: bool = True) -> str:
+def expand_video_prompt(prompt: str, n_frames: int, use_im_start_end: bool = False) -> str:
     """model_worker.py:338-341."""
     replace_token = DEFAULT_IMAGE_PATCH_TOKEN * 256
     if use_im_start_end:
@@ -38,7 +38,7 @@ def generate_video_stream(model, tokenizer, params: dict, video: Optional[torch.
     if video is not None:
         assert prompt.count(DEFAULT_VIDEO_TOKEN) == 1, "Number of video does not match number of <video> tokens in prompt"
         frames = video.permute(1, 0, 2, 3)
-        prompt = expand_video_prompt(prompt, frames.shape[0], getattr(model.config, "mm_use_im_start_end", True))
+        prompt = expand_video_prompt(prompt, frames.shape[0], getattr(model.config, "mm_use_im_start_end", False))
         images = frames.unsqueeze(0)
     temperature = float(params.get("temperature", 1.0))
     max_new_tokens = min(int(params.get("max_new_tokens", 256)), 1024)

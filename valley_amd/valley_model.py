@@ -150,7 +150,7 @@ class ValleyLlamaModel:
             sd = {k.split(".")[-1]: v for k, v in sd.items()}
             self.mm_projector = HipLinear(sd["weight"].to(self.device, torch.bfloat16).contiguous(),
                                           sd["bias"].to(self.device, torch.float32).contiguous())
-        return dict(image_processor=None, image_token_len=num_patches, vision_config=vc)
+        return dict(image_processor=_clip_image_processor(vision_tower, vc), image_token_len=num_patches, vision_config=vc)
 
     # ---- visual tokens -----------------------------------------------------------------------------
     def encode_clips(self, images) -> (torch.Tensor, List[int]):
@@ -261,7 +261,13 @@ class ValleyLlamaModel:
             B, S = input_ids.shape
             h = self.embed_inputs(input_ids, images, visual_tokens, frames_per_clip)
         cache = past_key_values
-        if cache is None or not isinstance(cache, HipKVCache):
+        if cache is not None and not isinstance(cache, HipKVCache):
+            if len(cache) and (not hasattr(cache, "get_seq_length") or cache.get_seq_length()):
+                raise TypeError(f"past_key_values must be the HipKVCache a previous forward returned, got {type(cache).__name__}: "
+                                "a foreign (HF tuple / DynamicCache) cache cannot be continued on the HIP path")
+            cache = None                                       # an EMPTY foreign cache (HF generate's step 0) starts fresh
+        if cache is None:
+            # sized for what the caller can still append: the whole context when the cache is handed back, else S
             ctx = max(getattr(self.config, "max_position_embeddings", 2048), S)
             cache = self.llama.new_cache(B, ctx if use_cache else S)
         if attention_mask is not None:
@@ -275,6 +281,21 @@ class ValleyLlamaModel:
         return BaseModelOutputWithPast(last_hidden_state=x.view(B, S, -1), past_key_values=cache if use_cache else None)
 
     __call__ = forward
+
+
+def _clip_image_processor(name_or_tower, vc):
+    """valley_model.py:63,99-103 returns ``CLIPImageProcessor.from_pretrained(vision_tower)``.  From a local checkpoint
+    directory that is what is loaded; otherwise (no hub access) the processor is built from CLIP's published
+    preprocessing constants — short side to ``image_size``, centre crop, CLIP mean/std — which is what the
+    ``openai/clip-vit-large-patch14`` preprocessor_config.json holds."""
+    try:
+        from transformers import CLIPImageProcessor
+        if isinstance(name_or_tower, str) and os.path.isdir(name_or_tower) and \
+                os.path.exists(os.path.join(name_or_tower, "preprocessor_config.json")):
+            return CLIPImageProcessor.from_pretrained(name_or_tower)
+        return CLIPImageProcessor(size={"shortest_edge": vc.image_size}, crop_size={"height": vc.image_size, "width": vc.image_size})
+    except Exception:  # noqa: BLE001 - transformers build without any image backend
+        return None
 
 
 def _rope_theta(c) -> float:
@@ -339,9 +360,12 @@ class ValleyLlamaForCausalLM:
                 pos=_dev(sd["model.position_matrix"], d, f32))
         vt = {k[len("model.vision_tower."):]: v for k, v in sd.items() if k.startswith("model.vision_tower.")}
         if vt:
-            if self.model.vision_tower is None:
+            created = self.model.vision_tower is None
+            if created:
                 self.model.vision_tower = build_vision_tower(None, device=self.device)
-            self.model.vision_tower.load_state_dict(vt)
+            # a model checkpoint stores its whole tower (save_pretrained): when this model had to create the tower
+            # object itself, from defaults, the stored depth is the tower's depth
+            self.model.vision_tower.load_state_dict(vt, shallow_ok=created)
         return self
 
     @classmethod
@@ -350,6 +374,12 @@ class ValleyLlamaForCausalLM:
         from .checkpoint import load_valley_checkpoint
         config, sd = load_valley_checkpoint(path, ValleyConfig)
         config.mm_vision_tower_name = getattr(config, "mm_vision_tower", None)
+        return cls.from_state_dict(config, sd, device=device)
+
+    @classmethod
+    def from_state_dict(cls, config, sd: Dict, device="cuda:0"):
+        """Model from an in-memory state dict with the reference's key names (what from_pretrained, the delta tool and
+        the LoRA merge all end in)."""
         tower_name = getattr(config, "mm_vision_tower", None)
         if tower_name is not None and not os.path.isdir(str(tower_name)):
             config.mm_vision_tower = None                    # no hub access: the tower must come from the state dict
@@ -408,9 +438,19 @@ class ValleyLlamaForCausalLM:
         out = self.forward(input_ids=input_ids, images=images, attention_mask=attention_mask, past_key_values=cache,
                            use_cache=True)
         greedy = not (do_sample and temperature >= 1e-4)
-        last = out.logits[:, -1, :].contiguous()
-        token = ops.argmax(last).to(torch.long) if greedy else \
-            torch.multinomial(torch.softmax(last / temperature, dim=-1), num_samples=1).view(B)
+
+        def pick(last):
+            return ops.argmax(last).to(torch.long) if greedy else \
+                torch.multinomial(torch.softmax(last / temperature, dim=-1), num_samples=1).view(B)
+
+        eos = None
+        if eos_token_id is not None:
+            eos = torch.as_tensor([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id), device=self.device)
+        pad = kw.get("pad_token_id", getattr(self.config, "pad_token_id", None))
+        if pad is None:
+            pad = int(eos[0]) if eos is not None else 0
+        finished = torch.zeros((B,), dtype=torch.bool, device=self.device)     # HF: a finished row emits pad from then on
+        token = pick(out.logits[:, -1, :].contiguous())
         seq = torch.cat([input_ids, token[:, None]], dim=1)
         if B > 8:
             use_graph = None                                 # GEMV decode path is for <= 8 sequences
@@ -421,27 +461,30 @@ class ValleyLlamaForCausalLM:
             sess.begin(token)
         mask = attention_mask
         for _ in range(max_new_tokens - 1):
-            if eos_token_id is not None and bool((token == eos_token_id).all()):
-                break
-            if stopping_criteria is not None and all(bool(c(seq, None)) for c in stopping_criteria):
-                break
-            if cache.seq_len + 1 > cache.ctx_max:
+            if eos is not None:
+                finished |= torch.isin(token, eos)
+            if stopping_criteria is not None:
+                # HF StoppingCriteriaList: generation stops as soon as ANY criterion fires; a criterion may answer
+                # per row (bool tensor [B]) or for the whole batch (python bool, as the reference's keyword criterion)
+                for c in stopping_criteria:
+                    r = c(seq, None)
+                    finished |= r.to(self.device).view(-1) if isinstance(r, torch.Tensor) else torch.full_like(finished, bool(r))
+            if bool(finished.all()) or cache.seq_len + 1 > cache.ctx_max:
                 break
             if sess is not None:
                 nxt = sess.step()
                 if greedy:
                     token = nxt.to(torch.long).clone()
                 else:
-                    probs = torch.softmax(sess.logits[:, :self.model.llama.V] / temperature, dim=-1)
-                    token = torch.multinomial(probs, num_samples=1).view(B)
+                    token = pick(sess.logits[:, :self.model.llama.V])
+                if bool(finished.any()) or not greedy:
+                    token = torch.where(finished, torch.full_like(token, pad), token)
                     sess.tok.copy_(token.to(torch.int32))
             else:
                 if mask is not None:
                     mask = torch.cat([mask.to(self.device), torch.ones((B, 1), dtype=mask.dtype, device=self.device)], dim=1)
                 out = self.forward(input_ids=token[:, None], attention_mask=mask, past_key_values=cache, use_cache=True)
-                last = out.logits[:, -1, :].contiguous()
-                token = ops.argmax(last).to(torch.long) if greedy else \
-                    torch.multinomial(torch.softmax(last / temperature, dim=-1), num_samples=1).view(B)
+                token = torch.where(finished, torch.full_like(token, pad), pick(out.logits[:, -1, :].contiguous()))
             seq = torch.cat([seq, token[:, None]], dim=1)
         return seq
 
@@ -547,3 +590,21 @@ def _dev(t, device, dtype):
     if not isinstance(t, torch.Tensor):
         t = torch.from_numpy(np.ascontiguousarray(t))
     return t.to(device=device, dtype=dtype).contiguous()
+
+
+def _register_auto():
+    """valley_model.py:441-442: ``AutoConfig.register("valley", ValleyConfig)`` and
+    ``AutoModelForCausalLM.register(ValleyConfig, ValleyLlamaForCausalLM)`` so that ``AutoConfig.from_pretrained`` /
+    ``AutoModelForCausalLM.from_pretrained`` on a Valley checkpoint resolve to this implementation."""
+    if LlamaConfig is None:
+        return False
+    try:
+        from transformers import AutoConfig, AutoModelForCausalLM
+        AutoConfig.register("valley", ValleyConfig, exist_ok=True)
+        AutoModelForCausalLM.register(ValleyConfig, ValleyLlamaForCausalLM, exist_ok=True)
+        return True
+    except Exception:  # noqa: BLE001 - a transformers build that refuses non-PreTrainedModel classes
+        return False
+
+
+AUTO_REGISTERED = _register_auto()

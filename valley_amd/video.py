@@ -41,19 +41,36 @@ def sample_indices(n_total: int, n: int = 8) -> np.ndarray:
 
 
 def preprocess_frames(frames_u8: np.ndarray, scale_size: int = 256, crop: int = 224) -> torch.Tensor:
-    """uint8 [T,H,W,3] -> float32 [3,T,224,224], the tensor layout ``load_video`` returns."""
-    x = torch.from_numpy(np.ascontiguousarray(frames_u8)).permute(0, 3, 1, 2).float()      # [T,3,H,W]
-    _, _, H, W = x.shape
-    if H <= W:
-        nh, nw = scale_size, int(round(W * scale_size / H))
-    else:
-        nh, nw = int(round(H * scale_size / W)), scale_size
-    x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)
-    t, l = int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
-    x = x[:, :, t:t + crop, l:l + crop] / 255.0
-    mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
-    std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
-    return ((x - mean) / std).permute(1, 0, 2, 3).contiguous()
+    """uint8 [T,H,W,3] -> float32 [3,T,224,224], the tensor ``load_video`` returns (valley/util/data_util.py:262-281):
+    short side to 256 with PIL's BILINEAR resample (which antialiases when it shrinks; target size floor-rounded,
+    valley/data/video_transform.py:74-81), centre crop 224 (offset ``int(round((w - 224) / 2.))``, :542-544), /255,
+    CLIP mean/std.  With a GPU the frames go through the Pillow-exact HIP kernels (valley_amd/preprocess.py) and the
+    result stays on the device; without one this is the reference's own host chain, PIL itself doing the resample —
+    both entry points of the model therefore see the same pixels (tests/test_preprocess_cpu.py)."""
+    frames_u8 = np.ascontiguousarray(frames_u8)
+    if torch.cuda.is_available():
+        from .preprocess import preprocess_frames_gpu
+        out = preprocess_frames_gpu(torch.from_numpy(frames_u8).cuda(), out_dtype=torch.float32, scale_size=scale_size, crop=crop)
+        return out.permute(1, 0, 2, 3).contiguous()
+    from PIL import Image
+
+    from .preprocess import resize_sizes
+    T, H, W, _ = frames_u8.shape
+    nh, nw = resize_sizes(H, W, scale_size)
+    if nh < crop or nw < crop:
+        raise ValueError(f"Initial image size should be larger then cropped size but got cropped sizes : ({crop}, {crop}) "
+                         f"while initial image is ({nw}, {nh})")
+    x1, y1 = int(round((nw - crop) / 2.0)), int(round((nh - crop) / 2.0))
+    out = np.empty((T, crop, crop, 3), np.float32)
+    for t in range(T):
+        im = Image.fromarray(frames_u8[t])
+        if (nh, nw) != (H, W):
+            im = im.resize((nw, nh), Image.BILINEAR)
+        out[t] = np.asarray(im, dtype=np.float32)[y1:y1 + crop, x1:x1 + crop]
+    x = torch.from_numpy(out).permute(3, 0, 1, 2) / 255.0                                  # [3,T,224,224]
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1, 1)
+    return ((x - mean) / std).contiguous()
 
 
 def load_video(path, fixed_frame_number: int = 8) -> torch.Tensor:

@@ -56,7 +56,7 @@ class HipCLIPVisionTower:
         self._ws = {}
 
     # ---- weights -------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Dict, prefix: str = "") -> "HipCLIPVisionTower":
+    def load_state_dict(self, sd: Dict, prefix: str = "", truncated_ok: bool = False, shallow_ok: bool = False) -> "HipCLIPVisionTower":
         """HF CLIPVisionModel key names, flat (transformers 5.x) or with the ``vision_model.`` prefix of
         the pinned commit."""
         if prefix == "" and any(k.startswith("vision_model.") for k in sd):
@@ -87,10 +87,17 @@ class HipCLIPVisionTower:
         if self.layers and self.layers[0]["w_fc1"].shape[0] != c.intermediate_size:
             c.intermediate_size = int(self.layers[0]["w_fc1"].shape[0])     # trust the checkpoint
             self._ws.clear()
-        if len(self.layers) < c.num_hidden_layers and (prefix + f"encoder.layers.{len(self.layers)}.layer_norm1.weight") not in sd \
-                and not getattr(c, "truncated_ok", False):
-            # a checkpoint of a shallower tower: hidden_states indexing follows the real depth
-            c.num_hidden_layers = len(self.layers)
+        if len(self.layers) < c.num_hidden_layers:
+            # fewer layers than the config says: either a SHALLOWER tower (then hidden_states indexing must follow the
+            # real depth — say so with shallow_ok=True) or a tower TRUNCATED to the layers hidden_states[select] needs
+            # (depth and indexing stay as configured — truncated_ok=True).  Guessing silently would make
+            # select_layer=-2 resolve to the wrong layer, so anything else is an error.
+            if shallow_ok:
+                c.num_hidden_layers = len(self.layers)
+            elif not (truncated_ok or getattr(c, "truncated_ok", False)):
+                raise ValueError(f"vision tower state dict holds {len(self.layers)} encoder layers, config says "
+                                 f"{c.num_hidden_layers}: pass truncated_ok=True (layers cut after the selected one) or "
+                                 f"shallow_ok=True (a shallower tower)")
         self.loaded = True
         return self
 
@@ -187,8 +194,11 @@ class HipCLIPVisionTower:
         nl = self.n_layers_for(select_layer)
         if nl > len(self.layers):
             raise RuntimeError(f"need {nl} encoder layers, tower holds {len(self.layers)}")
+        ops.sk_check_polled(self.device)                   # a stream-K hand-off failure of an earlier call surfaces here
         with runtime.stream_lock():                        # launch sequences on one stream must not interleave
-            return self._encode_locked(frames, nl, chunk, keep_all)
+            out = self._encode_locked(frames, nl, chunk, keep_all)
+            ops.sk_poll_async(self.device)
+            return out
 
     def _encode_locked(self, frames: torch.Tensor, nl: int, chunk: int, keep_all: bool):
         Ftot = frames.shape[0]
