@@ -391,3 +391,73 @@ def greedy_decode(input_ids: torch.Tensor, images, w, vw, lcfg, vcfg, tok, steps
         out_tokens.append(token)
         logits, past, _ = valley_forward(token[:, None], None, w, vw, lcfg, vcfg, tok, past=past)
     return torch.stack(out_tokens, 1), torch.stack(out_logits, 1)
+
+
+# --------------------------------------------------------------------------------------------
+# the worker's streaming loop
+# --------------------------------------------------------------------------------------------
+# valley/util/config.py:5-13
+IMAGE_PATCH, IM_START, IM_END = "<im_patch>", "<im_start>", "<im_end>"
+VIDEO, VI_FRAME, VI_START, VI_END = "<video>", "<vi_frame>", "<vi_start>", "<vi_end>"
+
+
+def generate_video_stream(params: dict, tokenizer, video: Optional[torch.Tensor], w, vw, lcfg, vcfg, tok: TokenIds,
+                          mm_use_im_start_end: bool = False, stream_interval: int = 2, context_len: int = 2048,
+                          sampler=None, trace: Optional[list] = None):
+    """valley/serve/model_worker.py:321-426, statement for statement, on the oracle forward.  ``video``: what the
+    worker's load_video returns, [3,T,224,224]; ``sampler(probs) -> int`` stands for ``torch.multinomial(probs, 1)``
+    (:393-394) so that a test can seed it.  Yields the ``json\0`` chunks."""
+    import json
+    prompt = params["prompt"]
+    ori_prompt = prompt
+    images = None
+    if video is not None:
+        assert 1 == prompt.count(VIDEO), "Number of video does not match number of <video> tokens in prompt"
+        frames = video.permute(1, 0, 2, 3)                                   # :337
+        replace_token = IMAGE_PATCH * 256                                     # :338
+        if mm_use_im_start_end:                                               # :339-340
+            replace_token = IM_START + replace_token + IM_END + VI_START + VI_FRAME * frames.shape[0] + VI_END
+        prompt = prompt.replace(VIDEO, replace_token)
+        images = frames.unsqueeze(0)
+    temperature = float(params.get("temperature", 1.0))
+    max_new_tokens = min(int(params.get("max_new_tokens", 256)), 1024)
+    stop_str = params.get("stop", None)
+    stop_idx = None
+    if stop_str is not None:
+        stop_idx = tokenizer(stop_str).input_ids
+        stop_idx = stop_idx[0] if len(stop_idx) == 1 else None
+    input_ids = tokenizer(prompt).input_ids
+    pred_ids = []
+    max_src_len = context_len - max_new_tokens - 8
+    input_ids = input_ids[-max_src_len:]
+    past = None
+    for i in range(max_new_tokens):
+        if i == 0:
+            logits, past, _ = valley_forward(torch.as_tensor([input_ids]), images, w, vw, lcfg, vcfg, tok)
+        else:
+            mask = torch.ones(1, past[0][0].shape[-2] + 1, dtype=torch.long)
+            logits, past, _ = valley_forward(torch.as_tensor([[token]]), None, w, vw, lcfg, vcfg, tok, attention_mask=mask, past=past)
+        last = logits[0][-1]
+        if trace is not None:
+            trace.append(last.clone())
+        if temperature < 1e-4:
+            token = int(torch.argmax(last))
+        else:
+            probs = torch.softmax(last / temperature, dim=-1)
+            token = int(torch.multinomial(probs, num_samples=1)) if sampler is None else int(sampler(probs))
+        pred_ids.append(token)
+        if stop_idx is not None and token == stop_idx:
+            stopped = True
+        elif token == tokenizer.eos_token_id:
+            stopped = True
+        else:
+            stopped = False
+        if i % stream_interval == 0 or i == max_new_tokens - 1 or stopped:
+            cur_out = tokenizer.decode(pred_ids, skip_special_tokens=True)
+            pos = cur_out.rfind(stop_str)                                     # the reference passes stop_str unguarded (:408)
+            if pos != -1:
+                cur_out = cur_out[:pos]
+                stopped = True
+            yield json.dumps({"text": ori_prompt + cur_out, "error_code": 0}).encode() + b"\0"
+        if stopped:
+            break

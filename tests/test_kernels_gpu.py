@@ -514,3 +514,126 @@ def test_gemm_packed_rejects_half_tile_loops():
     for t in (11, 33):
         with pytest.raises(ValleyHipError):
             ops.gemm_mfma(a, pw, tile_hint=t)
+
+
+# ---- the HIP kernels against op-level outputs of the HF sub-modules (tests/golden/g6_ops.npz) ---------
+def _g6():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_ops.npz"))
+
+
+def test_g6_rmsnorm_eps_and_layernorm_vs_hf():
+    """LlamaRMSNorm at eps 1e-5 (Llama-2) and 1e-6 (LLaMA-1 / Vicuna-13B), nn.LayerNorm(1024): bf16 output = the HF fp32
+    output rounded once (<= 1 bf16 ulp), fp32 LayerNorm output to 2e-5."""
+    from tests.golden_r2_cfg import OPS, op_input, op_weights
+    from valley_amd import ops
+    g, d = _g6(), dev()
+    x = torch.from_numpy(op_input("rms.x", (5, OPS["H"]))).to(d)
+    wn = torch.from_numpy(op_weights("rms.w", (OPS["H"],), 0.1, 1.0)).to(d)
+    for eps in (1e-5, 1e-6):
+        ref = torch.from_numpy(g[f"rmsnorm_eps{eps:g}"])
+        y = ops.rmsnorm(x, wn, eps)
+        assert maxabs(y, ref.to(torch.bfloat16)) <= float(ref.abs().max()) / 128 + 1e-6               # one bf16 ulp at the largest value
+        assert relerr(y, ref) < 3e-3
+    # the two eps settings differ by less than a bf16 ulp here, so also check the statistic itself on a tiny-norm row
+    tiny = (x[:1] * 1e-3).contiguous()
+    r5 = wn.cpu() * (tiny.cpu() * torch.rsqrt(tiny.cpu().pow(2).mean(-1, keepdim=True) + 1e-5))
+    r6 = wn.cpu() * (tiny.cpu() * torch.rsqrt(tiny.cpu().pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert relerr(ops.rmsnorm(tiny, wn, 1e-5), r5) < 3e-3 and relerr(ops.rmsnorm(tiny, wn, 1e-6), r6) < 3e-3
+    assert relerr(r5, r6) > 0.1                                               # eps matters at this scale: 1e-6 != 1e-5
+    y16, y32 = ops.layernorm(torch.from_numpy(op_input("ln.x", (5, 1024))).to(d), torch.from_numpy(op_weights("ln.w", (1024,), 0.1, 1.0)).to(d),
+                             torch.from_numpy(op_weights("ln.b", (1024,), 0.1)).to(d), 1e-5, want_f32=True)
+    assert maxabs(y32, torch.from_numpy(g["layernorm"])) < 2e-5
+
+
+def test_g6_rope_positions_vs_hf():
+    """vly_rope_kv at positions {0, 1, 327, 2047} (rotate-half, fp32 tables) vs HF apply_rotary_pos_emb: the bf16 result
+    is the fp32 HF value rounded once."""
+    from tests.golden_r2_cfg import OPS, op_input
+    from valley_amd import ops
+    g, d = _g6(), dev()
+    heads = OPS["heads"]
+    cos, sin = _rope_tables(2048)
+    assert maxabs(cos[OPS["rope_positions"]], torch.from_numpy(g["rope_cos"])[0, :, :64]) < 1e-6
+    q = torch.from_numpy(op_input("rope.q", (1, heads, 4, 128)))
+    k = torch.from_numpy(op_input("rope.k", (1, heads, 4, 128)))
+    for i, pos in enumerate(OPS["rope_positions"]):
+        qkv = torch.zeros((1, 3 * heads * 128), dtype=torch.bfloat16)
+        qkv[0, :heads * 128] = q[0, :, i].reshape(-1).to(torch.bfloat16)
+        qkv[0, heads * 128:2 * heads * 128] = k[0, :, i].reshape(-1).to(torch.bfloat16)
+        qd = qkv.to(d)
+        kc = torch.zeros((1, heads, 2048, 128), dtype=torch.bfloat16, device=d)
+        vc = torch.zeros_like(kc)
+        ops.rope_kv(qd, kc, vc, cos.to(d), sin.to(d), 1, 1, heads, pos)
+        # HF rotated the fp32 q; the kernel rotates the bf16-rounded q: compare against the rotation of the rounded input
+        qb, kb = q[0, :, i].to(torch.bfloat16).float(), k[0, :, i].to(torch.bfloat16).float()
+        c = torch.from_numpy(g["rope_cos"])[0, i]
+        s = torch.from_numpy(g["rope_sin"])[0, i]
+        rot = lambda t: torch.cat([-t[..., 64:], t[..., :64]], -1)  # noqa: E731
+        want_q, want_k = qb * c + rot(qb) * s, kb * c + rot(kb) * s
+        assert maxabs(qd.view(3, heads, 128)[0], want_q.to(torch.bfloat16)) <= 0.032, pos
+        assert maxabs(kc[0, :, pos], want_k.to(torch.bfloat16)) <= 0.032, pos
+        # and the HF fixture itself (fp32 input) within the input rounding
+        assert maxabs(qd.view(3, heads, 128)[0], torch.from_numpy(g["rope_q"])[0, :, i]) < 0.04, pos
+
+
+def test_g6_llama_attention_block_and_mlp_vs_hf():
+    """LlamaAttention (eager, causal, left-padded batch of 2, head_dim 128) and LlamaMLP (SwiGLU) through the kernels the
+    prefill uses: fused q|k|v GEMM -> vly_rope_kv -> vly_llama_attention -> o GEMM; interleaved gate/up GEMM with the
+    SwiGLU epilogue -> down GEMM.  bf16 operand tolerance: rel-L2 < 8e-3."""
+    from tests.golden_r2_cfg import OPS, op_input, op_weights
+    from valley_amd import ops
+    from valley_amd.llama import HipLlama
+    g, d, o = _g6(), dev(), OPS
+    H, heads, B, S = o["H"], o["heads"], 2, o["S"]
+    bf = torch.bfloat16
+    W = {n: torch.from_numpy(op_weights(f"att.{n}", (H, H), 0.05)).to(d, bf) for n in ("q_proj", "k_proj", "v_proj", "o_proj")}
+    x = torch.from_numpy(op_input("att.h", (B, S, H))).view(B * S, H).to(d, bf)
+    qkv = ops.gemm_mfma(x, torch.cat([W["q_proj"], W["k_proj"], W["v_proj"]], 0).contiguous())
+    cos, sin = _rope_tables(256)
+    kc = torch.zeros((B, heads, 256, 128), dtype=bf, device=d)
+    vc = torch.zeros_like(kc)
+    ops.rope_kv(qkv, kc, vc, cos.to(d), sin.to(d), B, S, heads, 0)
+    valid = torch.ones((B, 256), dtype=torch.uint8)
+    valid[1, :o["pad"]] = 0
+    att = ops.llama_attention(qkv, kc, vc, valid.to(d), B, S, heads, 0)
+    y = ops.gemm_mfma(att, W["o_proj"], out_dtype=torch.float32).view(B, S, H).cpu()
+    ref = torch.from_numpy(g["llama_attention"])
+    keep = valid[:, :S].bool()
+    e = relerr(y[keep], ref[keep])
+    print("G6 attention block rel-L2", e)
+    assert e < 8e-3
+    gate = torch.from_numpy(op_weights("mlp.gate", (o["I"], H), 0.05)).to(d, bf)
+    up = torch.from_numpy(op_weights("mlp.up", (o["I"], H), 0.05)).to(d, bf)
+    down = torch.from_numpy(op_weights("mlp.down", (H, o["I"]), 0.05)).to(d, bf)
+    xm = torch.from_numpy(op_input("mlp.x", (7, H))).to(d, bf)
+    xm = torch.cat([xm, torch.zeros((9, H), dtype=bf, device=d)], 0)                        # 16 rows: the MFMA path, not the GEMV
+    mid = ops.gemm_mfma(xm, HipLlama._interleave(gate, up), epilogue=ops.EPI_SWIGLU)
+    out = ops.gemm_mfma(mid, down, out_dtype=torch.float32)[:7].cpu()
+    e = relerr(out, torch.from_numpy(g["llama_mlp"]))
+    print("G6 SwiGLU MLP rel-L2", e)
+    assert e < 8e-3
+
+
+def test_g6_clip_mlp_and_attention_vs_hf():
+    """CLIPMLP (quick_gelu) and CLIPAttention (N = 257, 16 heads x 64) through fc1(+bias, quick_gelu) / fc2 GEMMs and the
+    fused q|k|v GEMM -> vly_vit_attention -> out_proj GEMM."""
+    from tests.golden_r2_cfg import OPS, op_input, op_weights
+    from valley_amd import ops
+    g, d, o = _g6(), dev(), OPS
+    bf = torch.bfloat16
+    tw = lambda n, shp, std=0.03: torch.from_numpy(op_weights(n, shp, std)).to(d)  # noqa: E731
+    x = torch.cat([torch.from_numpy(op_input("cmlp.x", (9, 1024))), torch.zeros(7, 1024)], 0).to(d, bf)
+    mid = ops.gemm_mfma(x, tw("cmlp.fc1.w", (o["VI"], 1024)).to(bf), tw("cmlp.fc1.b", (o["VI"],), 0.1), epilogue=ops.EPI_QUICK_GELU)
+    out = ops.gemm_mfma(mid, tw("cmlp.fc2.w", (1024, o["VI"])).to(bf), tw("cmlp.fc2.b", (1024,), 0.1), out_dtype=torch.float32)[:9]
+    e = relerr(out, torch.from_numpy(g["clip_mlp"]))
+    print("G6 CLIP MLP rel-L2", e)
+    assert e < 8e-3
+    wq = torch.cat([tw(f"catt.{n}.w", (1024, 1024)) for n in ("q_proj", "k_proj", "v_proj")], 0).to(bf).contiguous()
+    bq = torch.cat([tw(f"catt.{n}.b", (1024,), 0.1) for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
+    xa = torch.from_numpy(op_input("catt.x", (2, 257, 1024))).view(-1, 1024).to(d, bf)
+    att = ops.vit_attention(ops.gemm_mfma(xa, wq, bq), 2)
+    y = ops.gemm_mfma(att, tw("catt.out_proj.w", (1024, 1024)).to(bf), tw("catt.out_proj.b", (1024,), 0.1), out_dtype=torch.float32)
+    e = relerr(y.view(2, 257, 1024)[:, ::4], torch.from_numpy(g["clip_attention"]))
+    print("G6 CLIP attention rel-L2", e)
+    assert e < 8e-3

@@ -21,6 +21,7 @@ from tests import golden_cfg as G
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LOGIT_TOL = 6e-2        # bf16 operands / fp32 accumulate vs the fp32 reference, |logit| < 4 (tightened once measured: see DESIGN §2)
 
 
 def rel(a, b):
@@ -274,7 +275,6 @@ def test_decode_session_matches_generic_forward(use_graph):
         got_tokens.append(int(t[0]))
     assert c1.get_seq_length() == ids.shape[1] + 5
     assert got_tokens == ref_tokens
-    assert got_tokens[:4] == g["tokens"][0].tolist() or True      # reference tokens: informative (ties possible)
 
 
 def test_generate_graph_equals_eager_with_padding():
@@ -322,37 +322,85 @@ def test_from_pretrained_checkpoint_roundtrip(tmp_path):
     assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < 6e-2
 
 
-def test_generate_video_stream_matches_reference_loop():
-    """the worker's streaming loop (model_worker.py:321-426) on the HIP path — chunks,
-    prompt expansion with the real frame count, greedy decode — equals the same loop written with the
-    generic forward (the structure of the reference), token for token."""
-    import json
+def _stream_setup():
     from tests.fake_tokenizer import SPECIALS, FakeTokenizer
-    from valley_amd.serving import expand_video_prompt, generate_video_stream
     model = build_golden_model()
     model.config.mm_use_im_start_end = True
-    T = G.GCFG["T"]
     tok = FakeTokenizer(G.GCFG["vocab_text"])
     tok.add_tokens(SPECIALS[:2], special_tokens=True)       # same id order as valley_model.py:357-360
     tok.add_tokens(SPECIALS[2:], special_tokens=True)
     for k in ("im_patch_token", "vi_frame_token", "im_start_token", "im_end_token", "vi_start_token", "vi_end_token"):
         assert getattr(model.get_model().vision_tower.config, k) == G.special()[k]
-    video = torch.from_numpy(G.golden_pixels(T, "mixed")).permute(1, 0, 2, 3).contiguous()      # [3,T,224,224]
-    params = dict(prompt="describe <video> please now", temperature=0.0, max_new_tokens=9, stop="###")
-    chunks = [json.loads(c[:-1]) for c in generate_video_stream(model, tok, params, video=video.cuda(), stream_interval=2)]
-    assert all(c["error_code"] == 0 for c in chunks) and len(chunks) == 5       # i = 0,2,4,6,8 (8 is also the last)
-    # reference-structured loop on the generic forward
-    ids = tok(expand_video_prompt(params["prompt"], T)).input_ids
-    out = model(input_ids=torch.as_tensor([ids]).cuda(), images=video.permute(1, 0, 2, 3).unsqueeze(0).cuda(), use_cache=True)
-    past, pred = out.past_key_values, []
-    logits = out.logits
-    for i in range(9):
-        token = int(torch.argmax(logits[0][-1]))
-        pred.append(token)
-        o = model(input_ids=torch.as_tensor([[token]]).cuda(), use_cache=True, past_key_values=past,
-                  attention_mask=torch.ones(1, past[0][0].shape[-2] + 1).cuda())
-        logits, past = o.logits, o.past_key_values
-    assert chunks[-1]["text"] == params["prompt"] + tok.decode(pred)
+    video = torch.from_numpy(G.golden_pixels(G.GCFG["T"], "mixed")).permute(1, 0, 2, 3).contiguous()      # [3,T,224,224]
+    return model, tok, video
+
+
+def _oracle_stream(tok, params, video, **kw):
+    from oracle import valley_oracle as O
+    c = G.GCFG
+    lcfg = O.LlamaCfg(hidden=c["H"], heads=c["heads"], intermediate=c["I"], layers=c["L"], vocab=c["vocab"], eps=c["eps"])
+    vcfg = O.VisionCfg(intermediate=c["VI"], layers=c["VL"])
+    with torch.no_grad():
+        return list(O.generate_video_stream(params, tok, video, G.llama_state(), G.vision_state(), lcfg, vcfg,
+                                            O.TokenIds(**G.special()), mm_use_im_start_end=True, **kw))
+
+
+def test_generate_video_stream_matches_oracle_loop():
+    """the worker's streaming loop (model_worker.py:321-426) on the HIP path — prompt expansion with the
+    clip's real frame count, prefill, hipGraph decode steps, stop handling, `json\\0` chunks every stream_interval — against
+    the ORACLE's restatement of the same loop (oracle.generate_video_stream on the fp32 CPU forward), chunk for chunk.
+    The prompt was picked (oracle search over 40 prompts) for unambiguous greedy decisions; the test re-checks that on
+    the oracle's own logits (min top-2 gap > 0.12, 4x the bf16 path's logit error), so the HIP path must reproduce every
+    token."""
+    import json
+    from valley_amd.serving import generate_video_stream
+    model, tok, video = _stream_setup()
+    params = dict(prompt="kilo romeo victor <video> mike oscar hotel", temperature=0.0, max_new_tokens=9, stop="###")
+    trace = []
+    want = _oracle_stream(tok, params, video, stream_interval=2, trace=trace)
+    gaps = [float(v[-1] - v[-2]) for v in (torch.sort(t).values for t in trace)]
+    assert len(gaps) == 9 and min(gaps) > 0.12, gaps
+    got = list(generate_video_stream(model, tok, params, video=video.cuda(), stream_interval=2))
+    assert [json.loads(c[:-1]) for c in got] == [json.loads(c[:-1]) for c in want]
+    assert len(got) == 5 and all(c.endswith(b"\0") for c in got)                  # i = 0,2,4,6,8 (8 is also the last)
+    # a stop string that appears in the decoded text cuts the output there and ends the stream
+    first = json.loads(want[1][:-1])["text"][len(params["prompt"]):].split()
+    p2 = dict(params, stop=first[1])
+    want2, got2 = _oracle_stream(tok, p2, video, stream_interval=1), list(generate_video_stream(model, tok, p2, video=video.cuda(), stream_interval=1))
+    assert got2 == want2 and len(got2) == 2
+
+
+def test_generate_video_stream_temperature_sampling_vs_oracle():
+    """The temperature branch (model_worker.py:392-394: softmax(logits / T) + multinomial; T = 0.2 is the reference's
+    default).  A draw near a CDF boundary can legitimately differ between two fp paths, so the check is: the HIP loop
+    samples from ITS distribution with a seeded sampler; the oracle loop is then driven through the same token history
+    (its sampler replays the HIP tokens) and at every step the two distributions must agree (total variation < 0.05,
+    max-abs < 0.03) — and the chunks, built from the same tokens by the same chunking rules, must be identical."""
+    import json
+    from valley_amd.serving import generate_video_stream
+    model, tok, video = _stream_setup()
+    params = dict(prompt="kilo romeo victor <video> mike oscar hotel", temperature=0.2, max_new_tokens=8, stop="###")
+    for use_graph in (True, False):
+        g = torch.Generator().manual_seed(7)
+        hip_p, hip_t = [], []
+
+        def draw(probs):
+            p = probs.detach().float().cpu()
+            hip_p.append(p)
+            hip_t.append(int(torch.multinomial(p, 1, generator=g)))
+            return hip_t[-1]
+        got = list(generate_video_stream(model, tok, params, video=video.cuda(), stream_interval=3, sampler=draw, use_graph=use_graph))
+        ora_p, replay = [], iter(list(hip_t))
+
+        def follow(probs):
+            ora_p.append(probs.float())
+            return next(replay)
+        want = _oracle_stream(tok, params, video, stream_interval=3, sampler=follow)
+        assert got == want, use_graph
+        assert len(hip_t) == 8 and len(set(hip_t)) > 2                                 # a sampled, non-degenerate sequence
+        for a, b in zip(hip_p, ora_p):
+            assert float((a - b).abs().max()) < 0.03 and float((a - b).abs().sum()) / 2 < 0.05
+        assert json.loads(got[-1][:-1])["text"].startswith(params["prompt"])
 
 
 @pytest.mark.parametrize("own_streams", [False, True])
@@ -442,3 +490,104 @@ def test_llama_packed_weights_match_row_major():
         x1 = ll.forward(h1.clone(), B, 1, cache)                      # one decode step on the same cache
         outs.append((lg, ll.logits(x1).clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_greedy_decode2_tokens_exact_vs_reference():
+    """G5b (tools/gen_goldens_r2.py): prefill + 8 greedy KV steps of the REFERENCE on a prompt whose top-2 logit gaps
+    are all > 0.24 — the HIP path must produce the same 8 tokens, through the generic forward, the eager DecodeSession
+    and the hipGraph DecodeSession, with last-position logits within the stated bf16 tolerance."""
+    from valley_amd.decode import DecodeSession
+    g = np.load(os.path.join(GOLD, "g5_decode2.npz"))
+    model = build_golden_model()
+    T = G.GCFG["T"]
+    ids, _ = G.golden_ids("decode2")
+    img1 = torch.from_numpy(G.golden_pixels(T, "mixed")).view(1, T, 3, 224, 224).cuda()
+    want = g["tokens"][0].tolist()
+    seq = model.generate(torch.from_numpy(ids).cuda(), images=img1, max_new_tokens=8, use_graph=None)
+    assert seq[0, ids.shape[1]:].tolist() == want
+    for use_graph in (False, True):
+        ll = model.get_model().llama
+        cache = ll.new_cache(1, 512)
+        out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1, past_key_values=cache, use_cache=True)
+        assert maxabs(out.logits[:, -1].cpu().numpy(), g["prefill_last"]) < LOGIT_TOL
+        sess = DecodeSession(ll, cache, use_graph=use_graph)
+        sess.begin(out.logits[:, -1].argmax(-1))
+        toks = [int(sess.tok[0])]
+        for i in range(7):
+            t = sess.step()
+            torch.cuda.synchronize()
+            assert maxabs(sess.logits[0, :ll.V].cpu().numpy(), g["last_logits"][0, i + 1]) < LOGIT_TOL
+            toks.append(int(t[0]))
+        assert toks == want, (use_graph, toks)
+
+
+def test_completion_and_initialize_vision_tokenizer():
+    """valley_model.py:354-379 + :424-439 through a fake tokenizer: ``initialize_vision_tokenizer`` adds the six tokens in
+    the reference's order, resizes embed / lm_head (new rows = mean of the old ones, :366-377) and binds the ids;
+    ``completion`` takes decoded uint8 frames (GPU preprocessing) or a preprocessed tensor, builds the prompt (8 frame
+    tokens hard-coded, :387-389), generates until '###' / max_new_tokens and post-processes the text."""
+    from tests.fake_tokenizer import FakeTokenizer
+    from valley_amd import valley_model as vm
+    c = G.GCFG
+    cfg = vm.ValleyConfig(vocab_size=c["vocab_text"], hidden_size=c["H"], intermediate_size=c["I"], num_hidden_layers=c["L"],
+                          num_attention_heads=c["heads"], num_key_value_heads=c["heads"], rms_norm_eps=c["eps"])
+    cfg.use_mm_proj, cfg.mm_hidden_size, cfg.mm_vision_select_layer = True, 1024, -2
+    model = vm.ValleyLlamaForCausalLM(cfg)
+    sd = dict(G.llama_state())
+    sd["model.embed_tokens.weight"] = sd["model.embed_tokens.weight"][:c["vocab_text"]]      # the base vocabulary only
+    sd["lm_head.weight"] = sd["lm_head.weight"][:c["vocab_text"]]
+    model.load_state_dict(sd)
+    tower = vm.build_vision_tower(dict(intermediate_size=c["VI"], num_hidden_layers=c["VL"]), state_dict=G.vision_state())
+    info = model.get_model().initialize_vision_modules(tower, -2)
+    assert info["image_token_len"] == 256 and info["vision_config"] is tower.config
+    if info["image_processor"] is not None:                                  # CLIP's published preprocessing constants
+        assert abs(info["image_processor"].image_mean[0] - 0.48145466) < 1e-8
+    tok = FakeTokenizer(c["vocab_text"])
+    ll = model.get_model().llama
+    old_embed = ll.embed.clone()
+    model.initialize_vision_tokenizer(tok)
+    assert len(tok) == c["vocab_text"] + 6 == ll.V == model.config.vocab_size
+    assert {k: getattr(tower.config, k) for k in G.special()} == G.special()                # same ids as valley_model.py:357-360
+    assert torch.equal(ll.embed[:c["vocab_text"]], old_embed)
+    # :366-377: the rows of the LAST add_tokens call (4 start/end tokens) = mean of all rows before them
+    want = ll.embed[:ll.V - 4].float().mean(0)
+    assert maxabs(ll.embed[ll.V - 4:].float().cpu().numpy(), want.expand(4, -1).cpu().numpy()) <= 2e-3
+    msg = [{"role": "system", "content": "You are Valley."}, {"role": "user", "content": "Describe this video concisely.\n<video>"}]
+    frames = np.random.default_rng(0).integers(0, 256, (11, 240, 320, 3), dtype=np.uint8)    # 11 decoded frames -> 8 sampled
+    out = model.completion(tok, frames, msg, dict(do_sample=False, temperature=0.2, max_new_tokens=6), "cuda")
+    assert isinstance(out, list) and len(out) == 1 and isinstance(out[0], str)
+    # a preprocessed [3,T,224,224] tensor (what load_video returns) takes the other branch and must give the same answer
+    from valley_amd.video import load_video_gpu
+    pre = load_video_gpu(frames)[0].permute(1, 0, 2, 3).float()
+    assert model.completion(tok, pre, msg, dict(do_sample=False, max_new_tokens=6), "cuda") == out
+    n_words = len(out[0].split())
+    assert 0 < n_words <= 6 and all(w.startswith("w") for w in out[0].split())
+
+
+def test_generate_stopping_semantics_and_foreign_cache():
+    """HF generate semantics the reference relies on (valley_model.py:432): ANY stopping criterion ends the run; a row that
+    emitted eos keeps emitting pad while the others continue; a non-empty foreign cache is refused (TypeError), an empty
+    one starts fresh."""
+    model = build_golden_model()
+    T = G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224).cuda()
+    kw = dict(images=images, attention_mask=torch.from_numpy(mask).cuda())
+    ids_t = torch.from_numpy(ids).cuda()
+    free = model.generate(ids_t, max_new_tokens=6, **kw)
+    n_in = ids.shape[1]
+    never, after3 = (lambda seq, scores: False), (lambda seq, scores: seq.shape[1] >= n_in + 3)
+    got = model.generate(ids_t, max_new_tokens=6, stopping_criteria=[never, after3], **kw)
+    assert got.shape[1] == n_in + 3 and torch.equal(got, free[:, :n_in + 3])
+    # eos on row 0 only: its second generated token
+    eos = int(free[0, n_in + 1])
+    if eos not in free[1, n_in:].tolist():
+        got = model.generate(ids_t, max_new_tokens=6, eos_token_id=eos, pad_token_id=0, **kw)
+        assert got[0, n_in:n_in + 2].tolist() == free[0, n_in:n_in + 2].tolist()
+        assert got[0, n_in + 2:].tolist() == [0] * (got.shape[1] - n_in - 2)            # finished row pads
+        assert torch.equal(got[1], free[1, :got.shape[1]])                               # the other row is unaffected
+    with pytest.raises(TypeError):
+        model(input_ids=ids_t[:, -1:], past_key_values=((torch.zeros(2, 2, 3, 128), torch.zeros(2, 2, 3, 128)),) * 2, use_cache=True)
+    from transformers import DynamicCache
+    out = model(input_ids=ids_t, past_key_values=DynamicCache(), use_cache=True, **kw)    # empty foreign cache: fresh start
+    assert out.past_key_values.get_seq_length() == n_in

@@ -1,0 +1,43 @@
+"""Multi-rank frame data parallelism on the REAL encoder: N ranks share the one GPU of the test box
+(gloo carries the collective; on an 8-GPU node the same code runs over RCCL), every rank checks that the gathered
+pooled tokens are bit-identical to the single-rank result — equal shards, ragged frame counts, an idle rank, and the
+frames mode.  Also launches bench.py exactly as the driver does for N > 1 (tiny config) to keep that path alive."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, world, port, extra_env=None, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_encode_clips_dp_real_encoder_bit_identical(world):
+    r = _run([os.path.join(ROOT, "tests", "dp_worker.py")], world, 29611 + world)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    for rank in range(world):
+        assert f"DP_OK rank {rank}/{world}" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_multi_rank_launch_path():
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` as the driver launches it, two ranks
+    on one device: both prefill modes produce one JSON line on rank 0 with n_gpus = 2 and the whole-job frame count."""
+    for mode in ("sharded", "replicated"):
+        r = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1", "--prefill", mode,
+                  "--no-cpu-baseline", "--traffic", "none"], 2, 29631,
+                 extra_env={"VALLEY_BENCH_SAME_DEVICE": "1", "VALLEY_BENCH_BACKEND": "gloo"})
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(line) == 1, r.stdout[-2000:]
+        j = json.loads(line[0])
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+        assert j["config"]["parallelism"].startswith("frame-dp2") and ("replicated" in j["config"]["parallelism"]) == (mode == "replicated")

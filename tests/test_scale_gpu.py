@@ -195,3 +195,65 @@ def test_gemm_hot_shapes_vs_fp32(M, N, K, epi, has_bias, label, monkeypatch):
     assert e_sk < 4e-3, (label, e_sk)
     assert ops.sk_error_flag(d) == 0
     print(f"{label}: {M}x{N}x{K} rel-L2 tile {e_tile:.2e} tuned {e_tuned:.2e} pair {e_pair} stream-K {e_sk:.2e}; out cols {No}")
+
+
+# ---- the v2 / v3 temporal modules at production width ------------------------------------------------
+@pytest.mark.parametrize("method", ["mean", "max", "temporal_importance", "temporal_transformer"])
+def test_temporal_pooling_at_production_width_vs_oracle(method):
+    """All four pooling variants at H = 4096 (the 7B projector width), T = 8 frames, B = 2 clips: the projected visual
+    tokens [B, 256+T, H] of the HIP path (vly_pool_tokens / vly_temporal_scores / temporal_delta.hip + MFMA GEMMs) against
+    the oracle (valley_model.py:187-193, 206-215, 113-121, 123-133), on a 3-layer ViT-L/14-geometry tower so that the
+    oracle's tower finishes in seconds; prints the time of the pooling + projection stage."""
+    from oracle import valley_oracle as O
+    from tests import golden_cfg as G
+    from valley_amd import valley_model as vm, weights as W
+    H, T, B, V = 4096, 8, 2, 64
+    cfg = vm.ValleyConfig(vocab_size=V, hidden_size=H, intermediate_size=11008, num_hidden_layers=0, num_attention_heads=32,
+                          num_key_value_heads=32, rms_norm_eps=1e-5)
+    cfg.use_mm_proj, cfg.mm_hidden_size, cfg.mm_vision_select_layer = True, 1024, -2
+    sd = W.valley_llama_weights(31, V, H, 11008, 0)
+    s = 31
+    if method == "temporal_importance":
+        sd["model.pooling_layer.weight"] = W.det_normal(s, "pool.w", (1, H * 256), 0.002)
+        sd["model.pooling_layer.bias"] = W.det_normal(s, "pool.b", (1,), 0.01)
+    if method == "temporal_transformer":
+        shapes = {"self_attn.in_proj_weight": (3 * H, H), "self_attn.in_proj_bias": (3 * H,), "self_attn.out_proj.weight": (H, H),
+                  "self_attn.out_proj.bias": (H,), "linear1.weight": (2048, H), "linear1.bias": (2048,), "linear2.weight": (H, 2048),
+                  "linear2.bias": (H,), "norm1.weight": (H,), "norm1.bias": (H,), "norm2.weight": (H,), "norm2.bias": (H,)}
+        for k, shp in shapes.items():
+            t = W.det_normal(s, "tde." + k, shp, 0.02)
+            sd["model.transformer_delta_encoder.layers.0." + k] = (t + 1.0 if k in ("norm1.weight", "norm2.weight") else t).astype(np.float32)
+        sd["model.position_matrix"] = O.sinusoid_position_matrix(2048, H).numpy()
+    model = vm.ValleyLlamaForCausalLM(cfg)
+    model.load_state_dict(sd)
+    vs = G.vision_state()
+    tower = vm.build_vision_tower(dict(intermediate_size=G.GCFG["VI"], num_hidden_layers=G.GCFG["VL"]), state_dict=vs)
+    mm = model.get_model()
+    mm.vision_tower = tower
+    mm.patch_pooling_method = method
+    px = torch.from_numpy(G.golden_pixels(B * T, "n4")).view(B, T, 3, 224, 224)
+    pooled, Ts = mm.encode_clips(px.cuda())
+    vis = mm.project_pooled(pooled).float().view(B, 256 + T, H).cpu().numpy()
+    with torch.no_grad():
+        vcfg = O.VisionCfg(intermediate=G.GCFG["VI"], layers=G.GCFG["VL"])
+        ref = []
+        for b in range(B):
+            proj = O.mm_project(O.vit_select(px[b], vs, vcfg, -2), sd)
+            patches, cls = O.pool_clip(proj, method, sd)
+            ref.append(torch.cat([patches, cls], 0))
+        ref = torch.stack(ref).numpy()
+    # time the stage after the tower (pool + project, or project + pool + v2 / v3 module)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    frames = px.cuda().view(-1, 3, 224, 224)
+    for _ in range(2):
+        ev[0].record()
+        tower.encode(frames, -2)
+        ev[1].record()
+        ev[2].record()
+        mm.project_pooled(mm.encode_clips(px.cuda())[0])
+        ev[3].record()
+    torch.cuda.synchronize()
+    e = rel(vis, ref)
+    print(f"N4 {method}: visual tokens [B={B}, {256 + T}, H={H}] rel-L2 {e:.2e} max-abs {maxabs(vis, ref):.3e} "
+          f"(|ref| max {float(np.abs(ref).max()):.2f}); pooling+projection stage {ev[2].elapsed_time(ev[3]) - ev[0].elapsed_time(ev[1]):.3f} ms")
+    assert e < 8e-3

@@ -29,9 +29,10 @@ def expand_video_prompt(prompt: str, n_frames: int, use_im_start_end: bool = Fal
 
 
 def generate_video_stream(model, tokenizer, params: dict, video: Optional[torch.Tensor] = None, stream_interval: int = 2,
-                          context_len: int = 2048, use_graph: bool = True) -> Iterator[bytes]:
+                          context_len: int = 2048, use_graph: bool = True, sampler=None) -> Iterator[bytes]:
     """``params``: prompt, temperature, max_new_tokens, stop (model_worker.py:323-358).  ``video``: preprocessed
-    frames [3,T,224,224] (what ``load_video`` returns) or None."""
+    frames [3,T,224,224] (what ``load_video`` returns) or None.  ``sampler(probs) -> token`` replaces the default
+    ``torch.multinomial(probs, 1)`` of the temperature branch (:393-394), e.g. to seed it."""
     prompt = params["prompt"]
     ori_prompt = prompt
     images = None
@@ -72,7 +73,7 @@ def generate_video_stream(model, tokenizer, params: dict, video: Optional[torch.
             token = int(torch.argmax(last))
         else:
             probs = torch.softmax(last / temperature, dim=-1)
-            token = int(torch.multinomial(probs, num_samples=1))
+            token = int(torch.multinomial(probs, num_samples=1)) if sampler is None else int(sampler(probs))
         pred_ids.append(token)
         if stop_idx is not None and token == stop_idx:
             stopped = True
