@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 1
+#define VLY_ABI_VERSION 2   /* 2: + the fp32 "precise" entry points (vly_*_f32) */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -247,6 +247,46 @@ int vly_incr_i32(int32_t *p, int n, int delta, void *stream);
 /* argmax over the last dim of fp32 [M,N] (row stride ld >= N) -> int32 [M]; first maximal index.
  *   serve/model_worker.py:389-391. */
 int vly_argmax(const float *x, int32_t *idx, int M, int N, int ld, void *stream);
+
+/* ---- fp32 "precise" path (VALLEY_PRECISION=fp32): the same operators with fp32 tensors end to end and contractions on
+ * the exact f32-input MFMA (v_mfma_f32_32x32x2_f32).  It exists to demonstrate the north star's "logits within 1e-3 of
+ * the reference", which bf16 operands cannot reach; ~1/16 of the bf16 path's rate by construction. ------------------- */
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T + bias) + residual, all fp32 (nn.Linear / the patch conv as a GEMM;
+ *   hf:clip/modeling_clip.py:148-154,293-350, hf:llama/modeling_llama.py:160-173,230-241).  K % 16 == 0, N % 4 == 0,
+ *   16-byte aligned rows; SWIGLU as in vly_gemm_bf16 (interleaved rows, N/2-wide output, no residual); residual may
+ *   alias C. */
+int vly_gemm_f32(const float *A, const float *W, const float *bias, const float *residual, float *C,
+                 int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, void *stream);
+
+/* out = softmax(q k^T * head_dim^-0.5 [+ mask]) v in fp32 (hf:clip/modeling_clip.py:259-277 without mask;
+ *   hf:llama/modeling_llama.py:191-213 with causal + key-validity mask: key j visible to query i iff
+ *   j <= i + past_len and key_valid[b][j]).  q / out row r of batch b, head h: base + b*batch_stride + r*row_stride + h*hd;
+ *   k / v row j: base + b*kv_batch_stride + h*kv_head_stride + j*kv_row_stride (covers the q|k|v GEMM buffer of the
+ *   ViT and the [B,heads,ctx,hd] fp32 KV cache).  head_dim 64 or 128.  Fully masked query rows come out as zeros. */
+int vly_attention_f32(const float *q, long q_batch_stride, int q_row_stride, const float *k, const float *v,
+                      long kv_batch_stride, long kv_head_stride, int kv_row_stride, const uint8_t *key_valid,
+                      int key_valid_stride, float *out, long out_batch_stride, int out_row_stride, int B, int heads,
+                      int n_q, int n_kv, int head_dim, int causal, int past_len, void *stream);
+
+/* y = LayerNorm(x; gamma, beta, eps) (rms == 0) or gamma * x * rsqrt(mean(x^2) + eps) (rms != 0, beta unused), fp32
+ *   [M,D] -> fp32 [M,D]; y may alias x.  hf:clip/modeling_clip.py:605,642; hf:llama/modeling_llama.py:51-67. */
+int vly_norm_f32(const float *x, const float *gamma, const float *beta, float *y, int M, int D, float eps, int rms,
+                 void *stream);
+
+/* vly_rope_kv with fp32 q|k|v rows [B*S, 3*heads*128] and fp32 caches [B,heads,ctx_max,128] (hf:llama 127-157). */
+int vly_rope_kv_f32(float *qkv, float *kcache, float *vcache, const float *cos_table, const float *sin_table,
+                    int B, int S, int heads, int past_len, int ctx_max, void *stream);
+
+/* vly_patchify at fp32: [F,3,224,224] -> [F*256, k_padded] (k_padded >= 588, a multiple of 16; pad columns zero). */
+int vly_patchify_f32(const float *images, float *patches, int F, int k_padded, void *stream);
+
+/* vly_pool_tokens with an fp32 result [B, 256+T, W] (valley_model.py:206-215, 113-121). */
+int vly_pool_tokens_f32(const float *feats, float *out, int B, int T, int W, int mode, const float *scores, void *stream);
+
+/* vly_embed_splice with an fp32 embedding table [V,H] and fp32 visual tokens (valley_model.py:160, 195-247). */
+int vly_embed_splice_f32(const int32_t *row_map, const float *embed, const float *visual, float *out, int R, int H,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,43 @@ def _t(w: Dict, k: str) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# optional "same-dtype" mode (the bf16-rounded-at-the-same-points oracle)
+# --------------------------------------------------------------------------------------------
+# The reference arithmetic above is fp32.  The HIP production path stores GEMM operands and most activations in bf16
+# (fp32 accumulation, fp32 softmax / norm statistics, fp32 residual stream — DESIGN.md §3).  Inside ``with rounding():``
+# every function of this file rounds to bf16 exactly where that pipeline stores bf16: GEMM weights (``_tw``) and the
+# tensors marked ``_q(...)`` below.  What remains between the HIP path and this mode is summation order (and the
+# flash-style online softmax), so the HIP path can be held to ~1e-3-level agreement with it, while its distance to the
+# fp32 mode measures the cost of bf16 storage itself.  Norm parameters, biases, position / class embeddings and RoPE
+# tables stay fp32 in both.
+_ROUND = False
+
+
+class rounding:
+    """Context manager: ``with oracle.rounding(): ...`` evaluates the path with bf16 storage rounding."""
+
+    def __enter__(self):
+        global _ROUND
+        self._old, _ROUND = _ROUND, True
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUND
+        _ROUND = self._old
+        return False
+
+
+def _q(x: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (nearest-even) and back when the same-dtype mode is on; identity otherwise."""
+    return x.to(torch.bfloat16).float() if _ROUND else x
+
+
+def _tw(w: Dict, k: str) -> torch.Tensor:
+    """A GEMM weight (kept in bf16 by the HIP path)."""
+    return _q(_t(w, k))
+
+
+# --------------------------------------------------------------------------------------------
 # CLIP vision tower
 # --------------------------------------------------------------------------------------------
 def quick_gelu(x: torch.Tensor) -> torch.Tensor:
@@ -96,8 +133,8 @@ def quick_gelu(x: torch.Tensor) -> torch.Tensor:
 
 def clip_embeddings(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, prefix: str = "") -> torch.Tensor:
     """hf:clip/modeling_clip.py:203-218.  pixels [F,3,H,W] -> [F, 1+P, D]."""
-    pw = _t(w, prefix + "embeddings.patch_embedding.weight")
-    x = F.conv2d(pixels.float(), pw, bias=None, stride=cfg.patch)          # [F, D, g, g]
+    pw = _tw(w, prefix + "embeddings.patch_embedding.weight")
+    x = F.conv2d(_q(pixels.float()), pw, bias=None, stride=cfg.patch)      # [F, D, g, g]
     x = x.flatten(2).transpose(1, 2)                                        # [F, P, D]
     cls = _t(w, prefix + "embeddings.class_embedding").expand(x.shape[0], 1, -1)
     x = torch.cat([cls, x], dim=1)
@@ -108,26 +145,26 @@ def clip_attention(x: torch.Tensor, w: Dict, p: str, heads: int) -> torch.Tensor
     """hf:clip/modeling_clip.py:302-334 with eager_attention_forward :258-277 (no mask)."""
     Fn, N, D = x.shape
     hd = D // heads
-    q = F.linear(x, _t(w, p + "q_proj.weight"), _t(w, p + "q_proj.bias")).view(Fn, N, heads, hd).transpose(1, 2)
-    k = F.linear(x, _t(w, p + "k_proj.weight"), _t(w, p + "k_proj.bias")).view(Fn, N, heads, hd).transpose(1, 2)
-    v = F.linear(x, _t(w, p + "v_proj.weight"), _t(w, p + "v_proj.bias")).view(Fn, N, heads, hd).transpose(1, 2)
+    q = _q(F.linear(x, _tw(w, p + "q_proj.weight"), _t(w, p + "q_proj.bias"))).view(Fn, N, heads, hd).transpose(1, 2)
+    k = _q(F.linear(x, _tw(w, p + "k_proj.weight"), _t(w, p + "k_proj.bias"))).view(Fn, N, heads, hd).transpose(1, 2)
+    v = _q(F.linear(x, _tw(w, p + "v_proj.weight"), _t(w, p + "v_proj.bias"))).view(Fn, N, heads, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)
-    a = torch.softmax(s, dim=-1, dtype=torch.float32)
-    o = torch.matmul(a, v).transpose(1, 2).reshape(Fn, N, D)
-    return F.linear(o, _t(w, p + "out_proj.weight"), _t(w, p + "out_proj.bias"))
+    a = _q(torch.softmax(s, dim=-1, dtype=torch.float32))
+    o = _q(torch.matmul(a, v).transpose(1, 2).reshape(Fn, N, D))
+    return _q(F.linear(o, _tw(w, p + "out_proj.weight"), _t(w, p + "out_proj.bias")))
 
 
 def clip_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
     """hf:clip/modeling_clip.py:338-350: fc2(quick_gelu(fc1(x))); p ends in 'mlp.'."""
-    h = F.linear(h, _t(w, p + "fc1.weight"), _t(w, p + "fc1.bias"))
-    return F.linear(quick_gelu(h), _t(w, p + "fc2.weight"), _t(w, p + "fc2.bias"))
+    h = F.linear(h, _tw(w, p + "fc1.weight"), _t(w, p + "fc1.bias"))
+    return _q(F.linear(_q(quick_gelu(h)), _tw(w, p + "fc2.weight"), _t(w, p + "fc2.bias")))
 
 
 def clip_layer(x: torch.Tensor, w: Dict, p: str, cfg: VisionCfg) -> torch.Tensor:
     """hf:clip/modeling_clip.py:353-383 (pre-LN encoder layer)."""
-    h = F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm1.weight"), _t(w, p + "layer_norm1.bias"), cfg.eps)
+    h = _q(F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm1.weight"), _t(w, p + "layer_norm1.bias"), cfg.eps))
     x = x + clip_attention(h, w, p + "self_attn.", cfg.heads)
-    h = F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm2.weight"), _t(w, p + "layer_norm2.bias"), cfg.eps)
+    h = _q(F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm2.weight"), _t(w, p + "layer_norm2.bias"), cfg.eps))
     return x + clip_mlp(h, w, p + "mlp.")
 
 
@@ -158,7 +195,7 @@ def vit_select(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, select_layer: int 
 # --------------------------------------------------------------------------------------------
 def mm_project(feats: torch.Tensor, w: Dict) -> torch.Tensor:
     """valley_model.py:54-55,190: Linear(mm_hidden -> H) + bias on every token."""
-    return F.linear(feats, _t(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias"))
+    return F.linear(_q(feats), _tw(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias"))
 
 
 def sinusoid_position_matrix(seq_len: int, d: int, n: float = 10000.0) -> torch.Tensor:
@@ -221,7 +258,7 @@ def torch_encoder_layer(x: torch.Tensor, w: Dict, p: str, nhead: int) -> torch.T
 # --------------------------------------------------------------------------------------------
 def splice_visual_tokens(input_ids: torch.Tensor, inputs_embeds: torch.Tensor,
                          image_features: Sequence[torch.Tensor], tok: TokenIds, method: str = "mean",
-                         w: Optional[Dict] = None) -> torch.Tensor:
+                         w: Optional[Dict] = None, pooled: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None) -> torch.Tensor:
     """valley_model.py:195-247, statement for statement.
 
     image_features: per multimodal sample, projected features [T_i, 1+P, H].  ``cur_image_idx``
@@ -236,8 +273,8 @@ def splice_visual_tokens(input_ids: torch.Tensor, inputs_embeds: torch.Tensor,
             new_embeds.append(emb)                       # + 0*dummy.sum() is a numeric no-op (:200)
             continue
         feats = image_features[cur_image_idx]
-        pooled, cls = pool_clip(feats, method, w)
-        P = pooled.shape[0]
+        pooled_c, cls = pool_clip(feats, method, w) if pooled is None else pooled[cur_image_idx]   # (same-dtype mode: pre-pooled rows)
+        P = pooled_c.shape[0]
         if (ids == tok.im_start_token).sum() != (ids == tok.im_end_token).sum():
             raise ValueError("The number of im_start_token and im_end_token should be the same")
         cur = emb.clone()
@@ -246,7 +283,7 @@ def splice_visual_tokens(input_ids: torch.Tensor, inputs_embeds: torch.Tensor,
             # reference indexes ids[pos+P+1] unguarded: IndexError if the prompt is too short
             if ids[pos + P + 1] != tok.im_end_token:
                 raise ValueError("Seems that the image is cut.")
-            cur = torch.cat((cur[:pos + 1], pooled, cur[pos + P + 1:]), dim=0)
+            cur = torch.cat((cur[:pos + 1], pooled_c, cur[pos + P + 1:]), dim=0)
         try:
             if (ids == tok.vi_start_token).sum() != (ids == tok.vi_end_token).sum():
                 raise ValueError("The number of vi_start_token and vi_end_token should be the same")
@@ -311,34 +348,37 @@ def llama_attention_block(h: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, 
     softmax(QK^T * hd^-0.5 + mask) V in fp32, o_proj.  h [B,S,H] is the NORMED hidden state; p ends in 'self_attn.'."""
     B, S, H = h.shape
     hd = H // cfg.heads
-    q = F.linear(h, _t(w, p + "q_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
-    k = F.linear(h, _t(w, p + "k_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
-    v = F.linear(h, _t(w, p + "v_proj.weight")).view(B, S, cfg.heads, hd).transpose(1, 2)
-    q = apply_rope(q, cos, sin)
-    k = apply_rope(k, cos, sin)
+    q = _q(F.linear(h, _tw(w, p + "q_proj.weight"))).view(B, S, cfg.heads, hd).transpose(1, 2)
+    k = _q(F.linear(h, _tw(w, p + "k_proj.weight"))).view(B, S, cfg.heads, hd).transpose(1, 2)
+    v = _q(F.linear(h, _tw(w, p + "v_proj.weight"))).view(B, S, cfg.heads, hd).transpose(1, 2)
+    q = _q(apply_rope(q, cos, sin))
+    k = _q(apply_rope(k, cos, sin))
     if past is not None:
         k = torch.cat([past[0], k], dim=2)
         v = torch.cat([past[1], v], dim=2)
     s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5) + mask
-    a = torch.softmax(s, dim=-1, dtype=torch.float32)
-    o = torch.matmul(a, v).transpose(1, 2).reshape(B, S, H)
-    return F.linear(o, _t(w, p + "o_proj.weight")), (k, v)
+    a = _q(torch.softmax(s, dim=-1, dtype=torch.float32))
+    o = _q(torch.matmul(a, v).transpose(1, 2).reshape(B, S, H))
+    out = F.linear(o, _tw(w, p + "o_proj.weight"))
+    # prefill hands the projection to the residual add as a bf16 tensor; the <= 8-row decode step adds in the GEMV epilogue
+    return (_q(out) if B * S > 8 else out), (k, v)
 
 
 def llama_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
     """hf:llama/modeling_llama.py:160-173: down(silu(gate(x)) * up(x)); p ends in 'mlp.'."""
-    g = F.linear(h, _t(w, p + "gate_proj.weight"))
-    u = F.linear(h, _t(w, p + "up_proj.weight"))
-    return F.linear(F.silu(g) * u, _t(w, p + "down_proj.weight"))
+    g = F.linear(h, _tw(w, p + "gate_proj.weight"))
+    u = F.linear(h, _tw(w, p + "up_proj.weight"))
+    out = F.linear(_q(F.silu(g) * u), _tw(w, p + "down_proj.weight"))
+    return _q(out) if h.shape[0] * h.shape[1] > 8 else out
 
 
 def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
                 past: Optional[Tuple[torch.Tensor, torch.Tensor]]):
     """hf:llama/modeling_llama.py:292-332 (pre-norm decoder layer)."""
-    h = rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps)
+    h = _q(rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps))
     o, kv = llama_attention_block(h, w, p + "self_attn.", cfg, cos, sin, mask, past)
     x = x + o
-    h = rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps)
+    h = _q(rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps))
     return x + llama_mlp(h, w, p + "mlp."), kv
 
 
@@ -359,7 +399,7 @@ def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,
     for i in range(L):
         x, kv = llama_layer(x, w, f"model.layers.{i}.", cfg, cos, sin, mask, None if past is None else past[i])
         new_past.append(kv)
-    return rms_norm(x, _t(w, "model.norm.weight"), cfg.eps), new_past
+    return _q(rms_norm(x, _t(w, "model.norm.weight"), cfg.eps)), new_past
 
 
 # --------------------------------------------------------------------------------------------
@@ -370,12 +410,26 @@ def valley_forward(input_ids: torch.Tensor, images, w: Dict, vw: Dict, lcfg: Lla
                    select_layer: int = -2, method: str = "mean", vprefix: str = ""):
     """ValleyLlamaForCausalLM.forward (valley_model.py:272-330) without the loss.
     images: [B,T,3,H,W] tensor or list of [T_i,3,H,W] (valley_model.py:168-184)."""
-    emb = F.embedding(input_ids, _t(w, "model.embed_tokens.weight"))
+    emb = F.embedding(input_ids, _tw(w, "model.embed_tokens.weight"))
     if images is not None and input_ids.shape[1] != 1:
-        feats = [mm_project(vit_select(clip, vw, vcfg, select_layer, vprefix), w) for clip in images]
-        emb = splice_visual_tokens(input_ids, emb, feats, tok, method, w)
+        raw = [vit_select(clip, vw, vcfg, select_layer, vprefix) for clip in images]
+        if _ROUND and method in ("mean", "max"):
+            # the HIP path's storage points around the projector: mean pools the fp32 tower output first and projects
+            # 256 + T bf16 rows; max projects every (bf16) token into fp32 and pools there; visual tokens are bf16
+            pooled = []
+            for f in raw:
+                if method == "mean":
+                    rows = _q(torch.cat([f[:, 1:].mean(0), f[:, 0]], 0))
+                    rows = _q(F.linear(rows, _tw(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias")))
+                else:
+                    pr = mm_project(f, w)
+                    rows = _q(torch.cat([pr[:, 1:].max(0)[0], pr[:, 0]], 0))
+                pooled.append((rows[:f.shape[1] - 1], rows[f.shape[1] - 1:]))
+            emb = splice_visual_tokens(input_ids, emb, [mm_project(f, w) for f in raw], tok, method, w, pooled=pooled)
+        else:
+            emb = splice_visual_tokens(input_ids, emb, [mm_project(f, w) for f in raw], tok, method, w)
     hidden, new_past = llama_forward(emb, w, lcfg, attention_mask, past)
-    logits = F.linear(hidden, _t(w, "lm_head.weight"))
+    logits = F.linear(hidden, _tw(w, "lm_head.weight"))
     return logits, new_past, emb
 
 

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <vector>
 
+#include "../../include/valley_hip.h"      // VLY_ABI_VERSION (declarations only: every call below goes through dlsym)
+
 #define HIP_OK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "HIP call failed: %s\n", #x); return 2; } } while (0)
 
 static uint16_t f2bf(float f) {
@@ -41,7 +43,7 @@ int main(int argc, char** argv) {
     auto rms = (rms_fn)dlsym(h, "vly_rmsnorm");
     auto lasterr = (err_fn)dlsym(h, "vly_last_error");
     if (!ver || !gemm || !rms || !lasterr) { fprintf(stderr, "missing symbol\n"); return 2; }
-    if (ver() != 1) { fprintf(stderr, "ABI version %d\n", ver()); return 2; }
+    if (ver() != VLY_ABI_VERSION) { fprintf(stderr, "ABI version %d\n", ver()); return 2; }
 
     const int M = 300, N = 264, K = 192;
     std::vector<uint16_t> a(M * K), w(N * K);

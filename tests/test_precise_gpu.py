@@ -1,0 +1,271 @@
+"""BASELINE.json: "logits within 1e-3 of reference".  Three statements, each tested here (SURVEY.md §7 "hard parts", §8c):
+
+(i)   the bf16 production path against the fp32 reference fixtures: measured and asserted in tests/test_model_gpu.py
+      (max-abs 0.030 on |logit| < 4 — the cost of bf16 storage, NOT of the implementation, see (ii));
+(ii)  the bf16 production path against the SAME-DTYPE oracle (oracle.rounding(): the fp32 restatement rounded to bf16 at
+      exactly the points where the HIP pipeline stores bf16): what is left is summation order — asserted below;
+(iii) VALLEY_PRECISION=fp32 (valley_amd/precise.py: fp32 tensors end to end, exact f32 MFMA) against the fp32 reference
+      fixtures and the fp32 oracle: **max-abs logit error < 1e-3** asserted on the golden model (all of its cases) and
+      on 2 decoder layers at the Vicuna-13B layer shapes.
+
+Plus unit parity of every fp32 kernel (vly_*_f32) against a plain PyTorch fp32 statement of the op."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_cfg as G
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL_FP32 = 1e-3          # the north star's bound, fp32 mode
+D = "cuda:0"
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ---- fp32 kernels -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (64, 64, 16), (1, 512, 592), (771, 1028, 1024), (130, 36, 48)])
+def test_gemm_f32(M, N, K):
+    from valley_amd import ops, ops_f32 as F
+    a, w, bias, res = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.5), rnd((M, N), 4)
+    base = (a.double() @ w.double().t() + bias.double())
+    out = F.gemm(a.to(D), w.to(D), bias.to(D))
+    assert maxabs(out.cpu(), base) < 2e-5 * max(1.0, float(base.abs().max()))
+    h = res.to(D).clone()
+    F.gemm(a.to(D), w.to(D), bias.to(D), residual=h, out=h)                        # in-place residual update
+    assert maxabs(h.cpu(), base + res.double()) < 3e-5 * max(1.0, float(base.abs().max()))
+    out = F.gemm(a.to(D), w.to(D), bias.to(D), epilogue=ops.EPI_QUICK_GELU)
+    assert maxabs(out.cpu(), base * torch.sigmoid(1.702 * base)) < 3e-5 * max(1.0, float(base.abs().max()))
+    out = F.gemm(a.to(D), w.to(D), bias.to(D), epilogue=ops.EPI_RELU)
+    assert maxabs(out.cpu(), base.clamp_min(0)) < 3e-5 * max(1.0, float(base.abs().max()))
+    if N % 8 == 0:
+        nb = a.double() @ w.double().t()
+        out = F.gemm(a.to(D), w.to(D), epilogue=ops.EPI_SWIGLU)
+        assert out.shape == (M, N // 2)
+        assert maxabs(out.cpu(), torch.nn.functional.silu(nb[:, 0::2]) * nb[:, 1::2]) < 3e-5 * max(1.0, float(nb.abs().max()) ** 2)
+    # transpose detector
+    w1 = torch.zeros((N, K))
+    w1[3, K - 1] = 1.0
+    out = F.gemm(a.to(D), w1.to(D))
+    assert maxabs(out.cpu()[:, 3], a[:, K - 1]) == 0.0 and float(out.cpu()[:, :3].abs().max()) == 0.0
+
+
+def test_vit_attention_f32():
+    from valley_amd import ops_f32 as F
+    Fn = 3
+    qkv = rnd((Fn * 257, 3072), 5)
+    qkv[5, :64] *= 6.0
+    out = F.vit_attention(qkv.to(D), Fn).cpu()
+    x = qkv.double().view(Fn, 257, 3, 16, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(Fn * 257, 1024)
+    assert maxabs(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,S,past,heads,pad", [(2, 75, 0, 2, 9), (1, 130, 0, 3, 0), (2, 1, 130, 2, 5), (1, 40, 100, 2, 0)])
+def test_rope_and_llama_attention_f32(B, S, past, heads, pad):
+    from valley_amd import ops_f32 as F
+    H, ctx = heads * 128, 256
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    ang = torch.arange(ctx, dtype=torch.float32)[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    kc, vc = torch.zeros((B, heads, ctx, 128)), torch.zeros((B, heads, ctx, 128))
+    if past:
+        kc[:, :, :past], vc[:, :, :past] = rnd((B, heads, past, 128), 6), rnd((B, heads, past, 128), 7)
+    qkv = rnd((B * S, 3 * H), 8)
+    qd, kd, vd = qkv.to(D).clone(), kc.to(D), vc.to(D)
+    F.rope_kv(qd, kd, vd, cos.to(D), sin.to(D), B, S, heads, past)
+    x = qkv.double().view(B, S, 3, heads, 128)
+    pos = torch.arange(S) + past
+    c = torch.cat([cos[pos], cos[pos]], -1).double()[None, :, None]
+    sn = torch.cat([sin[pos], sin[pos]], -1).double()[None, :, None]
+    rot = lambda t: torch.cat([-t[..., 64:], t[..., :64]], -1)  # noqa: E731
+    qr, kr = x[:, :, 0] * c + rot(x[:, :, 0]) * sn, x[:, :, 1] * c + rot(x[:, :, 1]) * sn
+    assert maxabs(qd.cpu().view(B, S, 3, heads, 128)[:, :, 0], qr) < 2e-6
+    assert maxabs(kd.cpu()[:, :, past:past + S], kr.transpose(1, 2)) < 2e-6
+    assert maxabs(vd.cpu()[:, :, past:past + S], x[:, :, 2].transpose(1, 2)) == 0.0
+    kv = past + S
+    valid = torch.ones((B, ctx), dtype=torch.uint8)
+    if pad:
+        valid[0, :pad] = 0
+    out = F.llama_attention(qd, kd, vd, valid.to(D) if pad else None, B, S, heads, past).cpu()
+    K, V = kd.cpu().double()[:, :, :kv], vd.cpu().double()[:, :, :kv]
+    s = qr.transpose(1, 2) @ K.transpose(-1, -2) * 128 ** -0.5
+    i, j = torch.arange(S)[:, None] + past, torch.arange(kv)[None]
+    allowed = (j <= i)[None, None].expand(B, 1, S, kv) & valid[:, None, None, :kv].bool()
+    ref = (torch.softmax(torch.where(allowed, s, torch.tensor(-1e30, dtype=torch.float64)), -1) @ V).transpose(1, 2).reshape(B * S, H)
+    rows = torch.ones(B * S, dtype=torch.bool)
+    if pad and past == 0:
+        rows[:pad] = False                       # fully masked query rows: zeros by contract, don't-care in the reference
+        assert float(out[:pad].abs().max()) == 0.0
+    assert maxabs(out[rows], ref[rows]) < 2e-5
+
+
+def test_norm_patchify_pool_embed_f32():
+    from valley_amd import ops, ops_f32 as F
+    x, g, b = rnd((37, 5120), 9, 2.0) + 0.3, rnd((5120,), 10, 0.1) + 1.0, rnd((5120,), 11, 0.1)
+    assert maxabs(F.norm(x.to(D), g.to(D), b.to(D), 1e-5).cpu(), torch.nn.functional.layer_norm(x.double(), (5120,), g.double(), b.double(), 1e-5)) < 2e-5
+    ref = g.double() * (x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert maxabs(F.norm(x.to(D), g.to(D), None, 1e-6).cpu(), ref) < 2e-5
+    img = rnd((2, 3, 224, 224), 12)
+    cols = F.patchify(img.to(D)).cpu()
+    ref_cols = torch.nn.functional.unfold(img, kernel_size=14, stride=14).transpose(1, 2).reshape(512, 588)
+    assert maxabs(cols[:, :588], ref_cols) == 0.0 and float(cols[:, 588:].abs().max()) == 0.0 and cols.shape[1] == 592
+    Bc, T, W = 2, 5, 256
+    f = rnd((Bc, T, 257, W), 13)
+    sc = rnd((Bc * T,), 14)
+    for mode, pooled in ((ops.POOL_MEAN, f[:, :, 1:].mean(1)), (ops.POOL_MAX, f[:, :, 1:].max(1)[0]),
+                         (ops.POOL_IMPORTANCE, (torch.softmax(sc.view(Bc, T), 1)[:, :, None, None] * f[:, :, 1:]).sum(1))):
+        out = F.pool_tokens(f.to(D).view(-1, W), Bc, T, mode, sc.to(D) if mode == ops.POOL_IMPORTANCE else None).cpu()
+        assert maxabs(out, torch.cat([pooled, f[:, :, 0]], 1)) < 2e-6
+    emb, vis = rnd((50, 256), 15), rnd((7, 256), 16)
+    rmap = torch.tensor([0, 49, -1, -7, 3, -2, 10], dtype=torch.int32)
+    out = F.embed_splice(rmap.to(D), emb.to(D), vis.to(D)).cpu()
+    assert maxabs(out, torch.stack([emb[v] if v >= 0 else vis[-v - 1] for v in rmap.tolist()])) == 0.0
+
+
+# ---- the whole path in fp32 mode --------------------------------------------------------------------------------------
+def build_model(method="mean", precision="fp32"):
+    from valley_amd import valley_model as vm
+    c = G.GCFG
+    cfg = vm.ValleyConfig(vocab_size=c["vocab"], hidden_size=c["H"], intermediate_size=c["I"], num_hidden_layers=c["L"],
+                          num_attention_heads=c["heads"], num_key_value_heads=c["heads"], rms_norm_eps=c["eps"], max_position_embeddings=2048)
+    cfg.use_mm_proj, cfg.mm_hidden_size, cfg.mm_vision_select_layer, cfg.valley_precision = True, 1024, -2, precision
+    model = vm.ValleyLlamaForCausalLM(cfg)
+    sd = dict(G.llama_state())
+    sd.update(G.extra_pool_state(method))
+    model.load_state_dict(sd)
+    tower = vm.build_vision_tower(dict(intermediate_size=c["VI"], num_hidden_layers=c["VL"]), state_dict=G.vision_state(), precision=precision)
+    for k, v in G.special().items():
+        setattr(tower.config, k, v)
+    model.get_model().vision_tower = tower
+    model.get_model().patch_pooling_method = method
+    return model
+
+
+def test_fp32_mode_tower_vs_reference_fixture():
+    g = np.load(os.path.join(GOLD, "g1_tower.npz"))
+    tower = build_model().get_model().vision_tower
+    assert tower.precision == "fp32"
+    px = torch.from_numpy(G.golden_pixels(2, "g1"))
+    sel = tower.encode(px.cuda(), select_layer=-2).cpu().numpy()
+    print("fp32 tower max-abs", maxabs(sel[:1], g["hs_sel_full"]))
+    assert maxabs(sel[:1], g["hs_sel_full"]) < 2e-4                      # |x| up to ~15
+    for i, h in enumerate(tower(px.cuda(), output_hidden_states=True).hidden_states):
+        assert maxabs(h.cpu().numpy()[:, ::8, ::4], g[f"hs{i}"]) < 2e-4, i
+
+
+@pytest.mark.parametrize("method", ["mean", "max", "temporal_importance"])
+def test_fp32_mode_logits_within_1e3_of_reference(method):
+    """The north-star bound on the reference-captured fixtures: B = 2, left-padded, mixed text / visual tokens."""
+    g = np.load(os.path.join(GOLD, f"g2_forward_{method}.npz"))
+    model = build_model(method)
+    T = G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224).cuda()
+    emb = model.get_model().embed_inputs(torch.from_numpy(ids), images).view(2, -1, G.GCFG["H"]).cpu().numpy()
+    out = model(input_ids=torch.from_numpy(ids).cuda(), images=images, attention_mask=torch.from_numpy(mask).cuda())
+    logits = out.logits.cpu().numpy()
+    v = mask.astype(bool)
+    got, vv = (logits, v) if method == "mean" else (logits[:, ::4], v[:, ::4])
+    e_emb, e_log = maxabs(emb, g["embeds"]), maxabs(got[vv], g["logits"][vv])
+    print(f"fp32 mode / {method}: spliced-embedding max-abs {e_emb:.2e}, logits max-abs {e_log:.2e} (bound {TOL_FP32})")
+    assert e_emb < 2e-4 and e_log < TOL_FP32
+
+
+def test_fp32_mode_splice_cases_and_decode_vs_reference():
+    model = build_model()
+    T = G.GCFG["T"]
+    img1 = torch.from_numpy(G.golden_pixels(T, "mixed")).view(1, T, 3, 224, 224).cuda()
+    for case in ("mixed", "two_images", "frame_mismatch"):
+        g = np.load(os.path.join(GOLD, f"g3_{case}.npz"))
+        ids, mask = G.golden_ids(case)
+        out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1, attention_mask=torch.from_numpy(mask).cuda())
+        v = mask.astype(bool)[:, ::4]
+        assert maxabs(out.logits.cpu().numpy()[:, ::4][v], g["logits"][v]) < TOL_FP32, case
+    # prefill + 8 KV-cache decode steps (the generic forward on the fp32 cache) vs the reference loop
+    g = np.load(os.path.join(GOLD, "g5_decode2.npz"))
+    ids, _ = G.golden_ids("decode2")
+    out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1, use_cache=True)
+    past, logits, worst = out.past_key_values, out.logits, 0.0
+    for step in range(8):
+        last = logits[:, -1].cpu().numpy()
+        worst = max(worst, maxabs(last, g["last_logits"][:, step]))
+        assert int(last.argmax()) == int(g["tokens"][0, step])
+        assert past[0][0].shape[-2] == ids.shape[1] + step and past[0][0].dtype == torch.float32
+        tok = torch.from_numpy(g["tokens"][:, step]).cuda()
+        o = model(input_ids=tok[:, None], use_cache=True, past_key_values=past,
+                  attention_mask=torch.ones(1, past.get_seq_length() + 1, dtype=torch.long).cuda())
+        logits, past = o.logits, o.past_key_values
+    print("fp32 mode decode: worst last-position logit error over 8 steps", worst)
+    assert worst < TOL_FP32
+    seq = model.generate(torch.from_numpy(ids).cuda(), images=img1, max_new_tokens=8)
+    assert seq[0, ids.shape[1]:].tolist() == g["tokens"][0].tolist()
+
+
+def test_fp32_mode_13b_layer_shapes_within_1e3_of_oracle():
+    """2 decoder layers + final norm + lm_head at the Vicuna-13B layer shapes (H 5120, 40 heads, I 13824, eps 1e-6),
+    B = 2 x S = 336 with left padding, fp32 mode vs the fp32 oracle: the 1e-3 bound at production width."""
+    from oracle import valley_oracle as O
+    from valley_amd import weights as W
+    from valley_amd.precise import PreciseLlama
+    H, heads, I, V, B, S = 5120, 40, 13824, 512, 2, 336
+    sd = W.valley_llama_weights(5, V, H, I, 2)
+    ll = PreciseLlama(H, heads, I, 2, V, 1e-6).load_state_dict(sd)
+    emb = W.det_normal(9, "emb.13b", (B, S, H), 0.5)
+    mask = np.ones((B, S), np.int64)
+    mask[1, :11] = 0
+    cache = ll.new_cache(B, S)
+    cache.key_valid = torch.from_numpy(mask).to(torch.uint8).cuda()
+    x = ll.forward(torch.from_numpy(emb).cuda().view(B * S, H).clone(), B, S, cache)
+    got = ll.logits(x).view(B, S, -1).cpu().numpy()
+    with torch.no_grad():
+        ref_h, _ = O.llama_forward(torch.from_numpy(emb), sd, O.LlamaCfg(hidden=H, heads=heads, intermediate=I, layers=2, vocab=V, eps=1e-6),
+                                   torch.from_numpy(mask))
+        ref = torch.nn.functional.linear(ref_h, torch.from_numpy(sd["lm_head.weight"])).numpy()
+    v = mask.astype(bool)
+    e = maxabs(got[v], ref[v])
+    print(f"fp32 mode, 13B layer shapes: logits max-abs {e:.2e} (|logit| max {float(np.abs(ref[v]).max()):.2f}), rel-L2 {rel(got[v], ref[v]):.1e}")
+    assert e < TOL_FP32
+
+
+# ---- (ii) the bf16 path against the same-dtype oracle --------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["mean", "max"])
+def test_bf16_path_vs_same_dtype_oracle(method):
+    """The production bf16 path vs oracle.rounding() (bf16 rounding at the pipeline's storage points): what remains is fp32
+    summation order and the online-softmax form.  Also prints the distance of both to the fp32 reference fixture."""
+    from oracle import valley_oracle as O
+    g = np.load(os.path.join(GOLD, f"g2_forward_{method}.npz"))
+    model = build_model(method, precision="bf16")
+    c, T = G.GCFG, G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    px = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224)
+    out = model(input_ids=torch.from_numpy(ids).cuda(), images=px.cuda(), attention_mask=torch.from_numpy(mask).cuda())
+    got = out.logits.cpu().numpy()
+    lcfg = O.LlamaCfg(hidden=c["H"], heads=c["heads"], intermediate=c["I"], layers=c["L"], vocab=c["vocab"], eps=c["eps"])
+    vcfg = O.VisionCfg(intermediate=c["VI"], layers=c["VL"])
+    with torch.no_grad(), O.rounding():
+        same, _, _ = O.valley_forward(torch.from_numpy(ids), px, G.llama_state(), G.vision_state(), lcfg, vcfg, O.TokenIds(**G.special()),
+                                      torch.from_numpy(mask), method=method)
+    same = same.numpy()
+    v = mask.astype(bool)
+    ref = g["logits"] if method == "mean" else None
+    e_same = maxabs(got[v], same[v])
+    msg = f"bf16 path / {method}: vs same-dtype oracle max-abs {e_same:.2e} rel-L2 {rel(got[v], same[v]):.1e}"
+    if ref is not None:
+        msg += f"; vs fp32 reference {maxabs(got[v], ref[v]):.2e}; same-dtype oracle vs fp32 reference {maxabs(same[v], ref[v]):.2e}"
+    print(msg)
+    assert e_same < 1.2e-2                     # tightened to ~1.5x the measurement in DESIGN §2 once measured

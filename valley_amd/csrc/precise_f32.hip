@@ -1,0 +1,351 @@
+// fp32 "precise" path (VALLEY_PRECISION=fp32): every tensor on the path is fp32 and every contraction runs on the exact
+// f32-input matrix instruction v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md §Matrix cores: bitwise an fmaf chain, 157 TF
+// peak = 1/16 of the bf16 rate).  Purpose: demonstrate BASELINE.json's "logits within 1e-3 of reference" against the
+// fp32 reference, which bf16 operands cannot reach (one bf16 rounding is 4e-3 relative) — SURVEY.md §7 "hard parts",
+// §8c tolerances.  These kernels are written for clarity and exactness, not for the roofline; the production path is
+// the bf16 pipeline (gemm_bf16.hip, attention.hip, ...).
+//
+// Replaces, at fp32: K1-K18 of SURVEY.md §2.2 —
+//   vly_gemm_f32          nn.Linear / conv-as-GEMM (+bias, quick_gelu | SwiGLU | ReLU, +residual)   hf:clip 148-154,293-350; hf:llama 160-173,230-241
+//   vly_attention_f32     softmax(QK^T * hd^-0.5 [+ causal/padding mask]) V, fp32 softmax            hf:clip 259-277; hf:llama 191-213
+//   vly_norm_f32          LayerNorm / RMSNorm                                                         hf:clip 605,642; hf:llama 51-67
+//   vly_rope_kv_f32       rotate-half RoPE of q,k + KV-cache append                                  hf:llama 127-157
+//   vly_patchify_f32      im2col of the 14x14 patch conv                                              hf:clip 148-154
+//   vly_pool_tokens_f32   temporal mean / max / importance pooling + CLS pick                         valley_model.py:206-215,113-121
+//   vly_embed_splice_f32  embedding gather + visual-token splice by row map                           valley_model.py:160,195-247
+#include "common.hpp"
+#include "../../include/valley_hip.h"
+
+namespace {
+
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+
+// ------------------------------------------------------------------------------------------------------------------
+// GEMM: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) + residual, all fp32.  64x64 tile per 256-thread workgroup, each of the
+// four waves owns 32x32 of it as ONE 32x32x2 accumulator block; K advances 16 per LDS tile (8 MFMAs per wave and tile).
+// The W fragment is the MFMA's first operand (as in the bf16 kernels), so a lane ends up with 4 consecutive n for one m:
+// register r of the 16 holds C[m = lane & 31][n = 8*(r/4) + 4*(lane >> 5) + r % 4].
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GB = 64, GK = 16, GLD = GK + 1;        // +1 float: ds_read_b32 of a column is conflict-free
+
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ R,
+                                                       float* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc,
+                                                       int ldr) {
+    __shared__ float sA[GB * GLD], sW[GB * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int l31 = lane & 31, hk = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging: thread -> (row = tid / 4, 4 consecutive k); rows past the edge re-read the last valid row (masked at the store)
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const float* ga = A + (size_t)min(m0 + srow, M - 1) * lda + sk;
+    const float* gw = W + (size_t)min(n0 + srow, N - 1) * ldw + sk;
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        const f32x4 va = *(const f32x4*)(ga + k0), vw = *(const f32x4*)(gw + k0);
+        __syncthreads();                                  // everyone finished reading the previous tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sA[srow * GLD + sk + i] = va[i];
+            sW[srow * GLD + sk + i] = vw[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float w = sW[(wn + l31) * GLD + kk + hk];
+            const float a = sA[(wm + l31) * GLD + kk + hk];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w, a, acc, 0, 0, 0);
+        }
+    }
+    const int m = m0 + wm + l31;
+    if (m >= M) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn + 8 * q + 4 * hk;
+        if (n >= N) continue;                              // N % 4 == 0: a group of 4 is inside or outside as a whole
+        f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        if (bias) v += *(const f32x4*)(bias + n);
+        if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + expf(-1.702f * v[r]));
+        }
+        if constexpr (EPI == VLY_EPI_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if constexpr (EPI == VLY_EPI_SWIGLU) {             // rows of W interleaved (gate, up): out column = n / 2
+            const float o0 = v[0] / (1.f + expf(-v[0])) * v[1];
+            const float o1 = v[2] / (1.f + expf(-v[2])) * v[3];
+            *(float2*)(C + (size_t)m * ldc + (n >> 1)) = make_float2(o0, o1);
+        } else {
+            if (R) v += *(const f32x4*)(R + (size_t)m * ldr + n);
+            *(f32x4*)(C + (size_t)m * ldc + n) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Attention: one wave per (query row, head, batch).  Keys are visited in chunks of 64 (lane j scores key j of the
+// chunk against the query held in LDS), online softmax in fp32, then every lane owns output dims {lane, lane + 64}.
+// ------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(64) attention_f32_kernel(const float* __restrict__ Q, long q_bs, int q_rs,
+                                                           const float* __restrict__ Kp, const float* __restrict__ Vp,
+                                                           long kv_bs, long kv_hs, int kv_rs, const uint8_t* __restrict__ key_valid,
+                                                           int kv_valid_stride, float* __restrict__ O, long o_bs, int o_rs,
+                                                           int n_q, int n_kv, int causal, int past, float scale) {
+    __shared__ float sq[HD];
+    const int lane = threadIdx.x, qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const float* q = Q + b * q_bs + (size_t)qi * q_rs + h * HD;
+    for (int d = lane; d < HD; d += 64) sq[d] = q[d];
+    __syncthreads();
+    const float* kb = Kp + b * kv_bs + h * kv_hs;
+    const float* vb = Vp + b * kv_bs + h * kv_hs;
+    const uint8_t* valid = key_valid ? key_valid + (size_t)b * kv_valid_stride : nullptr;
+    const int last = causal ? min(n_kv - 1, qi + past) : n_kv - 1;        // keys 0..last are visible
+    float m_run = -INFINITY, l_run = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int j0 = 0; j0 <= last; j0 += 64) {
+        const int j = j0 + lane;
+        float s = -INFINITY;
+        if (j <= last && (!valid || valid[j])) {
+            const float* kr = kb + (size_t)j * kv_rs;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < HD; d += 4) {
+                const f32x4 kv = *(const f32x4*)(kr + d);
+                acc = fmaf(sq[d], kv[0], acc);
+                acc = fmaf(sq[d + 1], kv[1], acc);
+                acc = fmaf(sq[d + 2], kv[2], acc);
+                acc = fmaf(sq[d + 3], kv[3], acc);
+            }
+            s = acc * scale;
+        }
+        const float m_new = fmaxf(m_run, wave_max(s));
+        if (m_new == -INFINITY) continue;                  // nothing visible yet (left padding)
+        const float p = s == -INFINITY ? 0.f : expf(s - m_new);
+        const float corr = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+        l_run = l_run * corr + wave_sum(p);
+        o0 *= corr;
+        o1 *= corr;
+        const int nj = min(64, last + 1 - j0);
+        for (int t = 0; t < nj; ++t) {
+            const float pt = __shfl(p, t, 64);
+            const float* vr = vb + (size_t)(j0 + t) * kv_rs;
+            o0 = fmaf(pt, vr[lane], o0);
+            if (HD > 64) o1 = fmaf(pt, vr[lane + 64], o1);
+        }
+        m_run = m_new;
+    }
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;     // a fully masked (padded) query row yields zeros
+    float* o = O + b * o_bs + (size_t)qi * o_rs + h * HD;
+    o[lane] = o0 * inv;
+    if (HD > 64) o[lane + 64] = o1 * inv;
+}
+
+// LayerNorm (beta != null) / RMSNorm (rms != 0): wave per row, fp32 statistics over the whole row.
+__global__ void __launch_bounds__(256) norm_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y, int M, int D,
+                                                       float eps, int rms) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d];
+    const float mean = rms ? 0.f : wave_sum(s) / D;
+    float v = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float c = xr[d] - mean;
+        v = fmaf(c, c, v);
+    }
+    const float rstd = rsqrtf(wave_sum(v) / D + eps);
+    float* yr = y + (size_t)row * D;
+    for (int d = lane; d < D; d += 64) {
+        const float n = (xr[d] - mean) * rstd;
+        yr[d] = rms ? gamma[d] * n : fmaf(n, gamma[d], beta[d]);
+    }
+}
+
+// rotate-half RoPE of q (in place) and k (into the cache) + v append; one thread per (token, head, d < 64)
+__global__ void __launch_bounds__(256) rope_kv_f32_kernel(float* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc,
+                                                          const float* __restrict__ cs, const float* __restrict__ sn, int B, int S,
+                                                          int heads, int past, int ctx_max) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d = (int)(i & 63);
+    const long u = i >> 6;
+    if (u >= (long)B * S * heads) return;
+    const int h = (int)(u % heads);
+    const long tok = u / heads;
+    const int s = (int)(tok % S), b = (int)(tok / S);
+    const int pos = past + s;
+    const float c = cs[pos * 64 + d], sv = sn[pos * 64 + d];
+    const int H = heads * 128;
+    float* row = qkv + (size_t)tok * 3 * H;
+    float* q = row + h * 128;
+    const float q0 = q[d], q1 = q[d + 64];
+    q[d] = rope_rot(q0, q1, c, sv, -1.f);
+    q[d + 64] = rope_rot(q1, q0, c, sv, 1.f);
+    const float* k = row + H + h * 128;
+    const float* v = row + 2 * H + h * 128;
+    const size_t o = (((size_t)b * heads + h) * ctx_max + pos) * 128;
+    kc[o + d] = rope_rot(k[d], k[d + 64], c, sv, -1.f);
+    kc[o + d + 64] = rope_rot(k[d + 64], k[d], c, sv, 1.f);
+    vc[o + d] = v[d];
+    vc[o + d + 64] = v[d + 64];
+}
+
+// im2col of Conv2d(3 -> 1024, k = 14, s = 14): [F,3,224,224] -> [F*256, KP], column = c*196 + ky*14 + kx, zero padded to KP
+__global__ void __launch_bounds__(256) patchify_f32_kernel(const float* __restrict__ img, float* __restrict__ out, long total, int KP) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % KP);
+    const long row = i / KP;
+    float v = 0.f;
+    if (col < 588) {
+        const int c = col / 196, r = col % 196, ky = r / 14, kx = r % 14;
+        const int f = (int)(row >> 8), p = (int)(row & 255), py = p >> 4, px = p & 15;
+        v = img[(((size_t)f * 3 + c) * 224 + py * 14 + ky) * 224 + px * 14 + kx];
+    }
+    out[i] = v;
+}
+
+// feats [B*T*257, W] -> out [B, 256 + T, W]: rows 0..255 pooled patch tokens, rows 256.. the T CLS tokens
+__global__ void __launch_bounds__(256) pool_f32_kernel(const float* __restrict__ feats, float* __restrict__ out, int B, int T, int W,
+                                                       int mode, const float* __restrict__ scores) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * (256 + T) * W) return;
+    const int w = (int)(i % W);
+    const long r = i / W;
+    const int row = (int)(r % (256 + T)), b = (int)(r / (256 + T));
+    const float* f = feats + (size_t)b * T * 257 * W;
+    float v;
+    if (row >= 256) {
+        v = f[(size_t)(row - 256) * 257 * W + w];
+    } else if (mode == VLY_POOL_MAX) {
+        v = -INFINITY;
+        for (int t = 0; t < T; ++t) v = fmaxf(v, f[((size_t)t * 257 + 1 + row) * W + w]);
+    } else if (mode == VLY_POOL_IMPORTANCE) {
+        float mx = -INFINITY, den = 0.f;
+        for (int t = 0; t < T; ++t) mx = fmaxf(mx, scores[b * T + t]);
+        v = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float e = expf(scores[b * T + t] - mx);
+            den += e;
+            v = fmaf(e, f[((size_t)t * 257 + 1 + row) * W + w], v);
+        }
+        v /= den;
+    } else {
+        v = 0.f;
+        for (int t = 0; t < T; ++t) v += f[((size_t)t * 257 + 1 + row) * W + w];
+        v /= T;
+    }
+    out[i] = v;
+}
+
+__global__ void __launch_bounds__(256) embed_splice_f32_kernel(const int32_t* __restrict__ row_map, const float* __restrict__ embed,
+                                                               const float* __restrict__ visual, float* __restrict__ out, long total,
+                                                               int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int r = row_map[i / H], c = (int)(i % H);
+    out[i] = r >= 0 ? embed[(size_t)r * H + c] : visual[(size_t)(-r - 1) * H + c];
+}
+
+}  // namespace
+
+extern "C" int vly_gemm_f32(const float* A, const float* W, const float* bias, const float* residual, float* C, int M, int N,
+                            int K, int lda, int ldw, int ldc, int ldr, int epilogue, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % GK || N % 4 || lda % 4 || ldw % 4 || ldc % 2 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||
+        ((uintptr_t)C & 7) || (epilogue != VLY_EPI_SWIGLU && (ldc % 4 || ((uintptr_t)C & 15))) ||
+        (bias && ((uintptr_t)bias & 15)) || (residual && (ldr % 4 || ((uintptr_t)residual & 15))) ||
+        (epilogue == VLY_EPI_SWIGLU && residual)) {
+        vly_set_error("vly_gemm_f32: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d epi=%d", M, N, K, lda, ldw,
+                      ldc, ldr, epilogue);
+        return -22;
+    }
+    dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define VLY_F32_LAUNCH(E) hipLaunchKernelGGL((gemm_f32_kernel<E>), grid, block, 0, st, A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr)
+    switch (epilogue) {
+        case VLY_EPI_NONE: VLY_F32_LAUNCH(VLY_EPI_NONE); break;
+        case VLY_EPI_QUICK_GELU: VLY_F32_LAUNCH(VLY_EPI_QUICK_GELU); break;
+        case VLY_EPI_SWIGLU: VLY_F32_LAUNCH(VLY_EPI_SWIGLU); break;
+        case VLY_EPI_RELU: VLY_F32_LAUNCH(VLY_EPI_RELU); break;
+        default: vly_set_error("vly_gemm_f32: bad epilogue %d", epilogue); return -22;
+    }
+#undef VLY_F32_LAUNCH
+    return vly_check_launch("vly_gemm_f32");
+}
+
+extern "C" int vly_attention_f32(const float* q, long q_batch_stride, int q_row_stride, const float* k, const float* v,
+                                 long kv_batch_stride, long kv_head_stride, int kv_row_stride, const uint8_t* key_valid,
+                                 int key_valid_stride, float* out, long out_batch_stride, int out_row_stride, int B, int heads,
+                                 int n_q, int n_kv, int head_dim, int causal, int past_len, void* stream) {
+    if (B <= 0 || heads <= 0 || n_q <= 0 || n_kv <= 0 || (head_dim != 64 && head_dim != 128) || kv_row_stride % 4 ||
+        ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || kv_batch_stride % 4 || kv_head_stride % 4) {
+        vly_set_error("vly_attention_f32: bad args B=%d heads=%d n_q=%d n_kv=%d hd=%d", B, heads, n_q, n_kv, head_dim);
+        return -22;
+    }
+    const float scale = 1.f / sqrtf((float)head_dim);
+    dim3 grid(n_q, heads, B), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 64)
+        hipLaunchKernelGGL((attention_f32_kernel<64>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+                           kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
+                           causal, past_len, scale);
+    else
+        hipLaunchKernelGGL((attention_f32_kernel<128>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+                           kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
+                           causal, past_len, scale);
+    return vly_check_launch("vly_attention_f32");
+}
+
+extern "C" int vly_norm_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int D, float eps, int rms,
+                            void* stream) {
+    if (M <= 0 || D <= 0 || !gamma || (!rms && !beta)) { vly_set_error("vly_norm_f32: bad args M=%d D=%d", M, D); return -22; }
+    hipLaunchKernelGGL(norm_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, M, D, eps, rms);
+    return vly_check_launch("vly_norm_f32");
+}
+
+extern "C" int vly_rope_kv_f32(float* qkv, float* kcache, float* vcache, const float* cos_table, const float* sin_table, int B,
+                               int S, int heads, int past_len, int ctx_max, void* stream) {
+    if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || past_len + S > ctx_max) {
+        vly_set_error("vly_rope_kv_f32: bad args B=%d S=%d heads=%d past=%d ctx_max=%d", B, S, heads, past_len, ctx_max);
+        return -22;
+    }
+    const long n = (long)B * S * heads * 64;
+    hipLaunchKernelGGL(rope_kv_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, kcache, vcache,
+                       cos_table, sin_table, B, S, heads, past_len, ctx_max);
+    return vly_check_launch("vly_rope_kv_f32");
+}
+
+extern "C" int vly_patchify_f32(const float* images, float* patches, int F, int k_padded, void* stream) {
+    if (F <= 0 || k_padded < 588) { vly_set_error("vly_patchify_f32: bad args F=%d KP=%d", F, k_padded); return -22; }
+    const long total = (long)F * 256 * k_padded;
+    hipLaunchKernelGGL(patchify_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, patches,
+                       total, k_padded);
+    return vly_check_launch("vly_patchify_f32");
+}
+
+extern "C" int vly_pool_tokens_f32(const float* feats, float* out, int B, int T, int W, int mode, const float* scores, void* stream) {
+    if (B <= 0 || T <= 0 || W <= 0 || mode < VLY_POOL_MEAN || mode > VLY_POOL_IMPORTANCE || (mode == VLY_POOL_IMPORTANCE && !scores)) {
+        vly_set_error("vly_pool_tokens_f32: bad args B=%d T=%d W=%d mode=%d", B, T, W, mode);
+        return -22;
+    }
+    const long total = (long)B * (256 + T) * W;
+    hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feats, out, B, T, W,
+                       mode, scores);
+    return vly_check_launch("vly_pool_tokens_f32");
+}
+
+extern "C" int vly_embed_splice_f32(const int32_t* row_map, const float* embed, const float* visual, float* out, int R, int H,
+                                    void* stream) {
+    if (R <= 0 || H <= 0) { vly_set_error("vly_embed_splice_f32: bad args R=%d H=%d", R, H); return -22; }
+    const long total = (long)R * H;
+    hipLaunchKernelGGL(embed_splice_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row_map, embed,
+                       visual, out, total, H);
+    return vly_check_launch("vly_embed_splice_f32");
+}

@@ -50,9 +50,18 @@ _SIGS = {
     "vly_add2_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
+    # fp32 "precise" path
+    "vly_gemm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_attention_f32": (c_int, [_P, c_long, c_int, _P, _P, c_long, c_long, c_int, _P, c_int, _P, c_long, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_norm_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P]),
+    "vly_rope_kv_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_patchify_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vly_pool_tokens_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vly_embed_splice_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ValleyHipError(RuntimeError):

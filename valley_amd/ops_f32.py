@@ -1,0 +1,128 @@
+"""Typed wrappers of the fp32 "precise" entry points (include/valley_hip.h, vly_*_f32; valley_amd/csrc/precise_f32.hip).
+Same conventions as valley_amd.ops: torch device tensors in, raw pointers + the current HIP stream to the C ABI."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+from .ops import EPI_NONE, EPI_SWIGLU, POOL_MEAN, _chk, _ptr, _stream
+
+F32 = torch.float32
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual, fp32 operands on the exact f32 MFMA."""
+    _chk(a, F32, "a", contiguous=False)
+    _chk(w, F32, "w", contiguous=False)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1, (a.shape, w.shape)
+    No = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, No), dtype=F32, device=a.device)
+    else:
+        _chk(out, F32, "out", contiguous=False)
+        assert tuple(out.shape) == (M, No) and out.stride(1) == 1
+    if bias is not None:
+        _chk(bias, F32, "bias")
+    if residual is not None:
+        _chk(residual, F32, "residual", contiguous=False)
+        assert tuple(residual.shape) == (M, N)
+    rc = _lib.load().vly_gemm_f32(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0),
+                                  w.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, _stream())
+    _lib.check(rc, "vly_gemm_f32")
+    return out
+
+
+def norm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm (beta given) or RMSNorm (beta None), fp32 -> fp32."""
+    _chk(x, F32, "x")
+    M, D = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    rc = _lib.load().vly_norm_f32(x.data_ptr(), gamma.data_ptr(), _ptr(beta), y.data_ptr(), M, D, eps, 0 if beta is not None else 1,
+                                  _stream())
+    _lib.check(rc, "vly_norm_f32")
+    return y
+
+
+def vit_attention(qkv: torch.Tensor, F: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv fp32 [F*257, 3072] (q | k | v, 16 heads x 64) -> fp32 [F*257, 1024]; no mask."""
+    _chk(qkv, F32, "qkv")
+    assert tuple(qkv.shape) == (F * 257, 3072)
+    if out is None:
+        out = torch.empty((F * 257, 1024), dtype=F32, device=qkv.device)
+    base = qkv.data_ptr()
+    rc = _lib.load().vly_attention_f32(base, 257 * 3072, 3072, base + 1024 * 4, base + 2048 * 4, 257 * 3072, 64, 3072, None, 0,
+                                       out.data_ptr(), 257 * 1024, 1024, F, 16, 257, 257, 64, 0, 0, _stream())
+    _lib.check(rc, "vly_attention_f32")
+    return out
+
+
+def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, key_valid: Optional[torch.Tensor], B: int, S: int,
+                    heads: int, past_len: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rotated q rows fp32 [B*S, 3*heads*128] + fp32 caches [B,heads,ctx_max,128] -> fp32 [B*S, heads*128]; causal + key validity."""
+    _chk(qkv, F32, "qkv")
+    _chk(kcache, F32, "kcache")
+    _chk(vcache, F32, "vcache")
+    H = heads * 128
+    ctx_max = kcache.shape[2]
+    assert tuple(kcache.shape) == (B, heads, ctx_max, 128) and past_len + S <= ctx_max
+    kvs = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        kvs = key_valid.stride(0)
+    if out is None:
+        out = torch.empty((B * S, H), dtype=F32, device=qkv.device)
+    rc = _lib.load().vly_attention_f32(qkv.data_ptr(), S * 3 * H, 3 * H, kcache.data_ptr(), vcache.data_ptr(), heads * ctx_max * 128,
+                                       ctx_max * 128, 128, _ptr(key_valid), kvs, out.data_ptr(), S * H, H, B, heads, S, past_len + S, 128,
+                                       1, past_len, _stream())
+    _lib.check(rc, "vly_attention_f32")
+    return out
+
+
+def rope_kv(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, B: int, S: int,
+            heads: int, past_len: int):
+    _chk(qkv, F32, "qkv")
+    _chk(kcache, F32, "kcache")
+    _chk(vcache, F32, "vcache")
+    ctx_max = kcache.shape[2]
+    assert cos.shape[0] >= past_len + S and cos.shape[1] == 64
+    rc = _lib.load().vly_rope_kv_f32(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, S, heads,
+                                     past_len, ctx_max, _stream())
+    _lib.check(rc, "vly_rope_kv_f32")
+
+
+def patchify(images: torch.Tensor, k_padded: int = 592) -> torch.Tensor:
+    _chk(images, F32, "images")
+    F = images.shape[0]
+    assert tuple(images.shape[1:]) == (3, 224, 224)
+    out = torch.empty((F * 256, k_padded), dtype=F32, device=images.device)
+    rc = _lib.load().vly_patchify_f32(images.data_ptr(), out.data_ptr(), F, k_padded, _stream())
+    _lib.check(rc, "vly_patchify_f32")
+    return out
+
+
+def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN, scores: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(feats, F32, "feats")
+    W = feats.shape[-1]
+    assert feats.numel() == B * T * 257 * W
+    out = torch.empty((B, 256 + T, W), dtype=F32, device=feats.device)
+    rc = _lib.load().vly_pool_tokens_f32(feats.data_ptr(), out.data_ptr(), B, T, W, mode, _ptr(scores), _stream())
+    _lib.check(rc, "vly_pool_tokens_f32")
+    return out
+
+
+def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(row_map, torch.int32, "row_map")
+    _chk(embed, F32, "embed")
+    if visual is not None:
+        _chk(visual, F32, "visual")
+    R, H = row_map.numel(), embed.shape[1]
+    if out is None:
+        out = torch.empty((R, H), dtype=F32, device=embed.device)
+    rc = _lib.load().vly_embed_splice_f32(row_map.data_ptr(), embed.data_ptr(), _ptr(visual), out.data_ptr(), R, H, _stream())
+    _lib.check(rc, "vly_embed_splice_f32")
+    return out

@@ -21,8 +21,9 @@ from typing import Dict, List, Optional, Sequence, Union
 import numpy as np
 import torch
 
-from . import ops, runtime
+from . import ops, ops_f32, runtime
 from .llama import HipKVCache, HipLlama
+from .precise import F32KVCache, PreciseCLIPVisionTower, PreciseLlama
 from .splice import build_row_map
 from .vision_tower import HipCLIPVisionTower, VisionConfig
 
@@ -61,11 +62,21 @@ else:                                                    # pragma: no cover
         model_type = "valley"
 
 
-def build_vision_tower(config_or_name=None, device="cuda:0", state_dict: Optional[Dict] = None, **kw) -> HipCLIPVisionTower:
+def default_precision() -> str:
+    """"bf16" (production: bf16 MFMA operands, fp32 accumulation and residual stream) or "fp32" (validation: every tensor
+    fp32, exact f32 MFMA — valley_amd/precise.py), from VALLEY_PRECISION."""
+    p = os.environ.get("VALLEY_PRECISION", "bf16").lower()
+    if p not in ("bf16", "fp32"):
+        raise ValueError(f"VALLEY_PRECISION must be bf16 or fp32, got {p!r}")
+    return p
+
+
+def build_vision_tower(config_or_name=None, device="cuda:0", state_dict: Optional[Dict] = None, precision: Optional[str] = None,
+                       **kw) -> HipCLIPVisionTower:
     """Factory named by the north star (absent in the reference snapshot).  Accepts a
     ``VisionConfig``/HF ``CLIPVisionConfig``-like object, a dict, or a checkpoint directory holding
     ``config.json`` + safetensors/bin weights (the role of ``CLIPVisionModel.from_pretrained`` at
-    valley_model.py:38,66)."""
+    valley_model.py:38,66).  ``precision``: "bf16" | "fp32" (default: VALLEY_PRECISION)."""
     cfg = VisionConfig(**kw)
     if isinstance(config_or_name, dict):
         cfg = VisionConfig(**{**config_or_name, **kw})
@@ -76,7 +87,8 @@ def build_vision_tower(config_or_name=None, device="cuda:0", state_dict: Optiona
         fields = ("hidden_size", "num_attention_heads", "intermediate_size", "num_hidden_layers", "image_size",
                   "patch_size", "layer_norm_eps", "hidden_act")
         cfg = VisionConfig(**{f: getattr(config_or_name, f) for f in fields if hasattr(config_or_name, f)})
-    tower = HipCLIPVisionTower(cfg, device=device)
+    cls = PreciseCLIPVisionTower if (precision or default_precision()) == "fp32" else HipCLIPVisionTower
+    tower = cls(cfg, device=device)
     if state_dict is not None:
         tower.load_state_dict(state_dict)
     return tower
@@ -91,7 +103,10 @@ class HipLinear:
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         shp = x.shape
-        y = ops.gemm(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous(), self.weight, self.bias)
+        if self.weight.dtype == torch.float32:               # fp32 "precise" mode
+            y = ops_f32.gemm(x.reshape(-1, shp[-1]).to(torch.float32).contiguous(), self.weight, self.bias)
+        else:
+            y = ops.gemm(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous(), self.weight, self.bias)
         return y.view(*shp[:-1], self.out_features)
 
 
@@ -105,15 +120,18 @@ class ValleyLlamaModel:
         self.training = False
         self.patch_pooling_method = "mean"                   # :27
         c = config
-        self.llama = HipLlama(c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers,
-                              c.vocab_size, c.rms_norm_eps, getattr(c, "rope_theta", None) or _rope_theta(c),
-                              getattr(c, "max_position_embeddings", 2048), device=self.device)
+        self.precision = getattr(config, "valley_precision", None) or default_precision()
+        self.wdtype = torch.float32 if self.precision == "fp32" else torch.bfloat16      # dtype of GEMM weights / activations
+        engine = PreciseLlama if self.precision == "fp32" else HipLlama
+        self.llama = engine(c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers,
+                            c.vocab_size, c.rms_norm_eps, getattr(c, "rope_theta", None) or _rope_theta(c),
+                            getattr(c, "max_position_embeddings", 2048), device=self.device)
         self.vision_tower: Optional[HipCLIPVisionTower] = None
         self.mm_projector: Optional[HipLinear] = None
         self.pooling_layer = None                            # v2: SimpleNamespace(weight fp32 [256*H], bias fp32 [1])
         self.delta_encoder = None                            # v3: dict of packed TransformerEncoderLayer weights
         if getattr(config, "mm_vision_tower", None):         # :29-38
-            self.vision_tower = build_vision_tower(config.mm_vision_tower, device=self.device)
+            self.vision_tower = build_vision_tower(config.mm_vision_tower, device=self.device, precision=self.precision)
         if getattr(config, "use_patch_importance_pooling", False):   # :40-43
             self.patch_pooling_method = "temporal_importance"
         if getattr(config, "use_delta_transformer", False):  # :45-52
@@ -128,8 +146,8 @@ class ValleyLlamaModel:
         """valley_model.py:59-103."""
         self.config.mm_vision_tower = vision_tower
         if self.vision_tower is None:
-            self.vision_tower = vision_tower if isinstance(vision_tower, HipCLIPVisionTower) \
-                else build_vision_tower(vision_tower, device=self.device)
+            self.vision_tower = vision_tower if isinstance(vision_tower, (HipCLIPVisionTower, PreciseCLIPVisionTower)) \
+                else build_vision_tower(vision_tower, device=self.device, precision=self.precision)
         vc = self.vision_tower.config
         num_patches = (vc.image_size // vc.patch_size) ** 2
         self.config.use_mm_proj = True
@@ -144,11 +162,11 @@ class ValleyLlamaModel:
         if self.mm_projector is None:
             g = torch.Generator(device=self.device).manual_seed(0)
             w = torch.randn((self.config.hidden_size, vc.hidden_size), generator=g, device=self.device) * vc.hidden_size ** -0.5
-            self.mm_projector = HipLinear(w.to(torch.bfloat16), torch.zeros(self.config.hidden_size, device=self.device))
+            self.mm_projector = HipLinear(w.to(self.wdtype), torch.zeros(self.config.hidden_size, device=self.device))
         if pretrain_mm_mlp_adapter is not None:
             sd = torch.load(pretrain_mm_mlp_adapter, map_location="cpu")
             sd = {k.split(".")[-1]: v for k, v in sd.items()}
-            self.mm_projector = HipLinear(sd["weight"].to(self.device, torch.bfloat16).contiguous(),
+            self.mm_projector = HipLinear(sd["weight"].to(self.device, self.wdtype).contiguous(),
                                           sd["bias"].to(self.device, torch.float32).contiguous())
         return dict(image_processor=_clip_image_processor(vision_tower, vc), image_token_len=num_patches, vision_config=vc)
 
@@ -169,6 +187,8 @@ class ValleyLlamaModel:
         method = self.patch_pooling_method
         if method not in ("mean", "max", "temporal_importance", "temporal_transformer"):
             raise ValueError(f"unknown patch_pooling_method {method!r}")
+        if self.precision == "fp32":
+            return self._pool_precise(feats, Ts, method)
         W = 1024
         if method in ("max", "temporal_importance", "temporal_transformer"):
             # max does not commute with the projector: project every token first (reference order)
@@ -199,6 +219,26 @@ class ValleyLlamaModel:
             pooled = torch.cat(outs, 0)
         return pooled, Ts
 
+    def _pool_precise(self, feats: torch.Tensor, Ts: List[int], method: str):
+        """fp32 mode, in the REFERENCE's order for every variant: project all tokens (valley_model.py:190), then pool
+        (:206-215) — no pool-before-project reordering, no bf16 anywhere.  Returns projected tokens fp32 [sum(256+T), H]."""
+        if method == "temporal_transformer":
+            raise NotImplementedError("the v3 temporal transformer has no fp32 mode (its attention kernel is bf16); use the bf16 path")
+        proj = ops_f32.gemm(feats.view(-1, 1024), self.mm_projector.weight, self.mm_projector.bias)
+        W = proj.shape[-1]
+        mode = {"mean": ops.POOL_MEAN, "max": ops.POOL_MAX, "temporal_importance": ops.POOL_IMPORTANCE}[method]
+        scores = None
+        if method == "temporal_importance":
+            if self.pooling_layer is None:
+                raise RuntimeError("temporal_importance pooling needs model.pooling_layer weights")
+            scores = ops.temporal_scores(proj, self.pooling_layer.weight, self.pooling_layer.bias, sum(Ts))
+        outs, f0 = [], 0
+        for T in Ts:
+            sc = None if scores is None else scores[f0:f0 + T].contiguous()
+            outs.append(ops_f32.pool_tokens(proj.view(-1, 257, W)[f0:f0 + T].reshape(-1, W), 1, T, mode, sc).view(-1, W))
+            f0 += T
+        return (outs[0] if len(outs) == 1 else torch.cat(outs, 0)), Ts
+
     def temporal_transformer_delta(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
         """valley_model.py:123-133 on B clips of T frames (projected feats fp32 [B*T*257, H]) ->
         bf16 [B, 256+T, H].  Only the last time step of the encoder output is consumed (:130), so the
@@ -219,6 +259,8 @@ class ValleyLlamaModel:
 
     def project_pooled(self, pooled: torch.Tensor) -> torch.Tensor:
         """pooled bf16 [NV, 1024] -> visual tokens bf16 [NV, H] (mm_projector, valley_model.py:190)."""
+        if self.precision == "fp32":
+            return pooled                                    # _pool_precise projects before pooling, as the reference does
         if pooled.shape[-1] == self.config.hidden_size and self.patch_pooling_method != "mean":
             return pooled                                    # these variants project every token before pooling
         return ops.gemm(pooled, self.mm_projector.weight, self.mm_projector.bias)
@@ -245,7 +287,8 @@ class ValleyLlamaModel:
         # host enqueue time of a c2 step was 25.4 of 27.1 ms, 16 ms of it inside this one `.to()`; 5.8 ms now)
         stage = torch.empty(row_map.shape, dtype=torch.int32, pin_memory=True)
         stage.numpy()[...] = row_map
-        return ops.embed_splice(stage.to(self.device, non_blocking=True), self.llama.embed, visual)
+        splice = ops_f32.embed_splice if self.precision == "fp32" else ops.embed_splice
+        return splice(stage.to(self.device, non_blocking=True), self.llama.embed, visual)
 
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
@@ -261,7 +304,7 @@ class ValleyLlamaModel:
             B, S = input_ids.shape
             h = self.embed_inputs(input_ids, images, visual_tokens, frames_per_clip)
         cache = past_key_values
-        if cache is not None and not isinstance(cache, HipKVCache):
+        if cache is not None and not isinstance(cache, (HipKVCache, F32KVCache)):
             if len(cache) and (not hasattr(cache, "get_seq_length") or cache.get_seq_length()):
                 raise TypeError(f"past_key_values must be the HipKVCache a previous forward returned, got {type(cache).__name__}: "
                                 "a foreign (HF tuple / DynamicCache) cache cannot be continued on the HIP path")
@@ -338,7 +381,7 @@ class ValleyLlamaForCausalLM:
         model.vision_tower.* (valley/model/apply_delta.py:25,30)."""
         self.model.llama.load_state_dict(sd)
         if "model.mm_projector.weight" in sd:
-            self.model.mm_projector = HipLinear(_dev(sd["model.mm_projector.weight"], self.device, torch.bfloat16),
+            self.model.mm_projector = HipLinear(_dev(sd["model.mm_projector.weight"], self.device, self.model.wdtype),
                                                 _dev(sd["model.mm_projector.bias"], self.device, torch.float32))
             self.config.use_mm_proj = True
         if "model.pooling_layer.weight" in sd:               # v2 temporal importance (valley_model.py:42)
@@ -362,7 +405,7 @@ class ValleyLlamaForCausalLM:
         if vt:
             created = self.model.vision_tower is None
             if created:
-                self.model.vision_tower = build_vision_tower(None, device=self.device)
+                self.model.vision_tower = build_vision_tower(None, device=self.device, precision=self.model.precision)
             # a model checkpoint stores its whole tower (save_pretrained): when this model had to create the tower
             # object itself, from defaults, the stored depth is the tower's depth
             self.model.vision_tower.load_state_dict(vt, shallow_ok=created)
@@ -452,8 +495,8 @@ class ValleyLlamaForCausalLM:
         finished = torch.zeros((B,), dtype=torch.bool, device=self.device)     # HF: a finished row emits pad from then on
         token = pick(out.logits[:, -1, :].contiguous())
         seq = torch.cat([input_ids, token[:, None]], dim=1)
-        if B > 8:
-            use_graph = None                                 # GEMV decode path is for <= 8 sequences
+        if B > 8 or self.model.precision == "fp32":
+            use_graph = None                                 # the GEMV decode session is bf16, for <= 8 sequences
         sess = None
         if use_graph is not None:
             from .decode import DecodeSession
@@ -494,10 +537,10 @@ class ValleyLlamaForCausalLM:
         if n == ll.V:
             return
         H, d = ll.H, self.device
-        emb = torch.zeros((n, H), dtype=torch.bfloat16, device=d)
+        emb = torch.zeros((n, H), dtype=ll.embed.dtype, device=d)
         keep = min(n, ll.V)
         emb[:keep] = ll.embed[:keep]
-        head = torch.zeros(((n + 7) // 8 * 8, H), dtype=torch.bfloat16, device=d)
+        head = torch.zeros(((n + 7) // 8 * 8, H), dtype=ll.lm_head.dtype, device=d)
         head[:keep] = ll.lm_head[:keep]
         ll.embed, ll.lm_head, ll.V, ll.Vpad = emb, head, n, head.shape[0]
         self.config.vocab_size = n
@@ -516,8 +559,8 @@ class ValleyLlamaForCausalLM:
         vc.vi_frame_token = tokenizer.convert_tokens_to_ids(DEFAULT_VIDEO_FRAME_TOKEN)
         if num_new > 0:
             ll = self.model.llama
-            ll.embed[ll.V - num_new:ll.V] = ll.embed[:ll.V - num_new].float().mean(0, keepdim=True).to(torch.bfloat16)
-            ll.lm_head[ll.V - num_new:ll.V] = ll.lm_head[:ll.V - num_new].float().mean(0, keepdim=True).to(torch.bfloat16)
+            ll.embed[ll.V - num_new:ll.V] = ll.embed[:ll.V - num_new].float().mean(0, keepdim=True).to(ll.embed.dtype)
+            ll.lm_head[ll.V - num_new:ll.V] = ll.lm_head[:ll.V - num_new].float().mean(0, keepdim=True).to(ll.lm_head.dtype)
         vc.im_patch_token = tokenizer.convert_tokens_to_ids([DEFAULT_IMAGE_PATCH_TOKEN])[0]
 
     def build_inputs(self, tokenizer, messages):
