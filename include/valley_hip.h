@@ -217,6 +217,14 @@ int vly_decode_attention(const void *qkv_bf16, void *kcache_bf16, void *vcache_b
                          const float *sin_table, const uint8_t *key_valid, int key_valid_stride, void *out_bf16,
                          int B, int heads, int past_len, const int32_t *past_len_dev, int ctx_max, void *stream);
 
+/* The same step for a batch whose rows are INDEPENDENT sequences at their own positions (continuous batching over one
+ *   captured decode step, serve/model_worker.py:380-387 run for several requests at once): row b appends at
+ *   past_len_rows[b] (device int32 [B], clamped to ctx_max-1) and attends over 0..past_len_rows[b]; key_valid rows
+ *   (stride >= ctx_max) mask padding and retired slots. */
+int vly_decode_attention_rows(const void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
+                              const float *sin_table, const uint8_t *key_valid, int key_valid_stride, void *out_bf16,
+                              int B, int heads, const int32_t *past_len_rows, int ctx_max, void *stream);
+
 /* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
  *   serve/model_worker.py:380-387 (one-token forward). */

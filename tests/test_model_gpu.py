@@ -9,7 +9,8 @@ Tolerances (stated, measured on MI355X; bf16 GEMM operands with fp32 accumulatio
 stream, vs an fp32 reference):
     tower hidden state      rel-L2 < 6e-3, max-abs < 0.12 (|x| up to ~15)
     spliced visual tokens   rel-L2 < 8e-3
-    logits                  max-abs < 6e-2, rel-L2 < 2e-2   (tiny 2-layer golden model, |logit| < 4)
+    logits                  max-abs < 4.5e-2 (= 1.5 x the measured 0.030), rel-L2 < 1e-2 (measured 5.9e-3)   (2-layer golden model, |logit| < 4);
+                            the fp32 mode meets 1e-3 on the same fixtures (tests/test_precise_gpu.py: 4.5e-6)
 """
 import os
 
@@ -21,7 +22,7 @@ from tests import golden_cfg as G
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-LOGIT_TOL = 6e-2        # bf16 operands / fp32 accumulate vs the fp32 reference, |logit| < 4 (tightened once measured: see DESIGN §2)
+LOGIT_TOL = 4.5e-2      # bf16 operands / fp32 accumulate vs the fp32 reference, |logit| < 4: 1.5x the measured 0.030
 
 
 def rel(a, b):
@@ -84,7 +85,7 @@ def test_forward_vs_golden(method):
     got = logits if method == "mean" else logits[:, ::4]
     vv = v if method == "mean" else v[:, ::4]
     print(method, "logits max-abs", maxabs(got[vv], ref[vv]), "rel", rel(got[vv], ref[vv]))
-    assert maxabs(got[vv], ref[vv]) < 6e-2 and rel(got[vv], ref[vv]) < 2e-2
+    assert maxabs(got[vv], ref[vv]) < LOGIT_TOL and rel(got[vv], ref[vv]) < 1e-2
 
 
 @pytest.mark.parametrize("case", ["mixed", "two_images", "frame_mismatch"])
@@ -99,7 +100,7 @@ def test_splice_cases_vs_golden(case):
     out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1, attention_mask=torch.from_numpy(mask).cuda())
     v = mask.astype(bool)[:, ::4]
     got = out.logits.cpu().numpy()[:, ::4]
-    assert maxabs(got[v], g["logits"][v]) < 6e-2
+    assert maxabs(got[v], g["logits"][v]) < LOGIT_TOL
 
 
 def test_splice_errors_match_reference():
@@ -123,7 +124,7 @@ def test_list_of_clips_vs_golden():
     assert rel(emb, g["embeds"]) < 8e-3
     out = model(input_ids=torch.from_numpy(ids).cuda(), images=clips, attention_mask=torch.from_numpy(mask).cuda())
     v = mask.astype(bool)[:, ::4]
-    assert maxabs(out.logits.cpu().numpy()[:, ::4][v], g["logits"][v]) < 6e-2
+    assert maxabs(out.logits.cpu().numpy()[:, ::4][v], g["logits"][v]) < LOGIT_TOL
 
 
 def test_greedy_decode_vs_golden():
@@ -134,12 +135,12 @@ def test_greedy_decode_vs_golden():
     ids, _ = G.golden_ids("decode")
     img1 = torch.from_numpy(G.golden_pixels(T, "mixed")).view(1, T, 3, 224, 224).cuda()
     out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1, use_cache=True)
-    assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < 6e-2
+    assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < LOGIT_TOL
     past = out.past_key_values
     logits = out.logits
     for step in range(4):
         last = logits[:, -1, :].cpu().numpy()
-        assert maxabs(last, g["last_logits"][:, step]) < 6e-2
+        assert maxabs(last, g["last_logits"][:, step]) < LOGIT_TOL
         ctx = past[0][0].shape[-2]                      # legacy indexing used by the worker (:381)
         assert ctx == past.get_seq_length() == ids.shape[1] + step
         token = torch.from_numpy(g["tokens"][:, step]).cuda()      # teacher-force the reference's token
@@ -319,7 +320,7 @@ def test_from_pretrained_checkpoint_roundtrip(tmp_path):
     ids, _ = G.golden_ids("decode")
     img1 = torch.from_numpy(G.golden_pixels(c["T"], "mixed")).view(1, c["T"], 3, 224, 224).cuda()
     out = model(input_ids=torch.from_numpy(ids).cuda(), images=img1)
-    assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < 6e-2
+    assert maxabs(out.logits.cpu().numpy(), g["prefill_logits"]) < LOGIT_TOL
 
 
 def _stream_setup():
@@ -591,3 +592,55 @@ def test_generate_stopping_semantics_and_foreign_cache():
     from transformers import DynamicCache
     out = model(input_ids=ids_t, past_key_values=DynamicCache(), use_cache=True, **kw)    # empty foreign cache: fresh start
     assert out.past_key_values.get_seq_length() == n_in
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_continuous_batching_matches_solo_requests(use_graph):
+    """SURVEY §8f N3 "continuous batching over the hipGraph decode step": three requests with different prompts (one of
+    them left-padded) join a 4-slot ContinuousBatcher at different steps, share every captured decode step (per-slot
+    positions: vly_decode_attention_rows) and leave at different steps; each request's greedy tokens equal those of the
+    same request served alone by generate() (the loop of serve/model_worker.py:371-394) — the slots are independent
+    sequences, and a freed slot is reused by a later request."""
+    from valley_amd.serving import ContinuousBatcher
+    model = build_golden_model()
+    T = G.GCFG["T"]
+    img = torch.from_numpy(G.golden_pixels(T, "mixed")).view(1, T, 3, 224, 224).cuda()
+    reqs = []
+    for case in ("decode2", "decode"):
+        ids, _ = G.golden_ids(case)
+        reqs.append((torch.from_numpy(ids).cuda(), None))
+    ids, mask = G.golden_ids("main")                                        # row 1 of "main" is left-padded
+    reqs.append((torch.from_numpy(ids[1:2]).cuda(), torch.from_numpy(mask[1:2]).cuda()))
+    n_new = [9, 6, 7]
+    solo = []
+    for (ids_t, m), n in zip(reqs, n_new):
+        seq = model.generate(ids_t, images=img, attention_mask=m, max_new_tokens=n, use_graph=True)
+        solo.append(seq[0, ids_t.shape[1]:].tolist())
+    cb = ContinuousBatcher(model, slots=4, ctx_max=512, use_graph=use_graph)
+    got = {0: [], 1: [], 2: [], 3: []}
+    slot_of, done = {}, {}
+    join_at = {0: 0, 1: 2, 2: 3}                                           # request -> global step at which it joins
+    step = 0
+    while len(done) < 3 and step < 40:
+        for r, at in join_at.items():
+            if at == step:
+                ids_t, m = reqs[r]
+                slot_of[r] = cb.add(ids_t, images=img, attention_mask=m)
+                got[r].append(int(cb.sess.tok[slot_of[r]]))                 # first token = argmax of the prefill
+        live = {r: s for r, s in slot_of.items() if r not in done}
+        for r, s in list(live.items()):
+            if len(got[r]) >= n_new[r]:
+                cb.release(s)
+                done[r] = True
+        if len(done) == 3:
+            break
+        toks = cb.step()
+        for r, s in slot_of.items():
+            if r not in done and s in toks:
+                got[r].append(toks[s])
+        step += 1
+    for r in range(3):
+        assert got[r][:n_new[r]] == solo[r], (r, got[r], solo[r])
+    # a released slot is reused
+    s_new = cb.add(reqs[0][0], images=img)
+    assert s_new in (slot_of[0], slot_of[1], slot_of[2]) and int(cb.sess.tok[s_new]) == solo[0][0]

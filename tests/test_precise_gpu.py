@@ -3,7 +3,11 @@
 (i)   the bf16 production path against the fp32 reference fixtures: measured and asserted in tests/test_model_gpu.py
       (max-abs 0.030 on |logit| < 4 — the cost of bf16 storage, NOT of the implementation, see (ii));
 (ii)  the bf16 production path against the SAME-DTYPE oracle (oracle.rounding(): the fp32 restatement rounded to bf16 at
-      exactly the points where the HIP pipeline stores bf16): what is left is summation order — asserted below;
+      exactly the points where the HIP pipeline stores bf16).  Measured: that oracle is itself 3.1e-2 (max-abs) from the
+      fp32 reference, the HIP path 3.05e-2, and the two are 2.6e-2 from each other — two bf16-storage evaluations of a
+      2-layer model whose summation orders differ decorrelate (a 1-ulp flip of a bf16 rounding is a 4e-3 relative
+      perturbation that the next layers carry).  So the testable statement is: the HIP path's error against the fp32
+      reference does not exceed the error of the oracle's bf16-storage evaluation (x1.15) — asserted below;
 (iii) VALLEY_PRECISION=fp32 (valley_amd/precise.py: fp32 tensors end to end, exact f32 MFMA) against the fp32 reference
       fixtures and the fp32 oracle: **max-abs logit error < 1e-3** asserted on the golden model (all of its cases) and
       on 2 decoder layers at the Vicuna-13B layer shapes.
@@ -268,4 +272,7 @@ def test_bf16_path_vs_same_dtype_oracle(method):
     if ref is not None:
         msg += f"; vs fp32 reference {maxabs(got[v], ref[v]):.2e}; same-dtype oracle vs fp32 reference {maxabs(same[v], ref[v]):.2e}"
     print(msg)
-    assert e_same < 1.2e-2                     # tightened to ~1.5x the measurement in DESIGN §2 once measured
+    assert e_same < 4e-2                       # measured 2.57e-2 / 2.28e-2 (two decorrelated bf16 evaluations, see the module docstring)
+    if ref is not None:
+        assert maxabs(got[v], ref[v]) <= 1.15 * maxabs(same[v], ref[v]) + 2e-3      # measured 3.05e-2 vs 3.12e-2
+        assert rel(got[v], ref[v]) <= 1.15 * rel(same[v], ref[v])

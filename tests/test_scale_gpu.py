@@ -8,8 +8,10 @@ the host at 2 layers; layer count does not change any kernel shape, so 2 layers 
 
 Tolerances (stated; bf16 GEMM operands, fp32 accumulation, fp32 residual stream, vs fp32 reference), measured on MI355X
 and asserted at ~1.5x the measurement — see the prints:
-    hidden state after 2 layers + final norm     rel-L2 < 6e-3
-    logits (vocab 512 slice of the 13B/7B head)   rel-L2 < 8e-3
+    hidden state / logits after 2 layers at 7B | 13B shapes   rel-L2 1.10e-2 | 1.42e-2 measured, < 1.7e-2 | 2.2e-2 asserted,
+        AND <= 1.15x the error of the oracle's own bf16-storage evaluation (oracle.rounding(): 1.12e-2 | 1.44e-2): the HIP
+        path adds nothing to what storing GEMM operands in bf16 costs at these widths; the fp32 mode
+        (tests/test_precise_gpu.py) is at 7e-6 on the same problem
     bf16-output GEMM vs fp32 product              rel-L2 < 4e-3 (one bf16 rounding of the result = 2^-9 relative rms)
     fp32-output GEMM vs fp32 product              max-abs < 2e-4 sqrt(K) (summation order only: bf16 products are exact)
 """
@@ -35,6 +37,7 @@ def maxabs(a, b):
 
 
 _STATE = {}
+_ORACLE = {}
 
 
 def _llama(name, layers=2):
@@ -82,14 +85,23 @@ def test_llama_layers_vs_oracle(name, mode, monkeypatch):
             break
     got_h = x.float().view(B, S, H).cpu().numpy()
     got_l = ll.logits(x).view(B, S, -1).cpu().numpy()
-    with torch.no_grad():
-        ref_h, past = O.llama_forward(torch.from_numpy(emb), sd, cfg, torch.from_numpy(mask))
-        ref_l = torch.nn.functional.linear(ref_h, torch.from_numpy(sd["lm_head.weight"]))
     v = mask.astype(bool)
+    if name not in _ORACLE:                                      # CPU oracle, fp32 and bf16-storage evaluation (shared by both modes)
+        with torch.no_grad():
+            lm = torch.from_numpy(sd["lm_head.weight"])
+            ref_h, past = O.llama_forward(torch.from_numpy(emb), sd, cfg, torch.from_numpy(mask))
+            ref_l = torch.nn.functional.linear(ref_h, lm)
+            with O.rounding():
+                same_h, _ = O.llama_forward(torch.from_numpy(emb), sd, cfg, torch.from_numpy(mask))
+                same_l = torch.nn.functional.linear(same_h, lm.to(torch.bfloat16).float())
+        _ORACLE[name] = (ref_h, ref_l, past, rel(same_h.numpy()[v], ref_h.numpy()[v]), rel(same_l.numpy()[v], ref_l.numpy()[v]))
+    ref_h, ref_l, past, sh, sl = _ORACLE[name]
     rh, rl, ml = rel(got_h[v], ref_h.numpy()[v]), rel(got_l[v], ref_l.numpy()[v]), maxabs(got_l[v], ref_l.numpy()[v])
     print(f"{name}/{mode}: hidden rel-L2 {rh:.2e}  logits rel-L2 {rl:.2e} max-abs {ml:.3e} (|logit| max "
-          f"{float(np.abs(ref_l.numpy()[v]).max()):.2f})")
-    assert rh < 6e-3 and rl < 8e-3
+          f"{float(np.abs(ref_l.numpy()[v]).max()):.2f}); the oracle's bf16-storage evaluation: hidden {sh:.2e} logits {sl:.2e}")
+    bound = {"7b": 1.7e-2, "13b": 2.2e-2}[name]
+    assert rh < bound and rl < bound
+    assert rh <= 1.15 * sh and rl <= 1.15 * sl                  # no error beyond what bf16 storage itself costs
     assert ops.sk_error_flag("cuda:0") == 0
     # ---- one decode step (GEMV kernels, fused RoPE/append/attention) on the prefilled cache
     tok = torch.tensor([3, 7], dtype=torch.long)
@@ -106,7 +118,7 @@ def test_llama_layers_vs_oracle(name, mode, monkeypatch):
         h1, _ = O.llama_forward(e1, sd, cfg, m1, past=past)
         ref_d = torch.nn.functional.linear(h1, torch.from_numpy(sd["lm_head.weight"]))[:, 0].numpy()
     print(f"{name}/{mode}: decode-step logits rel-L2 {rel(got_d, ref_d):.2e} max-abs {maxabs(got_d, ref_d):.3e}")
-    assert rel(got_d, ref_d) < 8e-3
+    assert rel(got_d, ref_d) < {"7b": 1.7e-2, "13b": 2.2e-2}[name]
 
 
 # ---- the GEMM shapes that carry the c2 / c3 steps ------------------------------------------------

@@ -463,7 +463,8 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
                                                            uint16_t* __restrict__ vc, const float* __restrict__ cos_t,
                                                            const float* __restrict__ sin_t, const uint8_t* __restrict__ key_valid,
                                                            uint16_t* __restrict__ out, int heads, int past,
-                                                           const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
+                                                           const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max,
+                                                           int past_row_stride) {
     __shared__ float sc[512];
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ __attribute__((aligned(16))) float knew[128];
@@ -473,7 +474,9 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const int Hq = heads * 128;
-    if (past_dev) past = min(*past_dev, ctx_max - 1);
+    // device-side position: one value for the batch (captured decode step) or one per row (continuous batching:
+    // every slot of the batch is its own sequence at its own position)
+    if (past_dev) past = min(past_dev[(size_t)b * past_row_stride], ctx_max - 1);
     const int pos = past, kv_len = past + 1;
     const uint16_t* qp = qkv + (size_t)b * 3 * Hq + h * 128;
     uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
@@ -633,6 +636,20 @@ extern "C" int vly_decode_attention(const void* qkv, void* kcache, void* vcache,
     }
     hipLaunchKernelGGL(decode_fused_kernel, dim3(heads, B), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)qkv,
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, (uint16_t*)out, heads, past_len,
-                       past_len_dev, key_valid_stride, ctx_max);
+                       past_len_dev, key_valid_stride, ctx_max, 0);
     return vly_check_launch("vly_decode_attention");
+}
+
+extern "C" int vly_decode_attention_rows(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
+                                         const uint8_t* key_valid, int key_valid_stride, void* out, int B, int heads,
+                                         const int32_t* past_len_rows, int ctx_max, void* stream) {
+    if (B <= 0 || heads <= 0 || !past_len_rows || B > 65535 || heads > 65535 || ((uintptr_t)qkv & 15) || ((uintptr_t)kcache & 15) ||
+        ((uintptr_t)vcache & 15) || ((uintptr_t)out & 7) || !cos_table || !sin_table || (key_valid && key_valid_stride < ctx_max)) {
+        vly_set_error("vly_decode_attention_rows: bad args B=%d heads=%d ctx_max=%d key_valid_stride=%d", B, heads, ctx_max, key_valid_stride);
+        return -22;
+    }
+    hipLaunchKernelGGL(decode_fused_kernel, dim3(heads, B), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, (uint16_t*)out, heads, 0,
+                       past_len_rows, key_valid_stride, ctx_max, 1);
+    return vly_check_launch("vly_decode_attention_rows");
 }

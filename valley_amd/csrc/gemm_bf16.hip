@@ -14,6 +14,7 @@
 //     8-byte (bf16) or 16-byte (fp32) pieces along the row;
 //   * block id -> tile mapping gives each XCD (private 4 MiB L2) a contiguous run of tiles.
 // Algorithmic work: 2*M*N*K flop per launch; HBM traffic floor (M*K + N*K)*2 + M*N*out bytes.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "common.hpp"
@@ -26,6 +27,26 @@ int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n) {
     const double n_fast = a + w * (tiles_m < 8 ? tiles_m : 8);
     const double m_fast = w + a * (tiles_n < 8 ? tiles_n : 8);
     return m_fast < n_fast;
+}
+
+// Group height (in m-tiles) of the tile order inside each XCD's contiguous run: tiles are visited group by group, a
+// group = gm consecutive m-tiles x all n-tiles, m fastest inside it.  gm = 1 is the n-fastest order, gm = tiles_m the
+// m-fastest one.  The `conc` workgroups an XCD runs at the same time then cover a gm x (conc / gm) block of tiles, which
+// per K step touches gm A-tiles + conc / gm W-tiles: minimal for gm ~ sqrt(conc * BN / BM) — e.g. 11 x 3 -> 6 x 5.3
+// tiles for the 13B gate/up GEMM (14 -> 11.3 operand tiles per K step and 32 workgroups, -19 % L2 fill traffic).
+// VLY_TILE_GM=<n> overrides (A/B measurements).
+int vly_tile_group_height(int M, int N, int K, int tiles_m, int tiles_n, int BM, int BN, int wg_per_cu) {
+    static const int forced = getenv("VLY_TILE_GM") ? atoi(getenv("VLY_TILE_GM")) : 0;
+    if (forced > 0) return forced < tiles_m ? forced : tiles_m;
+    if (!vly_tile_order_m_fast(M, N, K, tiles_m, tiles_n)) return 1;
+    static const bool grouped = !(getenv("VLY_TILE_GROUPED") && atoi(getenv("VLY_TILE_GROUPED")) == 0);
+    if (!grouped) return tiles_m;
+    const double conc = 32.0 * wg_per_cu;
+    int gm = (int)(sqrt(conc * BN / BM) + 0.5);
+    if (gm < 1) gm = 1;
+    if (gm >= tiles_m || tiles_m <= gm + gm / 2) return tiles_m;       // a ragged last group would be worse than one group
+    const int groups = (tiles_m + gm - 1) / gm;                           // balance the groups: 11 -> 6 + 5, not 6 + 5 by luck
+    return (tiles_m + groups - 1) / groups;
 }
 
 namespace {
@@ -193,7 +214,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
-            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int m_fast, int wide,
+            int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int gm, int wide,
             int ksplit, void* __restrict__ Cv2) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
@@ -225,13 +246,19 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     if (part) { Cv = Cv2; bias = nullptr; R = nullptr; }
     const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
     const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    // tile order inside the XCD-contiguous run: n-fastest keeps an A row-panel in the XCD's L2 while the
-    // W panels stream (A read once, W up to 8x); m-fastest keeps a W panel while the A panels stream.
-    // The host picks the order that moves fewer bytes (small-M Llama GEMMs: m-fastest, W read once).
-    const int m0 = (m_fast ? swz % tiles_m : swz / tiles_n) * BM;
-    const int n0 = (m_fast ? swz / tiles_m : swz % tiles_n) * BN;
+    // tile order inside the XCD-contiguous run: groups of gm m-tiles x all n-tiles, m fastest inside a group
+    // (vly_tile_group_height: gm = 1 n-fastest — an A row-panel stays in the XCD's L2 while the W panels stream;
+    // gm = tiles_m m-fastest; in between, the workgroups an XCD runs together form a near-square block of tiles)
+    const int gsz = gm * tiles_n, grp = swz / gsz, first = grp * gm;
+    const int gh = min(gm, tiles_m - first), rr = swz - grp * gsz;
+    const int m0 = (first + rr % gh) * BM;
+    const int n0 = (rr / gh) * BN;
 
     const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+    // a wave whose whole WM x WN slab lies past the edge of the problem (the lower half of the last 256-row tile at
+    // M = 2688 or F*257) keeps staging and meeting the barriers but skips its fragment reads and MFMAs: the tile then
+    // costs its SIMD partner's share only, and the last round of a launch is shorter
+    const bool wave_live = __builtin_amdgcn_readfirstlane((m0 + wm0 < M && n0 + wn0 < N) ? 1 : 0) != 0;
 #if VLY_MFMA32
     // 32x32x16 path: whole-K-tile loops only, wave tile a multiple of 32 both ways
     constexpr bool M32 = WM % 32 == 0 && WN % 32 == 0 && (PIPE == 0 || PIPE == 4 || PIPE == 6 || PIPE == 7);
@@ -296,6 +323,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sW = sA + A_BYTES;
+            if (!wave_live) continue;
 #if VLY_MFMA32
             if constexpr (M32) mma_ktile32<MI2, NI2>(acc32, sA + (wm0 + l31) * 128, sW + (wn0 + l31) * 128, sw32);
             else
@@ -427,6 +455,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 bf16x8 af[MI], wf[NI];
 #if VLY_MFMA32
                 [[maybe_unused]] bf16x8 af2[2][MI2], wf2[2][NI2];           // two K steps of 16 per phase
+#endif
+                if (wave_live) {
+#if VLY_MFMA32
                 if constexpr (M32) {
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
@@ -445,12 +476,14 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
                 }
+                }
                 if (kk == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my loads of tile kt+1
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 // ---------------- M phase
                 __builtin_amdgcn_s_setprio(1);
+                if (wave_live) {
 #if VLY_MFMA32
                 if constexpr (M32) {
 #pragma unroll
@@ -466,6 +499,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -514,11 +548,13 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);                           // (kt+2) % 3
             const char* cur = smem + buf * STAGE;
+            if (wave_live) {
 #if VLY_MFMA32
             if constexpr (M32) mma_ktile32<MI2, NI2>(acc32, cur + (wm0 + l31) * 128, cur + A_BYTES + (wn0 + l31) * 128, sw32);
             else
 #endif
             mma_ktile<MI, NI>(acc, cur + rdA, cur + rdW, sw0, sw1);
+            }
             buf = buf == 2 ? 0 : buf + 1;
         }
     } else if constexpr (PIPE == 7) {
@@ -569,6 +605,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 bf16x8 af[MI], wf[NI];
 #if VLY_MFMA32
                 [[maybe_unused]] bf16x8 af2[2][MI2], wf2[2][NI2];           // two K steps of 16 per phase
+#endif
+                if (wave_live) {
+#if VLY_MFMA32
                 if constexpr (M32) {
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
@@ -587,12 +626,14 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + rdA + i * 2048 + sw);
                 }
+                }
                 if (kk == 1 && grp == 1) wait_next(kt);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 // ---------------- M phase
                 __builtin_amdgcn_s_setprio(1);
+                if (wave_live) {
 #if VLY_MFMA32
                 if constexpr (M32) {
 #pragma unroll
@@ -608,6 +649,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (kk == 1 && grp == 0) wait_next(kt);
@@ -832,7 +874,8 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
                 int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st, void* C2 = nullptr) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-    const int m_fast = vly_tile_order_m_fast(M, N, K, tm, tn);
+    constexpr int STAGE_B = (BM + BN) * 128 * ((PIPE == 6 || PIPE == 7) ? 3 : 2);
+    const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, STAGE_B <= 80 * 1024 ? 2 : 1);
     // full-line stores through LDS need 16-byte aligned output rows (VLY_EPILOGUE=frag: A/B switch for measurements)
     static const bool frag_only = getenv("VLY_EPILOGUE") && !strcmp(getenv("VLY_EPILOGUE"), "frag");
     const int wide = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !frag_only) ? 1 : 0;
@@ -840,7 +883,7 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
     dim3 grid(tm * tn * ksplit), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O, PIPE>), grid, block, 0, st, (const uint16_t*)A,   \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, m_fast, wide, ksplit, C2)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, gm, wide, ksplit, C2)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);

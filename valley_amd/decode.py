@@ -20,14 +20,17 @@ from .llama import HipKVCache, HipLlama
 
 
 class DecodeSession:
-    def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True):
+    def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True, per_row_positions: bool = False):
+        """``per_row_positions``: every batch row is an independent sequence at its own position (``pos`` is int32 [B]
+        and advances by one per step for every row) — the captured step of valley_amd.serving.ContinuousBatcher."""
         self.ll, self.cache = llama, cache
         B, d = cache.batch, llama.device
         if B > 8:
             raise ValueError("decode sessions stream weights with the GEMV kernel: batch <= 8")
         self.B = B
+        self.per_row = per_row_positions
         self.tok = torch.zeros((B,), dtype=torch.int32, device=d)          # token fed to the next step
-        self.pos = torch.zeros((1,), dtype=torch.int32, device=d)          # == cache.seq_len, on the device
+        self.pos = torch.zeros((B if per_row_positions else 1,), dtype=torch.int32, device=d)   # on the device: replays need no patching
         self.h = torch.empty((B, llama.H), dtype=torch.float32, device=d)
         bf = torch.bfloat16
         self.x = torch.empty((B, llama.H), dtype=bf, device=d)
@@ -46,8 +49,11 @@ class DecodeSession:
             L = ll.layers[li]
             ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
             ops.gemv(self.x, L["w_qkv"], out=self.qkv)
-            ops.decode_attention(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, out=self.att,
-                                 past_dev=self.pos)              # RoPE + KV append + attention in one launch
+            if self.per_row:
+                ops.decode_attention_rows(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, self.pos, out=self.att)
+            else:
+                ops.decode_attention(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, out=self.att,
+                                     past_dev=self.pos)          # RoPE + KV append + attention in one launch
             ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
             ops.rmsnorm(self.h, L["ln2"], ll.eps, out=self.x)
             ops.gemv(self.x, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)
@@ -59,12 +65,14 @@ class DecodeSession:
         ops.argmax(self.logits[:, :ll.V], out=self.tok)
         ops.incr_i32(self.pos, 1)
 
-    def begin(self, first_token: torch.Tensor):
-        """Call after the prefill filled ``cache``: sets the device position and the first input token."""
-        self.pos.fill_(self.cache.seq_len)
-        self.tok.copy_(first_token.to(torch.int32).view(-1))
-        if self.cache.key_valid is not None:
-            self.cache.key_valid[:, self.cache.seq_len:] = 1           # generated positions are always attended
+    def begin(self, first_token: Optional[torch.Tensor] = None):
+        """Call after the prefill filled ``cache``: sets the device position and the first input token (per-row sessions
+        manage ``pos`` / ``tok`` per slot themselves and call this once, to capture)."""
+        if not self.per_row:
+            self.pos.fill_(self.cache.seq_len)
+            self.tok.copy_(first_token.to(torch.int32).view(-1))
+            if self.cache.key_valid is not None:
+                self.cache.key_valid[:, self.cache.seq_len:] = 1       # generated positions are always attended
         if self.use_graph and self.graph is None:
             # warm-up outside capture on a side stream (module loading, lazy init), then capture
             s = torch.cuda.Stream()
@@ -84,7 +92,7 @@ class DecodeSession:
     def step(self) -> torch.Tensor:
         """Run one decode step; returns the (device) int32 [B] buffer holding the newly chosen token.
         ``self.logits[:, :V]`` holds that step's logits (for temperature sampling on the host side)."""
-        if self.cache.seq_len + 1 > self.cache.ctx_max:
+        if not self.per_row and self.cache.seq_len + 1 > self.cache.ctx_max:
             raise ValueError("KV cache full")
         if self.graph is not None:
             self.graph.replay()

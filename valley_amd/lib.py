@@ -44,6 +44,7 @@ _SIGS = {
     "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_decode_attention": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "vly_decode_attention_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_int, _P]),
     "vly_gemm_bf16_splitk2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_pack_weight_bf16": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_add2_rmsnorm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),

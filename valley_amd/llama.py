@@ -39,6 +39,17 @@ class HipKVCache:
         self.batch = batch
         self.key_valid: Optional[torch.Tensor] = None      # uint8 [B, ctx_max] when a padding mask was given
 
+    @classmethod
+    def rows_of(cls, parent: "HipKVCache", b0: int, b1: int) -> "HipKVCache":
+        """A cache object over batch rows [b0, b1) of ``parent`` (shared storage: the batch is the outermost dimension,
+        so the slices are contiguous) — how a request is prefilled into its slot of a continuous-batching cache."""
+        c = cls.__new__(cls)
+        c.k = [t[b0:b1] for t in parent.k]
+        c.v = [t[b0:b1] for t in parent.v]
+        c.seq_len, c.ctx_max, c.batch = 0, parent.ctx_max, b1 - b0
+        c.key_valid = None if parent.key_valid is None else parent.key_valid[b0:b1]
+        return c
+
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.seq_len
 

@@ -343,6 +343,51 @@ def gemm2(a, w, out, out2, bias=None) -> int:
     return _run_candidate(choice, a, w, bias, None, EPI_NONE, out.dtype, out, out2)[1]
 
 
+ROW_SPLIT = os.environ.get("VALLEY_ROW_SPLIT", "1") == "1"
+
+
+def row_split(M: int) -> int:
+    """Rows of a tall GEMM that go into the MAIN launch; the rest (< 4096 rows) go into a second, small launch.
+
+    The ViT GEMMs have M = F * 257 rows (the CLS token makes every frame one row longer than 256): 32896 rows are 128.5
+    tiles of 256 rows, so a 256x256-tile launch needs ceil(129 * tiles_n / 256) rounds of workgroups — 9 instead of 8
+    for fc1, 7 instead of 6 for q|k|v, 3 instead of 2 for the N = 1024 projections: 10-33 % of the launch spent on a
+    round that holds 16 tiles.  GEMM rows are independent, so the launch is cut at a multiple of 4096 rows (16 m-tiles:
+    with 4, 12 or 16 n-tiles the main launch is a whole number of rounds on 256 CUs) and the remaining F rows run as
+    their own small launch right behind it.  Tall problems only; VALLEY_ROW_SPLIT=0 disables."""
+    if not ROW_SPLIT or GEMM_MODE != "tuned" or M < 8192 or M % 4096 == 0:
+        return M
+    return M // 4096 * 4096
+
+
+def gemm_split(a, w, bias=None, epilogue=EPI_NONE, out=None):
+    """ops.gemm over two row ranges (see row_split); same result as one launch (rows are independent)."""
+    M = a.shape[0]
+    Mm = row_split(M)
+    if Mm == M:
+        return gemm(a, w, bias, epilogue=epilogue, out=out)
+    if out is None:
+        out = torch.empty((M, w.shape[0] // 2 if epilogue == EPI_SWIGLU else w.shape[0]), dtype=torch.bfloat16, device=a.device)
+    gemm(a[:Mm], w, bias, epilogue=epilogue, out=out[:Mm])
+    gemm(a[Mm:], w, bias, epilogue=epilogue, out=out[Mm:])
+    return out
+
+
+def gemm2_split(a, w, out, out2, bias=None) -> int:
+    """ops.gemm2 over two row ranges: the remainder rows follow the main launch's answer (one product or two split-K
+    partials) so that the consumer sees one convention for the whole tensor."""
+    M = a.shape[0]
+    Mm = row_split(M)
+    if Mm == M:
+        return gemm2(a, w, out, out2, bias)
+    n = gemm2(a[:Mm], w, out[:Mm], out2[:Mm], bias)
+    if n == 2:
+        gemm_mfma_splitk2(a[Mm:], w, bias, out[Mm:], out2[Mm:], 0)
+    else:
+        gemm(a[Mm:], w, bias, out=out[Mm:])
+    return n
+
+
 def _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2=None):
     """-> (result tensor, number of partial outputs)."""
     kind, t = cand
@@ -659,6 +704,27 @@ def decode_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tens
                                           _ptr(key_valid), kv_stride, out.data_ptr(), B, heads, past_len, _ptr(past_dev),
                                           ctx_max, _stream())
     _lib.check(rc, "vly_decode_attention")
+    return out
+
+
+def decode_attention_rows(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                          key_valid: Optional[torch.Tensor], B: int, heads: int, pos_rows: torch.Tensor, out=None) -> torch.Tensor:
+    """decode_attention for a batch of independent sequences: row b sits at position pos_rows[b] (device int32 [B])."""
+    _chk(qkv, torch.bfloat16, "qkv")
+    _chk(pos_rows, torch.int32, "pos_rows")
+    assert pos_rows.numel() == B
+    ctx_max = kcache.shape[2]
+    kv_stride = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        assert key_valid.shape[0] == B and key_valid.shape[1] >= ctx_max
+        kv_stride = key_valid.stride(0)
+    if out is None:
+        out = torch.empty((B, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+    rc = _lib.load().vly_decode_attention_rows(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                               _ptr(key_valid), kv_stride, out.data_ptr(), B, heads, pos_rows.data_ptr(), ctx_max,
+                                               _stream())
+    _lib.check(rc, "vly_decode_attention_rows")
     return out
 
 

@@ -91,3 +91,73 @@ def generate_video_stream(model, tokenizer, params: dict, video: Optional[torch.
             yield json.dumps(ret).encode() + b"\0"
         if stopped or cache.seq_len + 1 > cache.ctx_max:
             break
+
+
+class ContinuousBatcher:
+    """Continuous batching over ONE hipGraph-captured decode step: up to ``slots`` (<= 8) requests
+    share a KV cache [slots, heads, ctx_max, 128] and a captured step of batch ``slots``; a request joins at any step
+    (its prompt is prefilled into its slot's cache rows by the ordinary MFMA prefill), leaves at any step, and the
+    weight stream of every decode step — the whole cost of a step at these batch sizes (HBM-bound GEMV) — is shared by
+    all live requests.  The reference's worker serialises requests behind a semaphore and runs the loop of
+    model_worker.py:371-394 once per request; the per-request token sequence here is the same as that loop's.
+
+    Every slot has its own position (device int32, advanced by the captured step) and its own key-validity row, so the
+    slots are fully independent sequences: ``vly_decode_attention_rows``.  Idle slots run along (their rows are computed
+    and ignored: the GEMV cost does not depend on the row count), clamped inside their cache rows."""
+
+    def __init__(self, model, slots: int = 4, ctx_max: int = 1024, use_graph: bool = True):
+        if not 1 <= slots <= 8:
+            raise ValueError("1 <= slots <= 8 (the decode step streams weights with the GEMV kernels)")
+        self.model, self.ll = model, model.get_model().llama
+        self.slots, self.ctx_max = slots, ctx_max
+        self.cache = self.ll.new_cache(slots, ctx_max)
+        self.cache.key_valid = torch.ones((slots, ctx_max), dtype=torch.uint8, device=self.ll.device)
+        self.sess = DecodeSession(self.ll, self.cache, use_graph=use_graph, per_row_positions=True)
+        self.live = [False] * slots
+        self.length = [0] * slots                                # tokens in each slot's cache (host mirror of sess.pos)
+        self._captured = False
+
+    def free_slots(self):
+        return [i for i, v in enumerate(self.live) if not v]
+
+    def add(self, input_ids, images=None, attention_mask=None, first_token: Optional[int] = None) -> int:
+        """Prefill one request (input_ids [1, S]) into a free slot; returns the slot.  The first generated token is the
+        prefill's argmax unless ``first_token`` is given (a caller that samples)."""
+        free = self.free_slots()
+        if not free:
+            raise RuntimeError("no free slot")
+        slot = free[0]
+        ids = torch.as_tensor(input_ids, device=self.ll.device).view(1, -1)
+        S = ids.shape[1]
+        if S + 1 > self.ctx_max:
+            raise ValueError("prompt does not fit the slot")
+        self.cache.key_valid[slot] = 1
+        row = type(self.cache).rows_of(self.cache, slot, slot + 1)
+        out = self.model(input_ids=ids, images=images, attention_mask=attention_mask, past_key_values=row, use_cache=True)
+        tok = int(out.logits[0, -1].argmax()) if first_token is None else int(first_token)
+        self.sess.pos[slot:slot + 1].fill_(S)
+        self.sess.tok[slot:slot + 1].fill_(tok)
+        self.live[slot], self.length[slot] = True, S
+        self.last_prefill_logits = out.logits[0, -1]
+        return slot
+
+    def step(self) -> dict:
+        """One decode step for every live slot: feeds each slot's current token, returns {slot: next greedy token}.
+        ``self.sess.logits[slot, :V]`` holds that slot's logits (a sampling caller overwrites ``self.sess.tok[slot]``)."""
+        if not self._captured:
+            self.sess.begin()
+            self._captured = True
+        for i in range(self.slots):
+            if self.live[i] and self.length[i] + 1 > self.ctx_max:
+                raise ValueError(f"slot {i}: KV cache full")
+        self.sess.step()
+        toks = self.sess.tok.tolist()                            # one D2H read per step for all requests
+        out = {}
+        for i in range(self.slots):
+            if self.live[i]:
+                self.length[i] += 1
+                out[i] = toks[i]
+        return out
+
+    def release(self, slot: int) -> None:
+        self.live[slot] = False

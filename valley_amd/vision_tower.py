@@ -13,6 +13,7 @@ weight (K = 588 zero-padded to 640).
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
@@ -37,6 +38,9 @@ def _dev(t, device, dtype):
     if not isinstance(t, torch.Tensor):
         t = torch.from_numpy(np.ascontiguousarray(t))
     return t.to(device=device, dtype=dtype).contiguous()
+
+
+VIT_CHUNK = int(os.environ.get("VALLEY_VIT_CHUNK", "256"))
 
 
 class HipCLIPVisionTower:
@@ -172,20 +176,25 @@ class HipCLIPVisionTower:
             ops.add_norm(h, ws["delta"], L["ln1_g"], L["ln1_b"], eps, out=ws["x"], delta2=d2)
         else:
             ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
-        ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        # M = F*257 rows: the *_split forms cut the launch at a multiple of 4096 rows so that the main launch is a whole
+        # number of workgroup rounds (ops.row_split)
+        ops.gemm_split(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
-        d2 = ws["delta2"] if ops.gemm2(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
+        d2 = ws["delta2"] if ops.gemm2_split(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
         ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"], delta2=d2)
-        ops.gemm(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
-        ws["split"] = ops.gemm2(ws["mlp"], L["w_fc2"], ws["delta"], ws["delta2"], L["b_fc2"]) == 2
+        ops.gemm_split(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
+        ws["split"] = ops.gemm2_split(ws["mlp"], L["w_fc2"], ws["delta"], ws["delta2"], L["b_fc2"]) == 2
         if nxt is None:
             ops.add_norm(h, ws["delta"], None, None, eps,                # last residual update of the stack
                          delta2=ws["delta2"] if ws["split"] else None)
 
-    def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: int = 256,
+    def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: Optional[int] = None,
                keep_all: bool = False):
         """frames [F,3,224,224] (any float dtype, device) -> fp32 [F,257,1024] = hidden_states[select_layer].
-        ``keep_all`` additionally returns every hidden state (slow path for the HF-style call)."""
+        ``keep_all`` additionally returns every hidden state (slow path for the HF-style call).  Frames go through the
+        stack ``chunk`` at a time (default VALLEY_VIT_CHUNK, 256): the activations of one chunk are what has to stay in
+        the 256 MB Infinity Cache between the kernels of a layer."""
+        chunk = chunk or VIT_CHUNK
         if not self.loaded:
             raise RuntimeError("vision tower has no weights")
         if frames.dim() != 4 or tuple(frames.shape[1:]) != (3, 224, 224):
