@@ -354,7 +354,12 @@ def row_split(M: int) -> int:
     for fc1, 7 instead of 6 for q|k|v, 3 instead of 2 for the N = 1024 projections: 10-33 % of the launch spent on a
     round that holds 16 tiles.  GEMM rows are independent, so the launch is cut at a multiple of 4096 rows (16 m-tiles:
     with 4, 12 or 16 n-tiles the main launch is a whole number of rounds on 256 CUs) and the remaining F rows run as
-    their own small launch right behind it.  Tall problems only; VALLEY_ROW_SPLIT=0 disables."""
+    their own small launch right behind it.  Tall problems only; VALLEY_ROW_SPLIT=0 disables.
+
+    Measured at F = 128 (c3, profiles/r02_rowsplit_ab.txt): the main launches speed up — fc1 793 -> 899, fc2 990 -> 1158,
+    out-proj 778 -> 897 TFLOP/s, q|k|v unchanged — but the F-row remainder is a latency-bound launch (one tile's K loop:
+    14-17 us at K = 1024, 33 us at K = 4096), so only the MLP pair nets a gain (fc1 347 -> 322 us, fc2 276 -> 270 us per
+    layer); q|k|v and out-proj lose 2-13 us and are therefore not split (the callers decide: vision_tower.layer_forward)."""
     if not ROW_SPLIT or GEMM_MODE != "tuned" or M < 8192 or M % 4096 == 0:
         return M
     return M // 4096 * 4096
