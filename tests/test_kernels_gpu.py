@@ -637,3 +637,31 @@ def test_g6_clip_mlp_and_attention_vs_hf():
     e = relerr(y.view(2, 257, 1024)[:, ::4], torch.from_numpy(g["clip_attention"]))
     print("G6 CLIP attention rel-L2", e)
     assert e < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(128, 4096, 1024, 1), (128, 1024, 4096, 0), (32, 3072, 1024, 0), (200, 64, 128, 3), (9, 32, 640, 0),
+                                         (256, 1024, 1024, 0)])
+def test_gemm_skinny(M, N, K, epi):
+    """vly_gemm_skinny_bf16 (the latency-optimised kernel for the F-row remainders of the tall ViT GEMMs) vs an fp32
+    product: one bf16 rounding of the result; ragged M (rows past the edge never stored); a strided A (a row slice of a
+    wider buffer, as the remainder rows are); the transpose detector."""
+    from valley_amd import ops
+    d = dev()
+    big = rnd((M + 3, K + 64), 91, dtype=torch.bfloat16).to(d)
+    a = big[3:, 64:]                                                     # row stride K + 64, 16-byte aligned start
+    w = rnd((N, K), 92, 0.05, dtype=torch.bfloat16).to(d)
+    bias = rnd((N,), 93, 0.5).to(d)
+    base = a.float() @ w.float().t() + bias
+    ref = base * torch.sigmoid(1.702 * base) if epi == 1 else base.clamp_min(0) if epi == 3 else base
+    out = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device=d)
+    ops.gemm_skinny(a, w, bias, epilogue=epi, out=out[:M])
+    assert relerr(out[:M], ref) < 4e-3
+    assert float((out[M:].float() - 7.0).abs().max()) == 0.0              # nothing written past M
+    assert relerr(out[:M], ops.gemm_mfma(a, w, bias, epilogue=epi)) < 3e-3   # same math as the tile kernel (summation order only)
+    w1 = torch.zeros((N, K), dtype=torch.bfloat16, device=d)
+    w1[5, K - 3] = 1.0
+    o1 = ops.gemm_skinny(a, w1)
+    assert maxabs(o1[:, 5], a[:, K - 3]) == 0.0 and float(o1[:, :5].float().abs().max()) == 0.0
+    from valley_amd.lib import ValleyHipError
+    with pytest.raises(ValleyHipError):
+        ops.gemm_skinny(rnd((300, K), 1, dtype=torch.bfloat16).to(d), w)     # M > 256 is not this kernel's job

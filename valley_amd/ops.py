@@ -196,6 +196,38 @@ def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=to
                         (tile_hint, ws.data_ptr(), ws.numel() * 4, epoch))
 
 
+def skinny_ok(M: int, N: int, K: int, epilogue: int, out_dtype, residual) -> bool:
+    return 8 < M <= 256 and N % 32 == 0 and K % 128 == 0 and epilogue in (EPI_NONE, EPI_QUICK_GELU, EPI_RELU) and \
+        out_dtype == torch.bfloat16 and residual is None
+
+
+def gemm_skinny(a, w, bias=None, epilogue=EPI_NONE, out=None):
+    """Latency-optimised kernel for 8 < M <= 256 rows (vly_gemm_skinny_bf16): the F-row remainders of ops.row_split."""
+    _chk(a, torch.bfloat16, "a", contiguous=False)
+    wt, ldw = _w_args(w, False)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    else:
+        _chk(out, torch.bfloat16, "out", contiguous=False)
+        assert tuple(out.shape) == (M, N) and out.stride(1) == 1
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    rec = _RECORDER
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.load().vly_gemm_skinny_bf16(a.data_ptr(), wt.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, a.stride(0), ldw,
+                                          out.stride(0), epilogue, _stream())
+    if rec is not None:
+        e1.record()
+        rec.append((f"gemm_skinny_kernel<{epilogue}>", 2.0 * M * N * K, e0, e1, (M, N, K, epilogue)))
+    _lib.check(rc, "vly_gemm_skinny_bf16")
+    return out
+
+
 def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None):
     """Weight-streaming kernel for M <= 8 rows (decode)."""
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
@@ -360,8 +392,8 @@ def row_split(M: int) -> int:
     out-proj 778 -> 897 TFLOP/s, q|k|v unchanged — but the F-row remainder is a latency-bound launch (one tile's K loop:
     14-17 us at K = 1024, 33 us at K = 4096), so only the MLP pair nets a gain (fc1 347 -> 322 us, fc2 276 -> 270 us per
     layer); q|k|v and out-proj lose 2-13 us and are therefore not split (the callers decide: vision_tower.layer_forward)."""
-    if not ROW_SPLIT or GEMM_MODE != "tuned" or M < 8192 or M % 4096 == 0:
-        return M
+    if not ROW_SPLIT or GEMM_MODE != "tuned" or M < 32768 or M % 4096 == 0:
+        return M                 # F = 32 / 64 frames (M = 8224 / 16448): the latency-bound remainder costs more than the round saved
     return M // 4096 * 4096
 
 
@@ -374,7 +406,7 @@ def gemm_split(a, w, bias=None, epilogue=EPI_NONE, out=None):
     if out is None:
         out = torch.empty((M, w.shape[0] // 2 if epilogue == EPI_SWIGLU else w.shape[0]), dtype=torch.bfloat16, device=a.device)
     gemm(a[:Mm], w, bias, epilogue=epilogue, out=out[:Mm])
-    gemm(a[Mm:], w, bias, epilogue=epilogue, out=out[Mm:])
+    _gemm_rem(a[Mm:], w, bias, epilogue, out[Mm:])
     return out
 
 
@@ -389,8 +421,16 @@ def gemm2_split(a, w, out, out2, bias=None) -> int:
     if n == 2:
         gemm_mfma_splitk2(a[Mm:], w, bias, out[Mm:], out2[Mm:], 0)
     else:
-        gemm(a[Mm:], w, bias, out=out[Mm:])
+        _gemm_rem(a[Mm:], w, bias, EPI_NONE, out[Mm:])
     return n
+
+
+def _gemm_rem(a, w, bias, epilogue, out):
+    """The few remainder rows of a split launch: the skinny kernel where it applies (a few us instead of one tile row's
+    latency-bound K loop), else the ordinary dispatch."""
+    if skinny_ok(a.shape[0], w.shape[0], w.shape[1], epilogue, out.dtype, None):
+        return gemm_skinny(a, w, bias, epilogue, out)
+    return gemm(a, w, bias, epilogue=epilogue, out=out)
 
 
 def _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2=None):
@@ -400,6 +440,8 @@ def _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2=No
         return gemm_mfma_splitk2(a, w, bias, out, out2, t), 2
     if kind == "tile":
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t), 1
+    if kind == "skinny":
+        return gemm_skinny(a, w, bias, epilogue, out), 1
     return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, t), 1
 
 
@@ -530,10 +572,13 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bflo
         elif _multi_stream():
             choice = ("tile", 0)
         else:
-            return _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out)[0]
+            cands = CANDIDATES + [("skinny", 0)] if skinny_ok(M, N, K, epilogue, out.dtype, residual) else None
+            return _online_trial(key, a, w, bias, residual, epilogue, out_dtype, out, candidates=cands)[0]
     kind, t = choice
     if kind == "tile":
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, t)
+    if kind == "skinny":
+        return gemm_skinny(a, w, bias, epilogue, out)
     # the stream-K workspace is per stream (none inside a capture) and the kernel itself belongs to one stream
     if torch.cuda.is_current_stream_capturing() or not sk_stream_allowed(a.device):
         return gemm_mfma(a, w, bias, residual, epilogue, out_dtype, out, 0)

@@ -178,10 +178,11 @@ class HipCLIPVisionTower:
             ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
         ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
-        d2 = ws["delta2"] if ops.gemm2(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
+        # M = F*257 rows: the *_split forms cut a launch at a multiple of 4096 rows so that the main launch is a whole
+        # number of workgroup rounds and hand the F-row remainder to the latency-optimised skinny kernel (ops.row_split;
+        # q|k|v gains nothing from it: measured)
+        d2 = ws["delta2"] if ops.gemm2_split(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
         ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"], delta2=d2)
-        # M = F*257 rows: the *_split forms cut the MLP launches at a multiple of 4096 rows so that the main launch is a
-        # whole number of workgroup rounds (ops.row_split: measured gain on fc1 / fc2 only)
         ops.gemm_split(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
         ws["split"] = ops.gemm2_split(ws["mlp"], L["w_fc2"], ws["delta"], ws["delta2"], L["b_fc2"]) == 2
         if nxt is None:
