@@ -37,6 +37,8 @@ extern "C" {
                                    C is N/2 wide                     hf:llama/modeling_llama.py:171 */
 #define VLY_EPI_RELU        3   /* C = max(A W^T + bias, 0): the FFN of the v3 temporal transformer layer
                                    (torch.nn.TransformerEncoderLayer default activation)            */
+#define VLY_EPI_QKV_ROPE    4   /* vly_gemm_bf16_qkv_rope only: the fused q|k|v projection whose epilogue applies
+                                   rotate-half RoPE to q and k and appends k, v to the KV cache            */
 /* output dtypes */
 #define VLY_OUT_BF16 0
 #define VLY_OUT_F32  1
@@ -73,6 +75,19 @@ const char *vly_last_error(void);
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);
+
+/* The fused q|k|v projection of a Llama layer with RoPE and the KV-cache append in its epilogue
+ *   (hf:llama/modeling_llama.py:230-238 projections, :127-157 rotate-half RoPE, :261-262 cache update): A [M = B*S, K = H]
+ *   bf16, W = [q; k; v] rows [3H, H]; row m is token s = m % S of sequence b = m / S at position past_len + s.
+ *   q columns: rotated, written to qkv[m, 0:H] (row stride ldc; the k / v columns of that buffer are NOT written);
+ *   k columns: rotated, written to kcache[b, head, past_len + s, :]; v columns: written to vcache likewise
+ *   (caches bf16 [B, heads, ctx_max, 128]).  The rotation is applied to the bf16-rounded projection with the fp32
+ *   cos / sin tables [pos, 64], i.e. bit-identical to vly_gemm_bf16 followed by vly_rope_kv.  Needs a tile whose width is
+ *   a multiple of 128 (a head's two halves in one tile: tile_hint 0, 1, 2, 3, 4, 9, 51, 53, 54, 73, 74, 83, 84, 93, 94) and
+ *   16-byte aligned qkv rows; other tile hints return -22. */
+int vly_gemm_bf16_qkv_rope(const void *A, const void *W, void *qkv, void *kcache, void *vcache, const float *cos_table,
+                           const float *sin_table, int M, int H, int K, int lda, int ldw, int ldc, int S, int heads,
+                           int past_len, int ctx_max, int tile_hint, void *stream);
 
 /* Split-K by two in ONE launch:  C0 = A[:, :K/2] . W[:, :K/2]^T + bias,  C1 = A[:, K/2:] . W[:, K/2:]^T, both bf16
  *   [M,N] with row stride ldc; the consumer adds them (vly_add2_rmsnorm).  The grid holds every tile twice, so a

@@ -665,3 +665,50 @@ def test_gemm_skinny(M, N, K, epi):
     from valley_amd.lib import ValleyHipError
     with pytest.raises(ValleyHipError):
         ops.gemm_skinny(rnd((300, K), 1, dtype=torch.bfloat16).to(d), w)     # M > 256 is not this kernel's job
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 9, 51, 53, 54, 73, 74, 83, 84, 93, 94])
+@pytest.mark.parametrize("B,S,heads,past", [(2, 75, 2, 0), (1, 336, 3, 0), (3, 40, 2, 100)])
+def test_gemm_qkv_rope_fused_bit_identical(tile, B, S, heads, past):
+    """vly_gemm_bf16_qkv_rope (RoPE + KV append in the q|k|v GEMM epilogue) vs vly_gemm_bf16 followed by vly_rope_kv:
+    rotated q, the appended cache rows of k and v — every bit equal, on row-major and block-ordered weights; cache rows
+    outside [past, past + S) untouched."""
+    from valley_amd import ops
+    d = dev()
+    H, K, ctx = heads * 128, 256, 512
+    a = rnd((B * S, K), 101, dtype=torch.bfloat16).to(d)
+    w = rnd((3 * H, K), 102, 0.05, dtype=torch.bfloat16).to(d)
+    cos, sin = _rope_tables(ctx)
+    cos, sin = cos.to(d), sin.to(d)
+    seedk = rnd((B, heads, ctx, 128), 103, dtype=torch.bfloat16).to(d)
+    k0, v0 = seedk.clone(), (seedk * 0.5).clone()
+    ref = ops.gemm_mfma(a, w, tile_hint=tile)
+    ops.rope_kv(ref, k0, v0, cos, sin, B, S, heads, past)
+    for wt in (w, ops.PackedWeight(w)):
+        qkv = torch.full((B * S, 3 * H), 7.0, dtype=torch.bfloat16, device=d)
+        k1, v1 = seedk.clone(), (seedk * 0.5).clone()
+        ops.gemm_mfma_qkv_rope(a, wt, qkv, ops.RopeKV(k1, v1, cos, sin, B, S, heads, past), tile)
+        assert torch.equal(qkv[:, :H], ref[:, :H])
+        assert torch.equal(k1, k0) and torch.equal(v1, v0)
+        assert float((qkv[:, H:].float() - 7.0).abs().max()) == 0.0        # the k / v columns of the buffer are not written
+
+
+def test_gemm_qkv_rope_rejects_narrow_tiles_and_falls_back():
+    from valley_amd import ops
+    from valley_amd.lib import ValleyHipError
+    d = dev()
+    B, S, heads, K = 1, 64, 2, 128
+    a = rnd((B * S, K), 104, dtype=torch.bfloat16).to(d)
+    w = rnd((3 * heads * 128, K), 105, 0.05, dtype=torch.bfloat16).to(d)
+    cos, sin = (t.to(d) for t in _rope_tables(128))
+    kc = torch.zeros((B, heads, 128, 128), dtype=torch.bfloat16, device=d)
+    rope = ops.RopeKV(kc, torch.zeros_like(kc), cos, sin, B, S, heads, 0)
+    qkv = torch.empty((B * S, 3 * heads * 128), dtype=torch.bfloat16, device=d)
+    for t in (5, 6, 7, 8, 76, 86):                         # 192- / odd-width tiles cannot hold a head's two halves
+        with pytest.raises(ValleyHipError):
+            ops.gemm_mfma_qkv_rope(a, w, qkv, rope, t)
+    ops.gemm_qkv_rope(a, w, qkv, rope)                     # the dispatcher picks a tile that can
+    ref = ops.gemm_mfma(a, w)
+    k2 = torch.zeros_like(kc)
+    ops.rope_kv(ref, k2, torch.zeros_like(kc), cos, sin, B, S, heads, 0)
+    assert torch.equal(qkv[:, :heads * 128], ref[:, :heads * 128]) and torch.equal(kc, k2)

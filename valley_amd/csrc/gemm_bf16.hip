@@ -210,12 +210,21 @@ VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char*
 }
 #endif
 
+// arguments of the VLY_EPI_QKV_ROPE epilogue (kernel argument by value; unused by every other instantiation)
+struct RopeArgs {
+    const float* cos_t;
+    const float* sin_t;
+    uint16_t* kc;
+    uint16_t* vc;
+    int S, past, heads, ctx_max;
+};
+
 template <int BM, int BN, int WM, int WN, int EPI, int OUT, int PIPE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
             int M, int N, int K, int lda, int ldw, int ldc, int ldr, int tiles_m, int tiles_n, int gm, int wide,
-            int ksplit, void* __restrict__ Cv2) {
+            int ksplit, void* __restrict__ Cv2, RopeArgs rp) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = NW * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -804,8 +813,34 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                     const int row = (hr / HR) * WM + half * HR + hr % HR;
                     const int m = m0 + row, n = n0o + q * 8;
                     if (m >= M || n >= No) continue;
-                    const u32x4 d = *(const u32x4*)(smem + row * C_ROW + q * 16);
+                    u32x4 d = *(const u32x4*)(smem + row * C_ROW + q * 16);
                     uint16_t* dst = (uint16_t*)Cv + (size_t)m * ldc + n;
+                    if constexpr (EPI == VLY_EPI_QKV_ROPE) {
+                        // the bf16 image of the tile is complete in LDS: rotate q / k chunks with their partner chunk 64
+                        // columns away (same head: BN % 128 == 0 and n0 % 128 == 0), route k / v to the KV cache.
+                        // Same arithmetic on the same bf16-rounded inputs as rope_kv_kernel -> identical bits.
+                        const int Hq = rp.heads * 128, sect = n / Hq, nn = n - sect * Hq;
+                        const int head = nn >> 7, dd = nn & 127;
+                        const int b = m / rp.S, pos = rp.past + (m - b * rp.S);
+                        if (sect < 2) {
+                            const u32x4 pd = *(const u32x4*)(smem + row * C_ROW + (dd < 64 ? q + 8 : q - 8) * 16);
+                            const float* cp = rp.cos_t + (size_t)pos * 64 + (dd & 63);
+                            const float* sp = rp.sin_t + (size_t)pos * 64 + (dd & 63);
+                            const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+                            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+                            const float sign = dd < 64 ? -1.f : 1.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x0 = __uint_as_float(d[e] << 16), x1 = __uint_as_float(d[e] & 0xffff0000u);
+                                const float y0 = __uint_as_float(pd[e] << 16), y1 = __uint_as_float(pd[e] & 0xffff0000u);
+                                const float cc0 = e < 2 ? c0[2 * e] : c1[2 * e - 4], cc1 = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
+                                const float ss0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], ss1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
+                                d[e] = pack_bf16x2(rope_rot(x0, y0, cc0, ss0, sign), rope_rot(x1, y1, cc1, ss1, sign));
+                            }
+                        }
+                        if (sect > 0)
+                            dst = (sect == 1 ? rp.kc : rp.vc) + (((size_t)b * rp.heads + head) * rp.ctx_max + pos) * 128 + dd;
+                    }
                     if (n + 8 <= No) *(u32x4*)dst = d;
                     else *(u32x2*)dst = u32x2{d[0], d[1]};      // N % 4 == 0: the ragged chunk holds exactly 4 columns
                 }
@@ -871,7 +906,8 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 
 template <int BM, int BN, int WM, int WN, int PIPE>
 int launch_tile(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
-                int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st, void* C2 = nullptr) {
+                int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st, void* C2 = nullptr,
+                const RopeArgs* rope = nullptr) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     constexpr int STAGE_B = (BM + BN) * 128 * ((PIPE == 6 || PIPE == 7) ? 3 : 2);
@@ -883,12 +919,23 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
     dim3 grid(tm * tn * ksplit), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, E, O, PIPE>), grid, block, 0, st, (const uint16_t*)A,   \
-                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, gm, wide, ksplit, C2)
+                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, tm, tn, gm, wide, ksplit, C2, rope ? *rope : RopeArgs{})
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMM_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_SWIGLU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_RELU && out == VLY_OUT_BF16) VLY_GEMM_LAUNCH(VLY_EPI_RELU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_QKV_ROPE && out == VLY_OUT_BF16 && rope) {
+        // a head's two halves must sit in one tile (BN % 128 == 0) and the epilogue works on the LDS image (wide);
+        // PIPE 1 / 3 (half-tile loops) are not instantiated for it
+        if constexpr (BN % 128 == 0 && PIPE != 1 && PIPE != 3) {
+            if (!wide) { vly_set_error("vly_gemm_bf16_qkv_rope: qkv rows must be 16-byte aligned"); return -22; }
+            VLY_GEMM_LAUNCH(VLY_EPI_QKV_ROPE, VLY_OUT_BF16);
+        } else {
+            vly_set_error("vly_gemm_bf16_qkv_rope: this tile is not a multiple of 128 columns wide");
+            return -22;
+        }
+    }
     else {
         vly_set_error("vly_gemm_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
         return -22;
@@ -921,8 +968,8 @@ extern "C" int vly_gemm_tile_for(int M, int N) { return pick_tile(M, N); }
 
 static int run_tile(int t, int tile_hint, const void* A, const void* W, const float* bias, const float* residual, void* C,
                     int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, hipStream_t st,
-                    void* C2) {
-#define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2
+                    void* C2, const RopeArgs* rope = nullptr) {
+#define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
     if (ldw < 0 && ((t >= 11 && t <= 15) || (t >= 31 && t <= 35))) {
         vly_set_error("vly_gemm_bf16: the half-tile loops (tile_hint %d) read row-major weights only", tile_hint);
         return -22;
@@ -1006,4 +1053,27 @@ extern "C" int vly_gemm_bf16_splitk2(const void* A, const void* W, const float* 
     const int t = tile_hint ? tile_hint : 8;
     return run_tile(t, tile_hint, A, W, bias, nullptr, C0, M, N, K, lda, ldw, ldc, 0, VLY_EPI_NONE, VLY_OUT_BF16,
                     (hipStream_t)stream, C1);
+}
+
+extern "C" int vly_gemm_bf16_qkv_rope(const void* A, const void* W, void* qkv, void* kcache, void* vcache, const float* cos_table,
+                                      const float* sin_table, int M, int H, int K, int lda, int ldw, int ldc, int S, int heads,
+                                      int past_len, int ctx_max, int tile_hint, void* stream) {
+    const bool wpacked = ldw == VLY_LDW_PACKED64;
+    const int N = 3 * H;
+    if (M <= 0 || H <= 0 || K <= 0 || K % BK || H != heads * 128 || S <= 0 || M % S || past_len < 0 || past_len + S > ctx_max ||
+        lda % 8 || (ldw % 8 || (ldw <= 0 && !wpacked)) || ldc % 8 || ldc < N || !qkv || !kcache || !vcache || !cos_table || !sin_table ||
+        ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)qkv & 15) || ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) ||
+        ((uintptr_t)cos_table & 15) || ((uintptr_t)sin_table & 15)) {
+        vly_set_error("vly_gemm_bf16_qkv_rope: unsupported shape/alignment M=%d H=%d K=%d S=%d heads=%d past=%d ctx_max=%d lda=%d ldw=%d ldc=%d",
+                      M, H, K, S, heads, past_len, ctx_max, lda, ldw, ldc);
+        return -22;
+    }
+    if ((size_t)M * lda >= (1ull << 31) || (wpacked ? (size_t)((N + 63) / 64 * 64) * K : (size_t)N * ldw) >= (1ull << 31)) {
+        vly_set_error("vly_gemm_bf16_qkv_rope: operand exceeds 2^31 elements (32-bit byte offsets)");
+        return -22;
+    }
+    const RopeArgs rp{cos_table, sin_table, (uint16_t*)kcache, (uint16_t*)vcache, S, past_len, heads, ctx_max};
+    const int t = tile_hint ? tile_hint : pick_tile(M, N);
+    return run_tile(t, tile_hint, A, W, nullptr, nullptr, qkv, M, N, K, lda, ldw, ldc, 0, VLY_EPI_QKV_ROPE, VLY_OUT_BF16,
+                    (hipStream_t)stream, nullptr, &rp);
 }

@@ -51,6 +51,8 @@ _SIGS = {
     "vly_add2_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "vly_argmax": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vly_cast_f32_bf16": (c_int, [_P, _P, c_long, _P]),
+    "vly_gemm_bf16_qkv_rope": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, _P]),
     "vly_gemm_skinny_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     # fp32 "precise" path
     "vly_gemm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -190,12 +190,15 @@ class HipLlama:
                 ops.add_norm(h, ws["delta"], L["ln1"], None, self.eps, out=ws["x"], rms=True, delta2=d2)
             else:
                 ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
-            ops.gemm(ws["x"], W["w_qkv"], out=ws["qkv"])
             if S == 1:                                      # one-token step: RoPE + append + attention fused
+                ops.gemm(ws["x"], W["w_qkv"], out=ws["qkv"])
                 ops.decode_attention(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, kv, B, self.heads, past,
                                      out=ws["att"])
             else:
-                ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
+                # prefill: RoPE + KV append ride in the q|k|v GEMM's epilogue (the tile is assembled in LDS for the
+                # full-line stores anyway); bit-identical to gemm + rope_kv, one launch and one pass over q|k|v less
+                ops.gemm_qkv_rope(ws["x"], W["w_qkv"], ws["qkv"], ops.RopeKV(cache.k[li], cache.v[li], self.cos, self.sin, B, S,
+                                                                            self.heads, past))
                 ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
             if fused:
                 # o_proj / down_proj have fewer output tiles than the chip has CUs at prefill sizes: the tuner may

@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _lib
 
-EPI_NONE, EPI_QUICK_GELU, EPI_SWIGLU, EPI_RELU = 0, 1, 2, 3
+EPI_NONE, EPI_QUICK_GELU, EPI_SWIGLU, EPI_RELU, EPI_QKV_ROPE = 0, 1, 2, 3, 4
 OUT_BF16, OUT_F32 = 0, 1
 POOL_MEAN, POOL_MAX, POOL_IMPORTANCE = 0, 1, 2
 
@@ -228,6 +228,73 @@ def gemm_skinny(a, w, bias=None, epilogue=EPI_NONE, out=None):
     return out
 
 
+class RopeKV:
+    """Arguments of the fused q|k|v epilogue: RoPE tables, the layer's KV cache, batch geometry."""
+
+    def __init__(self, kcache, vcache, cos, sin, B: int, S: int, heads: int, past_len: int):
+        self.kcache, self.vcache, self.cos, self.sin = kcache, vcache, cos, sin
+        self.B, self.S, self.heads, self.past = B, S, heads, past_len
+
+
+def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
+    """vly_gemm_bf16_qkv_rope: qkv[:, :H] = RoPE(a @ Wq^T), kcache / vcache appended with RoPE(a @ Wk^T) / a @ Wv^T —
+    bit-identical to gemm + rope_kv (the k / v columns of ``qkv`` are not written)."""
+    _chk(a, torch.bfloat16, "a", contiguous=False)
+    wt, ldw = _w_args(w, True)
+    _chk(qkv, torch.bfloat16, "qkv", contiguous=False)
+    _chk(rope.kcache, torch.bfloat16, "kcache")
+    _chk(rope.vcache, torch.bfloat16, "vcache")
+    _chk(rope.cos, torch.float32, "cos")
+    _chk(rope.sin, torch.float32, "sin")
+    M, K = a.shape
+    N = w.shape[0]
+    H = N // 3
+    ctx_max = rope.kcache.shape[2]
+    assert w.shape[1] == K and tuple(qkv.shape) == (M, N) and M == rope.B * rope.S and H == rope.heads * 128
+    assert tuple(rope.kcache.shape) == (rope.B, rope.heads, ctx_max, 128) and rope.vcache.shape == rope.kcache.shape
+    assert rope.cos.shape[0] >= rope.past + rope.S and rope.cos.shape[1] == 64
+    rec = _RECORDER
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.load().vly_gemm_bf16_qkv_rope(a.data_ptr(), wt.data_ptr(), qkv.data_ptr(), rope.kcache.data_ptr(), rope.vcache.data_ptr(),
+                                            rope.cos.data_ptr(), rope.sin.data_ptr(), M, H, K, a.stride(0), ldw, qkv.stride(0), rope.S,
+                                            rope.heads, rope.past, ctx_max, tile_hint, _stream())
+    if rec is not None:
+        e1.record()
+        L = _lib.load()
+        t = tile_hint or L.vly_gemm_tile_for(M, N)
+        nm = TILE_SPECIAL[t][0] if t in TILE_SPECIAL else TILE_NAMES[t % 10]
+        loop = TILE_SPECIAL[t][1] if t in TILE_SPECIAL else ({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[t // 10]
+        rec.append((f"gemm_kernel<{nm}, 4, 0, {loop}>", 2.0 * M * N * K, e0, e1, (M, N, K, EPI_QKV_ROPE)))
+    _lib.check(rc, "vly_gemm_bf16_qkv_rope")
+    return qkv
+
+
+FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "1") == "1"
+
+
+def gemm_qkv_rope(a, w, qkv, rope: "RopeKV"):
+    """The q|k|v projection of a prefill with RoPE + KV append fused into its epilogue, through the same dispatch as
+    ops.gemm (whole-tile heuristic in "tiles" mode, online tuner otherwise — candidates that cannot host the epilogue,
+    i.e. stream-K and the 192-column tiles, drop out by themselves).  VALLEY_FUSE_ROPE=0: gemm + rope_kv."""
+    if not FUSE_ROPE or qkv.stride(0) % 8 or torch.cuda.is_current_stream_capturing():
+        gemm(a, w, out=qkv)
+        rope_kv(qkv, rope.kcache, rope.vcache, rope.cos, rope.sin, rope.B, rope.S, rope.heads, rope.past)
+        return qkv
+    M, K = a.shape
+    N = w.shape[0]
+    if GEMM_MODE != "tuned":
+        return gemm_mfma_qkv_rope(a, w, qkv, rope, 0)
+    key = _tune_key(M, N, K, EPI_QKV_ROPE, qkv.dtype, False, False, w)
+    choice = _TUNED.get(key)
+    if choice is None:
+        if _multi_stream():
+            return gemm_mfma_qkv_rope(a, w, qkv, rope, 0)
+        return _online_trial(key, a, w, rope, None, EPI_QKV_ROPE, qkv.dtype, qkv)[0]
+    return gemm_mfma_qkv_rope(a, w, qkv, rope, choice[1])
+
+
 def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=torch.bfloat16, out=None):
     """Weight-streaming kernel for M <= 8 rows (decode)."""
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
@@ -434,8 +501,12 @@ def _gemm_rem(a, w, bias, epilogue, out):
 
 
 def _run_candidate(cand, a, w, bias, residual, epilogue, out_dtype, out, out2=None):
-    """-> (result tensor, number of partial outputs)."""
+    """-> (result tensor, number of partial outputs).  ``bias`` carries the RopeKV arguments for EPI_QKV_ROPE."""
     kind, t = cand
+    if epilogue == EPI_QKV_ROPE:
+        if kind != "tile":
+            raise _lib.ValleyHipError("the fused RoPE / KV epilogue exists in the whole-tile kernel only")
+        return gemm_mfma_qkv_rope(a, w, out, bias, t), 1
     if kind == "tile2k":
         return gemm_mfma_splitk2(a, w, bias, out, out2, t), 2
     if kind == "tile":
