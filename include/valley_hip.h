@@ -83,7 +83,8 @@ int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *
  *   k columns: rotated, written to kcache[b, head, past_len + s, :]; v columns: written to vcache likewise
  *   (caches bf16 [B, heads, ctx_max, 128]).  The rotation is applied to the bf16-rounded projection with the fp32
  *   cos / sin tables [pos, 64], i.e. bit-identical to vly_gemm_bf16 followed by vly_rope_kv.  Needs a tile whose width is
- *   a multiple of 128 (a head's two halves in one tile: tile_hint 0, 1, 2, 3, 4, 9, 51, 53, 54, 73, 74, 83, 84, 93, 94) and
+ *   a multiple of 128 (a head's two halves in one tile: every tile_hint whose tile is 128 or 256 columns wide, whole-K-tile
+ *   loops only) and
  *   16-byte aligned qkv rows; other tile hints return -22. */
 int vly_gemm_bf16_qkv_rope(const void *A, const void *W, void *qkv, void *kcache, void *vcache, const float *cos_table,
                            const float *sin_table, int M, int H, int K, int lda, int ldw, int ldc, int S, int heads,

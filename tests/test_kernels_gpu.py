@@ -667,7 +667,7 @@ def test_gemm_skinny(M, N, K, epi):
         ops.gemm_skinny(rnd((300, K), 1, dtype=torch.bfloat16).to(d), w)     # M > 256 is not this kernel's job
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 9, 51, 53, 54, 73, 74, 83, 84, 93, 94])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 8, 9, 51, 53, 54, 55, 73, 74, 83, 84, 93, 94])
 @pytest.mark.parametrize("B,S,heads,past", [(2, 75, 2, 0), (1, 336, 3, 0), (3, 40, 2, 100)])
 def test_gemm_qkv_rope_fused_bit_identical(tile, B, S, heads, past):
     """vly_gemm_bf16_qkv_rope (RoPE + KV append in the q|k|v GEMM epilogue) vs vly_gemm_bf16 followed by vly_rope_kv:
@@ -704,7 +704,7 @@ def test_gemm_qkv_rope_rejects_narrow_tiles_and_falls_back():
     kc = torch.zeros((B, heads, 128, 128), dtype=torch.bfloat16, device=d)
     rope = ops.RopeKV(kc, torch.zeros_like(kc), cos, sin, B, S, heads, 0)
     qkv = torch.empty((B * S, 3 * heads * 128), dtype=torch.bfloat16, device=d)
-    for t in (5, 6, 7, 8, 76, 86):                         # 192- / odd-width tiles cannot hold a head's two halves
+    for t in (6, 7, 56, 57, 76, 86, 11, 31):               # 192-column tiles cannot hold a head's two halves; half-tile loops have no such epilogue
         with pytest.raises(ValleyHipError):
             ops.gemm_mfma_qkv_rope(a, w, qkv, rope, t)
     ops.gemm_qkv_rope(a, w, qkv, rope)                     # the dispatcher picks a tile that can

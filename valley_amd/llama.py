@@ -195,8 +195,8 @@ class HipLlama:
                 ops.decode_attention(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, kv, B, self.heads, past,
                                      out=ws["att"])
             else:
-                # prefill: RoPE + KV append ride in the q|k|v GEMM's epilogue (the tile is assembled in LDS for the
-                # full-line stores anyway); bit-identical to gemm + rope_kv, one launch and one pass over q|k|v less
+                # prefill: q|k|v GEMM, then RoPE + KV append (VALLEY_FUSE_ROPE=1: both in the GEMM's epilogue — bit-identical,
+                # one launch less, measured neutral)
                 ops.gemm_qkv_rope(ws["x"], W["w_qkv"], ws["qkv"], ops.RopeKV(cache.k[li], cache.v[li], self.cos, self.sin, B, S,
                                                                             self.heads, past))
                 ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])

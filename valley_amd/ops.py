@@ -271,13 +271,16 @@ def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
     return qkv
 
 
-FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "1") == "1"
+# Off by default: measured neutral (c3, same box, profiles/r02/r02_ab_rowsplit_rope.txt: q|k|v 355.7 us + rope_kv 27 us vs
+# 373.5 us fused, but the step moved 87.75 -> 88.22 ms, inside the noise) — the epilogue's 16 dependent cos / sin fetches
+# per thread cost what the removed pass over q|k|v saved.  Kept as a tested option (bit-identical to the unfused pair).
+FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "0") == "1"
 
 
 def gemm_qkv_rope(a, w, qkv, rope: "RopeKV"):
     """The q|k|v projection of a prefill with RoPE + KV append fused into its epilogue, through the same dispatch as
     ops.gemm (whole-tile heuristic in "tiles" mode, online tuner otherwise — candidates that cannot host the epilogue,
-    i.e. stream-K and the 192-column tiles, drop out by themselves).  VALLEY_FUSE_ROPE=0: gemm + rope_kv."""
+    i.e. stream-K and the 192-column tiles, drop out by themselves).  VALLEY_FUSE_ROPE=1 enables it; default: gemm + rope_kv."""
     if not FUSE_ROPE or qkv.stride(0) % 8 or torch.cuda.is_current_stream_capturing():
         gemm(a, w, out=qkv)
         rope_kv(qkv, rope.kcache, rope.vcache, rope.cos, rope.sin, rope.B, rope.S, rope.heads, rope.past)
