@@ -269,3 +269,86 @@ def test_temporal_pooling_at_production_width_vs_oracle(method):
     print(f"N4 {method}: visual tokens [B={B}, {256 + T}, H={H}] rel-L2 {e:.2e} max-abs {maxabs(vis, ref):.3e} "
           f"(|ref| max {float(np.abs(ref).max()):.2f}); pooling+projection stage {ev[2].elapsed_time(ev[3]) - ev[0].elapsed_time(ev[1]):.3f} ms")
     assert e < 8e-3
+
+
+# ---- BASELINE.json configs[2] end to end --------------------------------------------------------------------------------
+def test_c3_shape_end_to_end_vs_oracle():
+    """configs[2] as a whole — B = 8 clips x T = 16 frames (128 frames through the full-depth ViT-L/14, 23 contributing
+    layers) -> mean pool + projector -> splice into 8 prompts of S = 336 -> decoder at the Vicuna-13B layer shapes
+    (H 5120, 40 heads, I 13824, eps 1e-6) -> lm_head on every position — through the reference-shaped API
+    (ValleyLlamaForCausalLM.forward), tuned dispatch, against the CPU oracle on the same deterministic weights and
+    pixels.  Only the decoder DEPTH is reduced (2 of 40 layers: depth changes no kernel shape) so that the oracle needs
+    ~30 s of host time instead of ten minutes."""
+    from oracle import valley_oracle as O
+    from valley_amd import ops, valley_model as vm, weights as W
+    B, T, H, heads, I, V, VT = 8, 16, 5120, 40, 13824, 512, 500
+    S = 320 + T
+    cfg = vm.ValleyConfig(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=2, num_attention_heads=heads,
+                          num_key_value_heads=heads, rms_norm_eps=1e-6, max_position_embeddings=2048)
+    cfg.use_mm_proj, cfg.mm_hidden_size, cfg.mm_vision_select_layer = True, 1024, -2
+    _, sd, lcfg = _llama("13b")
+    vsd = W.clip_vision_weights(3, layers=24)
+    model = vm.ValleyLlamaForCausalLM(cfg)
+    model.load_state_dict(sd)
+    tower = vm.build_vision_tower(None, state_dict=vsd)
+    special = W.SPECIAL_IDS(VT)
+    for k, v in special.items():
+        setattr(tower.config, k, v)
+    model.get_model().vision_tower = tower
+    ids = np.stack([W.synthetic_prompt(7 + b, T, VT, ids=special) for b in range(B)])
+    assert ids.shape == (B, S)
+    px = torch.from_numpy(W.det_normal(4, "px.c3", (B, T, 3, 224, 224)))
+    saved_mode = ops.GEMM_MODE
+    ops.GEMM_MODE = "tuned"
+    try:
+        for _ in range(40):                                  # let the online tuner settle any shape not in the shipped table
+            out = model(input_ids=torch.from_numpy(ids).cuda(), images=px.cuda())
+            torch.cuda.synchronize()
+            if ops.tuning_pending() == 0:
+                break
+    finally:
+        ops.GEMM_MODE = saved_mode
+    got = out.logits.cpu().numpy()
+    assert got.shape == (B, S, V) and ops.sk_error_flag("cuda:0") == 0
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(16, nthr))                     # torch's CPU GEMM peaks at 16 threads on the GPU box's host
+    try:
+        with torch.no_grad():
+            ref, _, emb = O.valley_forward(torch.from_numpy(ids), px, sd, vsd, lcfg, O.VisionCfg(), O.TokenIds(**special))
+    finally:
+        torch.set_num_threads(nthr)
+    ref = ref.numpy()
+    e_l, m_l = rel(got, ref), maxabs(got, ref)
+    got_emb = model.get_model().embed_inputs(torch.from_numpy(ids), px.cuda()).view(B, S, H).cpu().numpy()
+    e_e = rel(got_emb, emb.numpy())
+    print(f"c3 end to end (2 of 40 decoder layers): spliced embeddings rel-L2 {e_e:.2e}; logits rel-L2 {e_l:.2e} max-abs {m_l:.3e} "
+          f"(|logit| max {float(np.abs(ref).max()):.2f})")
+    assert e_e < 8e-3 and e_l < 2.2e-2
+
+
+def test_c4_shape_tower_chunk_invariance():
+    """The per-GPU tower shape of configs[3] (8 clips x 32 frames = 256 frames in one pass): with the batch-invariant
+    whole-tile dispatch the 256-frame pass equals, bit for bit, the same frames encoded as 2 x 128 and as 8 x 32 — the
+    encode is per-frame, however many frames share a launch (and whatever the row split does to the launches in tuned
+    mode stays within fp32 summation-order noise)."""
+    from valley_amd import ops, valley_model as vm
+    tower = vm.build_vision_tower(None)
+    tower.init_random(seed=2)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    frames = torch.randn((256, 3, 224, 224), generator=g, device="cuda")
+    a = tower.encode(frames, -2, chunk=256)
+    assert torch.equal(a, tower.encode(frames, -2, chunk=128)) and torch.equal(a[:64], tower.encode(frames[:64], -2, chunk=32))
+    assert torch.isfinite(a).all()
+    saved = ops.GEMM_MODE
+    ops.GEMM_MODE = "tuned"
+    try:
+        for _ in range(30):
+            b = tower.encode(frames, -2)
+            torch.cuda.synchronize()
+            if ops.tuning_pending() == 0:
+                break
+    finally:
+        ops.GEMM_MODE = saved
+    r = float((b - a).norm() / a.norm())
+    print("c4 tower, tuned (row-split + skinny remainder) vs whole tiles: rel-L2", r)
+    assert r < 5e-3 and ops.sk_error_flag("cuda:0") == 0
