@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
         }
 
+        // raw scores (K . q) stay unscaled: the softmax scale rides in the exponent's FMA, exp2(s * sc - m * sc)
+        // (one multiply per score less; v_max3 halves the max chain) — the softmax VALU work, not the MFMAs, is what a
+        // SIMD's four waves contend for in this kernel
         f32x4 s[VNT];
 #pragma unroll
         for (int t = 0; t < VNT; ++t) {
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
                 const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
                 acc = mfma16(kf, qf[kk], acc);
             }
-            s[t] = acc * sc;
+            s[t] = acc;
             if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
         }
         // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
@@ -120,17 +123,16 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 
         float m = NEG_BIG;
 #pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        for (int t = 0; t < VNT; ++t) m = fmaxf(fmaxf(m, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float msc = m * sc;
         float l = 0.f;
 #pragma unroll
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[t][r] - m);
+                const float p = exp2f(fmaf(s[t][r], sc, -msc));
                 s[t][r] = p;
                 l += p;
             }

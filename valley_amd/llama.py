@@ -38,6 +38,31 @@ class HipKVCache:
         self.ctx_max = ctx_max
         self.batch = batch
         self.key_valid: Optional[torch.Tensor] = None      # uint8 [B, ctx_max] when a padding mask was given
+        self.generation = 0                                  # bumped when the storage moves (a captured decode graph must be rebuilt)
+        self.growable = False                                # set by the model for caches IT sized (the caller never said how deep)
+        self.limit = ctx_max
+
+    def reserve(self, n: int) -> None:
+        """Make room for ``n`` positions.  A cache the model created on the caller's behalf (use_cache=True without
+        past_key_values, the reference's worker loop, serve/model_worker.py:373-387) starts at prompt length + 256 instead
+        of max_position_embeddings (13B: 1.7 GB per sequence at 2048) and doubles when it fills up — the HF DynamicCache the
+        reference uses grows the same way; a cache the caller sized (new_cache(B, ctx)) never moves."""
+        if n <= self.ctx_max:
+            return
+        if not self.growable or n > self.limit:
+            raise ValueError(f"KV cache overflow: {n} > {self.ctx_max}")
+        new_ctx = min(self.limit, max(n, 2 * self.ctx_max))
+        for buf in (self.k, self.v):
+            for i, t in enumerate(buf):
+                g = torch.zeros((t.shape[0], t.shape[1], new_ctx, 128), dtype=t.dtype, device=t.device)
+                g[:, :, :self.seq_len] = t[:, :, :self.seq_len]
+                buf[i] = g
+        if self.key_valid is not None:
+            kv = torch.ones((self.batch, new_ctx), dtype=torch.uint8, device=self.key_valid.device)
+            kv[:, :self.ctx_max] = self.key_valid
+            self.key_valid = kv
+        self.ctx_max = new_ctx
+        self.generation += 1
 
     @classmethod
     def rows_of(cls, parent: "HipKVCache", b0: int, b1: int) -> "HipKVCache":
@@ -48,6 +73,7 @@ class HipKVCache:
         c.v = [t[b0:b1] for t in parent.v]
         c.seq_len, c.ctx_max, c.batch = 0, parent.ctx_max, b1 - b0
         c.key_valid = None if parent.key_valid is None else parent.key_valid[b0:b1]
+        c.generation, c.growable, c.limit = 0, False, parent.ctx_max
         return c
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
@@ -165,8 +191,7 @@ class HipLlama:
         if not self.loaded:
             raise RuntimeError("Llama engine has no weights")
         past = cache.seq_len
-        if past + S > cache.ctx_max:
-            raise ValueError(f"KV cache overflow: {past}+{S} > {cache.ctx_max}")
+        cache.reserve(past + S)                              # grows a model-sized cache, raises for a caller-sized one
         if cache.batch != B:
             raise ValueError("cache batch mismatch")
         ops.sk_check_polled(self.device)                   # a stream-K hand-off failure of an earlier call surfaces here

@@ -134,6 +134,26 @@ class F32KVCache:
         self.v = [torch.zeros((batch, heads, ctx_max, 128), dtype=F32, device=device) for _ in range(layers)]
         self.seq_len, self.ctx_max, self.batch = 0, ctx_max, batch
         self.key_valid: Optional[torch.Tensor] = None
+        self.generation, self.growable, self.limit = 0, False, ctx_max
+
+    def reserve(self, n: int) -> None:
+        """Same contract as llama.HipKVCache.reserve."""
+        if n <= self.ctx_max:
+            return
+        if not self.growable or n > self.limit:
+            raise ValueError(f"KV cache overflow: {n} > {self.ctx_max}")
+        new_ctx = min(self.limit, max(n, 2 * self.ctx_max))
+        for buf in (self.k, self.v):
+            for i, t in enumerate(buf):
+                g = torch.zeros((t.shape[0], t.shape[1], new_ctx, 128), dtype=t.dtype, device=t.device)
+                g[:, :, :self.seq_len] = t[:, :, :self.seq_len]
+                buf[i] = g
+        if self.key_valid is not None:
+            kv = torch.ones((self.batch, new_ctx), dtype=torch.uint8, device=self.key_valid.device)
+            kv[:, :self.ctx_max] = self.key_valid
+            self.key_valid = kv
+        self.ctx_max = new_ctx
+        self.generation += 1
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.seq_len
@@ -201,8 +221,7 @@ class PreciseLlama:
         if not isinstance(cache, F32KVCache):
             raise TypeError("the fp32 engine needs the F32KVCache it created")
         past = cache.seq_len
-        if past + S > cache.ctx_max:
-            raise ValueError(f"KV cache overflow: {past}+{S} > {cache.ctx_max}")
+        cache.reserve(past + S)
         if cache.batch != B:
             raise ValueError("cache batch mismatch")
         with runtime.stream_lock():

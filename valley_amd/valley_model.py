@@ -269,7 +269,7 @@ class ValleyLlamaModel:
                      frames_per_clip: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Token embedding + visual splice (valley_model.py:160-247) -> fp32 residual stream [B*S, H]."""
         B, S = input_ids.shape
-        ids_host = input_ids.detach().cpu().numpy()
+        ids_host = _ids_to_host(input_ids)
         row_map = ids_host.astype(np.int32).reshape(-1)
         visual = None
         has_vision = self.vision_tower is not None and (S != 1 or self.training)          # :164
@@ -310,9 +310,12 @@ class ValleyLlamaModel:
                                 "a foreign (HF tuple / DynamicCache) cache cannot be continued on the HIP path")
             cache = None                                       # an EMPTY foreign cache (HF generate's step 0) starts fresh
         if cache is None:
-            # sized for what the caller can still append: the whole context when the cache is handed back, else S
-            ctx = max(getattr(self.config, "max_position_embeddings", 2048), S)
-            cache = self.llama.new_cache(B, ctx if use_cache else S)
+            # a cache nobody sized: prompt + 256 positions (rounded to 128), growing by doubling up to
+            # max_position_embeddings when the caller keeps appending (HipKVCache.reserve) — not 2048 deep up front
+            limit = max(getattr(self.config, "max_position_embeddings", 2048), S)
+            cache = self.llama.new_cache(B, min(limit, (S + 256 + 127) // 128 * 128) if use_cache else S)
+            cache.growable, cache.limit = bool(use_cache), limit
+        cache.reserve(cache.seq_len + S)
         if attention_mask is not None:
             am = attention_mask.to(self.device)
             if cache.key_valid is None and bool((am == 0).any()):
@@ -324,6 +327,17 @@ class ValleyLlamaModel:
         return BaseModelOutputWithPast(last_hidden_state=x.view(B, S, -1), past_key_values=cache if use_cache else None)
 
     __call__ = forward
+
+
+def _ids_to_host(input_ids: torch.Tensor) -> np.ndarray:
+    """Token ids as a host array (the splice's index logic — which rows become visual tokens, the reference's
+    ValueErrors — runs on the host, B*S integers).  Host ids (what a tokenizer hands over) cost nothing.  Device ids
+    need a D2H copy that is ordered behind whatever is already queued on the stream: free when the forward is the first
+    thing queued (the reference's call pattern: ``model(input_ids.cuda(), images=...)`` embeds before it encodes, and so
+    does this forward), a stall only for a caller that queued the tower first and then passes device ids — such a
+    caller (bench.py's split step) keeps the ids on the host, where they came from."""
+    t = input_ids.detach()
+    return (t.cpu() if t.is_cuda else t).numpy()
 
 
 def _clip_image_processor(name_or_tower, vc):
