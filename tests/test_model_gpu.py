@@ -644,3 +644,52 @@ def test_continuous_batching_matches_solo_requests(use_graph):
     # a released slot is reused
     s_new = cb.add(reqs[0][0], images=img)
     assert s_new in (slot_of[0], slot_of[1], slot_of[2]) and int(cb.sess.tok[s_new]) == solo[0][0]
+
+
+def test_model_sized_kv_cache_grows_instead_of_preallocating_2048():
+    """A forward with use_cache=True and no past_key_values (the worker's first call, serve/model_worker.py:373-378) gets a
+    cache of prompt + 256 positions, not max_position_embeddings (13B: 1.7 GB per sequence); it doubles when the caller
+    keeps appending (like the HF DynamicCache it stands in for), a captured decode graph is rebuilt when the storage
+    moves, and the numbers do not change: chunked prefill across a growth step == one prefill; a decode session that
+    outgrows its cache produces the tokens of one that never has to."""
+    from valley_amd.decode import DecodeSession
+    model = build_golden_model()
+    T = G.GCFG["T"]
+    ids, _ = G.golden_ids("decode2")
+    img1 = torch.from_numpy(G.golden_pixels(T, "mixed")).view(1, T, 3, 224, 224).cuda()
+    ids_t = torch.from_numpy(ids).cuda()
+    S = ids.shape[1]
+    out = model(input_ids=ids_t, images=img1, use_cache=True)
+    cache = out.past_key_values
+    assert cache.ctx_max == (S + 256 + 127) // 128 * 128 < 2048 and cache.growable
+    # append text chunks until the cache has to grow twice; compare with ONE forward over the same tokens
+    rng = np.random.default_rng(0)
+    extra = torch.from_numpy(rng.integers(3, G.GCFG["vocab_text"], (1, 1100))).cuda()
+    pos, gens = 0, cache.generation
+    for n in (300, 300, 500):
+        o = model(input_ids=extra[:, pos:pos + n], past_key_values=cache, use_cache=True)
+        pos += n
+    assert cache.generation >= gens + 2 and cache.get_seq_length() == S + 1100 and cache.ctx_max >= S + 1100
+    full = model(input_ids=torch.cat([ids_t, extra], 1), images=img1)
+    assert maxabs(o.logits[:, -1].cpu().numpy(), full.logits[:, -1].cpu().numpy()) < 2e-2        # same kernels, different chunking
+    # a caller-sized cache never moves: overflow is an error
+    small = model.get_model().llama.new_cache(1, S + 2)
+    model(input_ids=ids_t, images=img1, past_key_values=small, use_cache=True)
+    with pytest.raises(ValueError):
+        model(input_ids=extra[:, :8], past_key_values=small, use_cache=True)
+    # decode session across a growth step (graph re-captured) vs a session on a roomy cache
+    toks = {}
+    for name, grow in (("roomy", False), ("tight", True)):
+        ll = model.get_model().llama
+        c = ll.new_cache(1, 1024 if not grow else S + 3)
+        c.growable, c.limit = grow, 1024
+        o0 = model(input_ids=ids_t, images=img1, past_key_values=c, use_cache=True)
+        sess = DecodeSession(ll, c, use_graph=True)
+        sess.begin(o0.logits[:, -1].argmax(-1))
+        seq = [int(sess.tok[0])]
+        for _ in range(12):
+            seq.append(int(sess.step()[0]))
+        toks[name] = seq
+        if grow:
+            assert c.generation >= 1 and c.ctx_max > S + 3
+    assert toks["tight"] == toks["roomy"]

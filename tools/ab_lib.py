@@ -147,9 +147,53 @@ def run_attn(names, shapes, reps=60):
         print(json.dumps({"attn": sh, **{n: round(statistics.median(t), 1) for n, t in zip(names, times)}, "unit": "us"}), flush=True)
 
 
+def run_vit_attn(names, frames, reps=40):
+    """ViT attention (vly_vit_attention) A/B: one arm per library, F frames per launch."""
+    import random
+    import torch
+    from valley_amd import build as b
+    P, I = ctypes.c_void_p, ctypes.c_int
+    libs = []
+    for n in names:
+        L = ctypes.CDLL(b.LIB if n == "base" else os.path.join(VARDIR, f"libvalley_hip_{n}.so"))
+        L.vly_vit_attention.restype = I
+        L.vly_vit_attention.argtypes = [P, P, I, P]
+        libs.append(L)
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rng = random.Random(0)
+    for F in frames:
+        qkvs = [torch.randn((F * 257, 3072), device=d).to(torch.bfloat16) for _ in range(3)]     # rotate: cold-ish inputs
+        outs = [torch.empty((F * 257, 1024), device=d, dtype=torch.bfloat16) for _ in libs]
+        times = [[] for _ in libs]
+        n = 0
+        for r in range(reps + 3):
+            order = list(range(len(libs)))
+            rng.shuffle(order)
+            for li in order:
+                q = qkvs[n % 3]
+                n += 1
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = libs[li].vly_vit_attention(q.data_ptr(), outs[li].data_ptr(), F, st)
+                e1.record()
+                assert rc == 0
+                torch.cuda.synchronize()
+                if r >= 3:
+                    times[li].append(e0.elapsed_time(e1) * 1e3)
+        for li in range(len(libs)):
+            libs[li].vly_vit_attention(qkvs[0].data_ptr(), outs[li].data_ptr(), F, st)
+        torch.cuda.synchronize()
+        errs = [float((outs[li].float() - outs[0].float()).norm() / outs[0].float().norm()) for li in range(len(libs))]
+        print(json.dumps({"vit_attn_frames": F, **{n_: round(statistics.median(t), 1) for n_, t in zip(names, times)}, "unit": "us",
+                          "rel_vs_first": [round(e, 5) for e in errs]}), flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "run-vit-attn":
+        run_vit_attn(sys.argv[2].split(","), [int(x) for x in sys.argv[3:]] or [32, 128, 256])
     elif sys.argv[1] == "run-attn":
         run_attn(sys.argv[2].split(","), sys.argv[3:] or ["4,328,32", "8,336,40", "8,352,40"])
     else:

@@ -101,6 +101,10 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
         }
 
+#ifndef VLY_VIT_SOFTMAX
+#define VLY_VIT_SOFTMAX 1      // 0: scale, then max / exp2(s - m) (round 1); 1: scale folded into the exponent FMA (A/B: tools/ab_lib.py run-vit-attn)
+#endif
+#if VLY_VIT_SOFTMAX == 1
         // raw scores (K . q) stay unscaled: the softmax scale rides in the exponent's FMA, exp2(s * sc - m * sc)
         // (one multiply per score less; v_max3 halves the max chain) — the softmax VALU work, not the MFMAs, is what a
         // SIMD's four waves contend for in this kernel
@@ -139,6 +143,44 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
 
+#else
+        f32x4 s[VNT];
+#pragma unroll
+        for (int t = 0; t < VNT; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                acc = mfma16(kf, qf[kk], acc);
+            }
+            s[t] = acc * sc;
+            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
+        }
+        // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
+
+        float m = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(s[t][r] - m);
+                s[t][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+
+#endif
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -40,6 +40,7 @@ class DecodeSession:
         self.logits = torch.empty((B, llama.Vpad), dtype=torch.float32, device=d)
         self.use_graph = use_graph
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._gen = cache.generation
 
     def _enqueue_step(self):
         ll, c = self.ll, self.cache
@@ -73,27 +74,40 @@ class DecodeSession:
             self.tok.copy_(first_token.to(torch.int32).view(-1))
             if self.cache.key_valid is not None:
                 self.cache.key_valid[:, self.cache.seq_len:] = 1       # generated positions are always attended
-        if self.use_graph and self.graph is None:
-            # warm-up outside capture on a side stream (module loading, lazy init), then capture
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            pos0, tok0 = self.pos.clone(), self.tok.clone()
-            with torch.cuda.stream(s):
-                self._enqueue_step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            self.pos.copy_(pos0)
-            self.tok.copy_(tok0)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue_step()
-            self.graph = g
+        if self.use_graph and (self.graph is None or self._gen != self.cache.generation):
+            self._capture()
+
+    def _capture(self):
+        """Warm-up outside capture on a side stream (module loading, lazy init), then capture ONE step; the device-side
+        position / token are restored, so capturing is invisible to the sequence.  Re-run whenever the cache's storage
+        moved (HipKVCache.reserve grew it): the graph holds raw pointers."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        pos0, tok0 = self.pos.clone(), self.tok.clone()
+        with torch.cuda.stream(s):
+            self._enqueue_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.pos.copy_(pos0)
+        self.tok.copy_(tok0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue_step()
+        self.graph = g
+        self._gen = self.cache.generation
 
     def step(self) -> torch.Tensor:
         """Run one decode step; returns the (device) int32 [B] buffer holding the newly chosen token.
         ``self.logits[:, :V]`` holds that step's logits (for temperature sampling on the host side)."""
-        if not self.per_row and self.cache.seq_len + 1 > self.cache.ctx_max:
-            raise ValueError("KV cache full")
+        if not self.per_row:
+            try:
+                self.cache.reserve(self.cache.seq_len + 1)           # grows a model-sized cache (new storage -> new graph)
+            except ValueError:
+                raise ValueError("KV cache full") from None
+            if self.cache.key_valid is not None and self.cache.key_valid.shape[1] != self.cache.ctx_max:
+                raise RuntimeError("key_valid out of step with the cache")
+            if self.graph is not None and self._gen != self.cache.generation:
+                self._capture()
         if self.graph is not None:
             self.graph.replay()
         else:
