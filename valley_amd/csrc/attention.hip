@@ -21,6 +21,21 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
 
+// Softmax exponentials: exp2 of (score - running max) <= 0.  The library exp2f wraps v_exp_f32 in a denormal-safe
+// rescale (v_cmp + 2 v_cndmask + v_add + v_exp + v_ldexp: six instructions, 396 of the ViT kernel's 978 VALU
+// instructions per query tile); the bare instruction flushes results below 2^-126 to zero, which is exactly what a
+// softmax weight that small is worth (VLY_FAST_EXP2=0 restores the library call for A/B builds).
+#ifndef VLY_FAST_EXP2
+#define VLY_FAST_EXP2 1
+#endif
+VLY_DEVICE float sm_exp2(float x) {
+#if VLY_FAST_EXP2
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return exp2f(x);
+#endif
+}
+
 VLY_DEVICE uint32_t sel16(const u32x4& a, const u32x4& b, int dd) {   // element dd (0..15) of 16 bf16 in (a,b)
     const uint32_t w = dd < 8 ? a[dd >> 1] : b[(dd - 8) >> 1];
     return (dd & 1) ? (w >> 16) : (w & 0xffffu);
@@ -102,7 +117,8 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         }
 
 #ifndef VLY_VIT_SOFTMAX
-#define VLY_VIT_SOFTMAX 1      // 0: scale, then max / exp2(s - m) (round 1); 1: scale folded into the exponent FMA (A/B: tools/ab_lib.py run-vit-attn)
+#define VLY_VIT_SOFTMAX 0      // 0 (default): scale, then max / exp2(s - m); 1: scale folded into the exponent FMA + max3 chain — fewer VALU
+                               // instructions, measured 4 % SLOWER (tools/ab_lib.py run-vit-attn: 113.4 vs 109.0 us at 128 frames)
 #endif
 #if VLY_VIT_SOFTMAX == 1
         // raw scores (K . q) stay unscaled: the softmax scale rides in the exponent's FMA, exp2(s * sc - m * sc)
@@ -136,7 +152,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(fmaf(s[t][r], sc, -msc));
+                const float p = sm_exp2(fmaf(s[t][r], sc, -msc));
                 s[t][r] = p;
                 l += p;
             }
@@ -173,7 +189,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[t][r] - m);
+                const float p = sm_exp2(s[t][r] - m);
                 s[t][r] = p;
                 l += p;
             }
@@ -356,14 +372,14 @@ __global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __
         rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
         rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
         const float mn = fmaxf(m, rm);
-        const float alpha = exp2f(m - mn);
+        const float alpha = sm_exp2(m - mn);
         m = mn;
         float ps = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[t][r] - mn);
+                const float p = sm_exp2(s[t][r] - mn);
                 s[t][r] = p;
                 ps += p;
             }
@@ -459,7 +475,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float l = 0.f;
     for (int j = tid; j < kv_len; j += 256) {
-        const float p = exp2f(sc[j] - m);
+        const float p = sm_exp2(sc[j] - m);
         sc[j] = p;
         l += p;
     }
@@ -603,8 +619,8 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 #pragma unroll
         for (int w = 1; w < 8; ++w) mc = fmaxf(mc, red[w]);
         const float m_new = fmaxf(m_run, mc);
-        const float alpha = exp2f(m_run - m_new);
-        const float p = s > 0.5f * NEG_BIG ? exp2f(s - m_new) : 0.f;   // masked keys never count, even in an all-masked chunk
+        const float alpha = sm_exp2(m_run - m_new);
+        const float p = s > 0.5f * NEG_BIG ? sm_exp2(s - m_new) : 0.f;   // masked keys never count, even in an all-masked chunk
         sc[tid] = p;
         float lc = wave_sum(p);
         if (lane == 0) red[8 + wave] = lc;

@@ -229,8 +229,13 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     constexpr int NT = NW * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;      // glds passes per tile
-    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+    // glds passes per tile.  A tile height that is not a multiple of NT / 8 rows (224 rows on 512 threads = 3.5 passes)
+    // takes a last pass in which only the waves whose 64-slot run still lies inside the tile load (wave-uniform guard);
+    // such tiles use the vmcnt(0) loops only (the counted-vmcnt loops assume the same number of loads in every wave)
+    constexpr int PA = (BM * 8 + NT - 1) / NT, PW = BN * 8 / NT;
+    constexpr bool A_RAGGED = BM * 8 % NT != 0;
+    static_assert(BN * 8 % NT == 0 && BM * 8 % 64 == 0, "tile/threads mismatch");
+    static_assert(!A_RAGGED || PIPE == 0 || PIPE == 4, "ragged A staging needs a vmcnt(0) loop");
 
     // bf16 outputs leave through LDS (see the epilogue): the C tile image may be larger than the K-loop stages
     constexpr int BNO = EPI == VLY_EPI_SWIGLU ? BN / 2 : BN;          // output columns of the tile
@@ -318,7 +323,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p)
+                if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
+                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
             for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
@@ -442,7 +449,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p)
+                if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
+                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
             for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
@@ -540,7 +549,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p)
+                if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
+                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
             for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
@@ -586,7 +597,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             char* sW = sA + A_BYTES;
             const int k0 = kt * BK;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PA; ++p)
+                if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
+                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
             for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
@@ -761,7 +774,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #define VLY_FRAG_ROW(i) frag_row(i)
 #define VLY_FRAG_COL(i, j) frag_col(i, j)
 #else
-#define EPI_NH 2
+#define EPI_NH (MI % 2 == 0 ? 2 : 1)        /* an odd number of 16-row fragments per wave leaves in one pass */
 #define VLY_FRAG_ROW(i) wm0 + i * 16 + l15
 #define VLY_FRAG_COL(i, j) wn0 + j * 16 + g * 4
 #endif
@@ -1002,6 +1015,10 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 93: return launch_tile<256, 128, 64, 32, 6>(VLY_TILE_ARGS);
         case 94: return launch_tile<128, 256, 32, 64, 6>(VLY_TILE_ARGS);
+        // 224 x 256: M = 2688 (13B prefill, 8 x 336 rows) is 12 x 224 exactly — no padded rows, 720 / 240 tiles instead of
+        // 660 / 220 where the 11th 256-row tile is half empty
+        case 95: return launch_tile<224, 256, 112, 64, 0>(VLY_TILE_ARGS);
+        case 96: return launch_tile<224, 256, 112, 64, 4>(VLY_TILE_ARGS);
         case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);
