@@ -543,6 +543,9 @@ class ValleyLlamaForCausalLM:
                 out = self.forward(input_ids=token[:, None], attention_mask=mask, past_key_values=cache, use_cache=True)
                 token = torch.where(finished, torch.full_like(token, pad), pick(out.logits[:, -1, :].contiguous()))
             seq = torch.cat([seq, token[:, None]], dim=1)
+        ops.sk_poll_async(self.device)
+        torch.cuda.current_stream().synchronize()            # the caller decodes the tokens next; a stream-K hand-off
+        ops.sk_check_polled(self.device)                     # failure anywhere in this generation is reported here at the latest
         return seq
 
     # -- tokenizer / prompt glue -----------------------------------------------------------------------
