@@ -247,7 +247,10 @@ constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row str
 
 // LNW waves x 16 query rows per workgroup: with 8 waves a K/V tile staged into LDS serves 128 queries (half the
 // redundant tile loads and transposes of the 64-query version) and a CU holds 16 waves.
-constexpr int LNW = 8;
+#ifndef VLY_LNW
+#define VLY_LNW 8               // 4 or 8 (A/B: tools/ab_lib.py build x --src attention.hip -DVLY_LNW=4; run-attn)
+#endif
+constexpr int LNW = VLY_LNW;
 
 __global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
                                                          const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
