@@ -38,14 +38,20 @@ int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n) {
 int vly_tile_group_height(int M, int N, int K, int tiles_m, int tiles_n, int BM, int BN, int wg_per_cu) {
     static const int forced = getenv("VLY_TILE_GM") ? atoi(getenv("VLY_TILE_GM")) : 0;
     if (forced > 0) return forced < tiles_m ? forced : tiles_m;
-    if (!vly_tile_order_m_fast(M, N, K, tiles_m, tiles_n)) return 1;
     static const bool grouped = !(getenv("VLY_TILE_GROUPED") && atoi(getenv("VLY_TILE_GROUPED")) == 0);
-    if (!grouped) return tiles_m;
+    if (!grouped) return vly_tile_order_m_fast(M, N, K, tiles_m, tiles_n) ? tiles_m : 1;      // round-1 behaviour
+    // the near-square block also serves the shapes whose byte count prefers n-fastest (tall A, small W — the ViT GEMMs):
+    // measured, own process per setting (tools/gemm_time.py, cold operands): fc1 32768x4096x1024 343 us (gm = 1) -> 327 us
+    // (gm = 6), fc2 286 -> 276 us (gm = 8); q|k|v and out-proj flat; gm = 1 is the WORST choice for the Llama shapes
+    // ... except when tiles_n divides the 8 XCDs: n-fastest then hands every XCD ONE column block of W for the whole launch
+    // (workgroup i -> XCD i % 8), which stays in its 4 MiB L2 — fc2 32768x1024x4096 in the c3 bench: 1172 TF n-fastest,
+    // 1121 TF grouped (profiles/r02/r02_ab_tile_group.txt)
+    if (tiles_n <= 8 && 8 % tiles_n == 0 && !vly_tile_order_m_fast(M, N, K, tiles_m, tiles_n)) return 1;
     const double conc = 32.0 * wg_per_cu;
     int gm = (int)(sqrt(conc * BN / BM) + 0.5);
     if (gm < 1) gm = 1;
     if (gm >= tiles_m || tiles_m <= gm + gm / 2) return tiles_m;       // a ragged last group would be worse than one group
-    const int groups = (tiles_m + gm - 1) / gm;                           // balance the groups: 11 -> 6 + 5, not 6 + 5 by luck
+    const int groups = (tiles_m + gm - 1) / gm;                           // balance the groups: 11 -> 6 + 5
     return (tiles_m + groups - 1) / groups;
 }
 
