@@ -83,6 +83,8 @@ def run(names, shapes, reps=40):
         torch.cuda.synchronize()
         for ai in range(1, len(arms)):
             err = float((outs[ai].float() - outs[0].float()).norm() / outs[0].float().norm())
+            if os.environ.get("AB_NOCHECK") == "1":                        # timing experiments with deliberately broken variants
+                continue
             assert err < 2e-3, (names[arms[ai][0]], arms[ai][1], sh, err)
         ncall = 0
         for r in range(reps + 3):

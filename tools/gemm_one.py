@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run ONE GEMM shape a few times (for rocprofv3 --pmc runs): gemm_one.py M N K kind tile [epi] [reps]"""
+"""Run ONE GEMM shape a few times (for rocprofv3 --pmc runs): gemm_one.py M N K tile|sk|lib tile [epi] [reps]"""
 import os
 import sys
 
@@ -18,5 +18,8 @@ w = (torch.randn((N, K), device=d) * 0.05).to(torch.bfloat16)
 out = torch.empty((M, N // 2 if epi == 2 else N), device=d, dtype=torch.bfloat16)
 fn = ops.gemm_mfma if kind == "tile" else ops.gemm_streamk
 for _ in range(reps):
-    fn(a, w, epilogue=epi, out=out, tile_hint=tile)
+    if kind == "lib":          # the vendor library's kernel for the same problem (information only: its counters beside ours)
+        torch.mm(a, w.t(), out=out)
+    else:
+        fn(a, w, epilogue=epi, out=out, tile_hint=tile)
 torch.cuda.synchronize()

@@ -22,11 +22,11 @@ agg = collections.defaultdict(list)
 dur = []
 for f in sorted(glob.glob(sys.argv[1] + "/p*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"]:
+        if "gemm" in r["Kernel_Name"] or "Cijk" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob(sys.argv[1] + "/p1_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"]:
+        if "gemm" in r["Kernel_Name"] or "Cijk" in r["Kernel_Name"]:
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 if dur:
     print("launches", len(dur), "median_us", sorted(dur)[len(dur) // 2] / 1e3)

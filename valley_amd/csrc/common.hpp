@@ -70,6 +70,16 @@ VLY_DEVICE void glds16_cp(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, CPOL);
 }
 
+// LDS-DMA through a buffer descriptor: address = descriptor base + voff (per lane, loop-invariant) + soff (SGPR, the K
+// position) — no per-piece 64-bit VALU address arithmetic, one SALU (m0) + one VMEM issue slot per piece.
+VLY_DEVICE __amdgpu_buffer_rsrc_t vly_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFFu, 0x00020000);
+}
+template <int CPOL>
+VLY_DEVICE void bglds16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, CPOL);
+}
+
 void vly_set_error(const char* fmt, ...);
 int vly_check_launch(const char* what);
 int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n);

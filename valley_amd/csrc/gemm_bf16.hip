@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -215,6 +216,56 @@ VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char*
     }
 }
 #endif
+
+// One phase of the 4-wave loop (PIPE 8): the MI x NI MFMAs of one 32-wide K step on fragments that are already in
+// registers, with up to three lists of other instructions (the NI + MI fragment reads of the NEXT step — W fragments
+// first, then A, the order the next phase consumes them —, the LDS-DMA pieces of a later K tile, a barrier) placed at fixed
+// MFMA indices.  Every non-MFMA instruction is fenced so the compiler cannot bunch them up in front of the MFMAs (it
+// does: ISA of the first version had nine ds_reads + lgkmcnt(0) ahead of the first MFMA of each phase).  One wave per
+// SIMD: nothing else hides a gap in this wave's MFMA stream.
+// f1(k), k < N1, goes after MFMA number S1 + k * D1 (row-major over the MI x NI MFMAs); f2 / f3 likewise
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3>
+VLY_DEVICE void phase_4w3(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            const int t = i * NI + j;
+            if (N1 > 0 && t >= S1 && (t - S1) % D1 == 0 && (t - S1) / D1 < N1) {
+                __builtin_amdgcn_sched_barrier(0);
+                f1((t - S1) / D1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (N3 > 0 && t >= S3 && (t - S3) % D3 == 0 && (t - S3) / D3 < N3) {
+                __builtin_amdgcn_sched_barrier(0);
+                f3((t - S3) / D3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (N2 > 0 && t >= S2 && (t - S2) % D2 == 0 && (t - S2) / D2 < N2) {
+                __builtin_amdgcn_sched_barrier(0);
+                f2((t - S2) / D2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // whatever did not fit the MFMA slots (small MI x NI)
+#pragma unroll
+    for (int k = 0; k < N1; ++k)
+        if (S1 + k * D1 >= MI * NI) f1(k);
+#pragma unroll
+    for (int k = 0; k < N3; ++k)
+        if (S3 + k * D3 >= MI * NI) f3(k);
+#pragma unroll
+    for (int k = 0; k < N2; ++k)
+        if (S2 + k * D2 >= MI * NI) f2(k);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, typename F1, typename F2>
+VLY_DEVICE void phase_4w(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2) {
+    phase_4w3<MI, NI, N1, S1, D1, N2, S2, D2, 0, 0, 1>(acc, af, wf, f1, f2, [](int) {});
+}
 
 // arguments of the VLY_EPI_QKV_ROPE epilogue (kernel argument by value; unused by every other instantiation)
 struct RopeArgs {
@@ -582,6 +633,138 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             mma_ktile<MI, NI>(acc, cur + rdA, cur + rdW, sw0, sw1);
             }
             buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else if constexpr (PIPE == 8) {
+        // ================= 4 waves, one per SIMD, 128 x 128 per wave; two whole-K-tile buffers (128-byte rows) ============
+        // LDS-pipe arithmetic per 256 x 256 x 64 K tile (MFMA time at peak: 2062 clk): fragment reads are
+        // waves x (WM + WN) x 128 B at 256 B/clk — 16 waves of 64 x 64: 1024 clk, 8 waves of 128 x 64: 768 clk, 4 waves of
+        // 128 x 128: 512 clk.  The many-wave tiles buy latency hiding with LDS traffic (MFMA busy 56-60 %, PMC); this loop
+        // has a quarter / half of their reads and hides latency in software (fragments of the next K step are read between
+        // the MFMAs of the current one, across K tiles too).
+        // What bounds it is the L1 -> LDS path: 64 B/clk per CU = one 1 KB LDS-DMA piece per 16 clk per CU = per 64 clk for
+        // each of the four waves, i.e. one piece per ~4 MFMAs; a wave that issues faster stalls in the issue and, being alone
+        // on its SIMD, feeds no MFMAs meanwhile (measured: 16 pieces at every 2nd MFMA -8 % against every 4th; a version of
+        // the loop WITHOUT the pieces runs 26-30 % faster; 64-byte-row half tiles (PIPE 9) cost twice the path time per piece).
+        // So the 16 pieces of a K tile are spread as thin as the buffers allow — the buffer of tile kt is released as soon as
+        // its last fragments are read, in the middle of phase 1, not at its end:
+        //   phase 1 (MFMAs of K step 0 of tile kt): reads of K step 1 first | lgkmcnt(0) + barrier A: buffer kt & 1 is free |
+        //            the first N1 pieces of tile kt+2 into it
+        //   vmcnt(N1) + barrier B: tile kt+1 has landed everywhere
+        //   phase 2 (MFMAs of K step 1): reads of K step 0 of tile kt+1 | the other 16 - N1 pieces of tile kt+2.
+        // 256 accumulator + 128 fragment registers per lane.
+        static_assert(NW == 4 && !A_RAGGED, "one wave per SIMD");
+        // slot arithmetic (T = MFMAs per phase): reads of phase 1 after MFMA 0 .. MI+NI-1, barrier A eight MFMAs (~140 clk, a
+        // ds_read round trip) later, then one piece every STRIDE MFMAs until the end of phase 2.  256 x 256: barrier after
+        // MFMA 24, 7 pieces after 26, 32 .. 62, 9 after 4, 10 .. 52 of phase 2; A/B of other placements: r02_ab_4wave.txt
+#ifndef VLY_P8_BAR_GAP
+#define VLY_P8_BAR_GAP 8
+#endif
+#ifndef VLY_P8_RD2_START
+#define VLY_P8_RD2_START 1       // phase 2: reads of the next tile's K step 0 after MFMA 1, 3, 5, ...
+#endif
+#ifndef VLY_P8_RD2_STRIDE
+#define VLY_P8_RD2_STRIDE 2
+#endif
+        constexpr int T = MI * NI, BAR_AT = MI + NI + VLY_P8_BAR_GAP, GL1_START = BAR_AT + 2;
+        static_assert(GL1_START < T, "phase too short for the early release");
+        constexpr int NS = PA + PW;
+        constexpr int GL_STRIDE = (2 * T - GL1_START) / NS;                          // 102 / 16 = 6
+        constexpr int N1 = (T - GL1_START + GL_STRIDE - 1) / GL_STRIDE, N2 = NS - N1;   // pieces in phase 1 / phase 2
+        constexpr int GL2_START = GL1_START + N1 * GL_STRIDE - T;
+        static_assert(GL_STRIDE >= 1 && N1 >= 0 && N2 >= 0 && GL2_START + (N2 - 1) * GL_STRIDE < T, "piece schedule");
+        uint32_t voA[PA], voW[PW];                                  // per-lane BYTE offsets
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int sl = q * NT + tid, row = sl >> 3, cp = sl & 7;
+            voA[q] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3)) * 2u;
+        }
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int sl = q * NT + tid, row = sl >> 3, cp = sl & 7;
+            voW[q] = (w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3)) * 2u;
+        }
+        const __amdgpu_buffer_rsrc_t rsA = vly_rsrc(A), rsW = vly_rsrc(W);
+        auto piece = [&](int kt, int buf, int q) {
+            char* st = smem + buf * STAGE;
+            if (q < PA) bglds16<VLY_A_CPOL>(rsA, voA[q < PA ? q : 0], (uint32_t)kt * (BK * 2u), st + (q * NT + wave * 64) * 16);
+            else bglds16<VLY_W_CPOL>(rsW, voW[q >= PA ? q - PA : 0], (uint32_t)kt * wk * 2u, st + A_BYTES + ((q - PA) * NT + wave * 64) * 16);
+        };
+        const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
+        const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+        bf16x8 a0[MI], w0[NI], a1[MI], w1[NI];
+        auto rd_step1 = [&](const char* st) {
+            return [&, st](int k) {
+                if (k < NI) w1[k < NI ? k : 0] = *(const bf16x8*)(st + rdW + k * 2048 + sw1);
+                else a1[k >= NI ? k - NI : 0] = *(const bf16x8*)(st + rdA + (k - NI) * 2048 + sw1);
+            };
+        };
+        auto rd_step0 = [&](const char* st) {
+            return [&, st](int k) {
+                if (k < NI) w0[k < NI ? k : 0] = *(const bf16x8*)(st + rdW + k * 2048 + sw0);
+                else a0[k >= NI ? k - NI : 0] = *(const bf16x8*)(st + rdA + (k - NI) * 2048 + sw0);
+            };
+        };
+        auto none = [](int) {};
+        auto bar_a = [](int) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+
+#pragma unroll
+        for (int q = 0; q < NS; ++q) piece(0, 0, q);
+        if (nk > 1) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) piece(1, 1, q);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wave_live) {
+            auto r0 = rd_step0(smem);
+#pragma unroll
+            for (int k = 0; k < MI + NI; ++k) r0(k);
+        }
+        int kt = 0;
+        if (nk == 1) {                                              // K = 64: one tile, nothing to overlap
+            if (wave_live) {
+                phase_4w<MI, NI, MI + NI, 0, 1, 0, 0, 1>(acc, a0, w0, rd_step1(smem), none);
+                phase_4w<MI, NI, 0, 0, 1, 0, 0, 1>(acc, a1, w1, none, none);
+            }
+        } else {
+        for (; kt + 2 < nk; ++kt) {
+            const char* cur = smem + (kt & 1) * STAGE;
+            const char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            if (wave_live)
+                phase_4w3<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1>(
+                    acc, a0, w0, rd_step1(cur), [&](int q) { piece(kt + 2, kt & 1, q); }, bar_a);
+            else {
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int q = 0; q < N1; ++q) piece(kt + 2, kt & 1, q);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave_live)
+                phase_4w<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE>(
+                    acc, a1, w1, rd_step0(nxt), [&](int q) { piece(kt + 2, kt & 1, N1 + q); });
+            else {
+#pragma unroll
+                for (int q = 0; q < N2; ++q) piece(kt + 2, kt & 1, N1 + q);
+            }
+        }
+        {   // kt = nk - 2, nk - 1: nothing left to request
+            const char* cur = smem + (kt & 1) * STAGE;
+            const char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            if (wave_live) phase_4w<MI, NI, MI + NI, 0, 1, 0, 0, 1>(acc, a0, w0, rd_step1(cur), none);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave_live) {
+                phase_4w<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, 0, 0, 1>(acc, a1, w1, rd_step0(nxt), none);
+                phase_4w<MI, NI, MI + NI, 0, 1, 0, 0, 1>(acc, a0, w0, rd_step1(nxt), none);
+                phase_4w<MI, NI, 0, 0, 1, 0, 0, 1>(acc, a1, w1, none, none);
+            }
+        }
         }
     } else if constexpr (PIPE == 7) {
         // ================= role-split (as PIPE 4) over THREE full-tile stages (as PIPE 6) =====================
@@ -993,6 +1176,14 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         vly_set_error("vly_gemm_bf16: the half-tile loops (tile_hint %d) read row-major weights only", tile_hint);
         return -22;
     }
+#ifdef VLY_FEW_TILES                                        /* fast A/B builds (tools/ab_lib.py): only the tiles under study */
+    switch (t) {
+        case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
+        case 97: return launch_tile<256, 256, 128, 128, 8>(VLY_TILE_ARGS);
+        case 98: return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
+        default: vly_set_error("vly_gemm_bf16: tile_hint %d is not in this VLY_FEW_TILES build", tile_hint); return -22;
+    }
+#else
     switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split over half tiles;
                                                           // 51..55: role-split over the full-tile 2-stage buffers
         case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
@@ -1025,6 +1216,11 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         // 660 / 220 where the 11th 256-row tile is half empty
         case 95: return launch_tile<224, 256, 112, 64, 0>(VLY_TILE_ARGS);
         case 96: return launch_tile<224, 256, 112, 64, 4>(VLY_TILE_ARGS);
+        // 4 waves x (128 x 128): a quarter of the 16-wave tile's LDS fragment traffic (PIPE 8 comment)
+        case 97:
+        case 98:                                            // 224 x 256 (M = 2688 = 12 x 224), 112 x 128 per wave
+            if (t == 97) return launch_tile<256, 256, 128, 128, 8>(VLY_TILE_ARGS);
+            return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
         case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);
@@ -1035,6 +1231,7 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 35: return launch_tile<192, 256, 96, 64, 3>(VLY_TILE_ARGS);
         default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
     }
+#endif
 #undef VLY_TILE_ARGS
 }
 
