@@ -967,6 +967,82 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #define VLY_FRAG_ROW(i) wm0 + i * 16 + l15
 #define VLY_FRAG_COL(i, j) wn0 + j * 16 + g * 4
 #endif
+#ifdef VLY_DBG_NO_EPILOGUE                                    /* timing experiment (WRONG results): what do the stores cost? */
+    if (PIPE == 8 && acc[0][0][0] != 12345.678f) return;
+#endif
+    if constexpr (OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE && NI % 4 == 0 && !VLY_MFMA32) {
+        if (wide == 2) {
+            // ---- full-line stores WITHOUT LDS: the four lanes that hold a row (g = 0 .. 3, sixteen lanes apart) trade
+            // register halves with v_permlane16_swap / v_permlane32_swap (gfx950) until each holds 16 contiguous bytes:
+            //   plain: per pair of 16-column blocks (j0, j1) one swap16 per packed dword — even g ends up with columns
+            //          4g .. 4g+7 of j0, odd g with columns 4(g-1) .. 4g+3 of j1: 64 contiguous bytes per row and pair;
+            //   SwiGLU (one dword = 2 outputs per block): a 4 x 4 transpose over four blocks, swap16 then swap32 — lane g
+            //          ends up with the 8 outputs of block 4q + g.
+            // swap16(x, y): even rows keep x and receive the odd row's x, odd rows receive the even row's y and keep y
+            // (tools/probes/permlane_swap.hip).  No barrier, no LDS: the K-loop buffers are not touched, and the epilogue
+            // needs no workgroup-wide synchronisation.  EXEC must be full at the swaps: math and swaps run for every lane,
+            // only loads and stores are predicated.
+            const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm0 + i * 16 + l15;
+                uint16_t* crow = (uint16_t*)Cv + (size_t)min(m, M - 1) * ldc;
+                if constexpr (EPI == VLY_EPI_SWIGLU) {
+#pragma unroll
+                    for (int jq = 0; jq < NI / 4; ++jq) {
+                        uint32_t d[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const f32x4 v = acc[i][4 * jq + jj];
+                            d[jj] = pack_bf16x2(x_sigmoid(v[0], 1.f) * v[1], x_sigmoid(v[2], 1.f) * v[3]);
+                        }
+                        const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                        const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+                        const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+                        const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+                        const u32x4 o = u32x4{q0[0], q1[0], q0[1], q1[1]};
+                        const int no = ((n0 + wn0) >> 1) + (4 * jq + g) * 8;
+                        if (m < M) {
+                            if (no + 8 <= No) *(u32x4*)(crow + no) = o;
+                            else if (no + 4 <= No) *(u32x2*)(crow + no) = u32x2{o[0], o[1]};
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int jp = 0; jp < NI / 2; ++jp) {
+                        u32x2 pk[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int n = n0 + wn0 + (2 * jp + jj) * 16 + g * 4;
+                            f32x4 v = acc[i][2 * jp + jj];
+                            const bool in = m < M && n < N;
+                            if (bias && in) v += *(const f32x4*)(bias + n);
+                            if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
+                            }
+                            if constexpr (EPI == VLY_EPI_RELU) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                            }
+                            if (R && in) v += *(const f32x4*)(R + (size_t)m * ldr + n);
+                            pk[jj][0] = pack_bf16x2(v[0], v[1]);
+                            pk[jj][1] = pack_bf16x2(v[2], v[3]);
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        const int n = n0 + wn0 + (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
+                        if (m < M) {
+                            if (n + 8 <= N) *(u32x4*)(crow + n) = o;
+                            else if (n + 4 <= N) *(u32x2*)(crow + n) = u32x2{o[0], o[1]};
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     if constexpr (OUT == VLY_OUT_BF16) {
         if (wide) {
             __syncthreads();                                  // every wave is done with the K-loop stages
@@ -1106,6 +1182,311 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #undef EPI_NH
 #endif
 
+// Read one accumulator block where it is USED: the "a" constraint keeps the value in the accumulation registers up to this
+// point (left alone, hipcc copies half of the 256 accumulators into VGPRs at the top of the epilogue and spills the K loop's
+// per-lane offsets to scratch to make room — a scratch reload in the K loop is a vmcnt(0) in front of the LDS-DMA stream).
+VLY_DEVICE f32x4 acc_read(const f32x4& a) {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
+                 : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]));
+    return v;
+}
+
+// ================= persistent 4-wave kernel: the PIPE 8 loop running THROUGH tile boundaries ==========================
+// One workgroup per CU walks tiles bid, bid + G, bid + 2G, ...  Measured on the one-tile-per-workgroup kernel
+// (profiles/r02/r02_ab_4wave.txt, "noepi"): without its epilogue the ViT fc1 GEMM (K = 1024: 16 K tiles per output tile)
+// runs 213 instead of 292 us — the stores of one round, the workgroup turn-around and the first loads of the next round
+// are all exposed when every CU holds ONE workgroup (128 KB of LDS, 512 registers per wave).  Here
+//   * the LOAD cursor runs two K tiles ahead of the COMPUTE cursor across tile boundaries (it owns the per-lane offsets and
+//     recomputes them when it enters a new tile), so the K-loop buffers never drain between tiles;
+//   * the epilogue works on registers only (v_permlane16/32_swap, gemm_kernel's `wide == 2` path): it needs neither the LDS
+//     the next tile's K tiles are landing in nor a barrier, and its stores are in flight while the next tile's MFMAs run;
+//   * past the last tile the load cursor re-requests the last K tile (valid addresses, free buffer): one code path, the
+//     vmcnt bookkeeping never changes, 128 KB of redundant L2 reads per workgroup and launch.
+// vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads return in order,
+// so an older load (the K tile this barrier publishes) cannot be outstanding unless the N1 younger ones are — whatever the
+// stores issued in between do; they only make the wait conservative.
+template <int BM, int BN, int EPI, int OUT>
+__global__ void __launch_bounds__(256)
+gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
+               const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+               int tiles_m, int tiles_n, int gm, int vec_ok) {
+    constexpr int WM = BM / 2, WN = BN / 2, NT = 256;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT, NS = PA + PW;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0 && NI % 4 == 0, "tile/threads mismatch");
+    constexpr int T = MI * NI, BAR_AT = MI + NI + VLY_P8_BAR_GAP, GL1_START = BAR_AT + 2;
+    constexpr int GL_STRIDE = (2 * T - GL1_START) / NS;
+    constexpr int N1 = (T - GL1_START + GL_STRIDE - 1) / GL_STRIDE, N2 = NS - N1;
+    constexpr int GL2_START = GL1_START + N1 * GL_STRIDE - T;
+    static_assert(GL1_START < T && GL_STRIDE >= 1 && N2 >= 0 && GL2_START + (N2 - 1) * GL_STRIDE < T, "piece schedule");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;
+    const int nk = K / BK;
+    __builtin_assume(nk >= 2);                                       // launcher: K >= 128 (a zero-trip K loop would make the accumulators a phi)
+    const uint32_t wk = ldw < 0 ? (uint32_t)((N + 63) >> 6) * 4096u : (uint32_t)BK;
+    // tile index -> (m0, n0): the mapping of gemm_kernel (XCD-contiguous runs, groups of gm m-tiles); tile t runs on
+    // workgroup t % G and G % 8 == 0 whenever a workgroup owns more than one tile, so t & 7 is still its XCD
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, qd = ntiles >> 3, rm = ntiles & 7;
+        const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (t >> 3);
+        const int gsz = gm * tiles_n, grp = swz / gsz, first = grp * gm;
+        const int gh = min(gm, tiles_m - first), rr = swz - grp * gsz;
+        m0 = (first + rr % gh) * BM;
+        n0 = (rr / gh) * BN;
+    };
+    const __amdgpu_buffer_rsrc_t rsA = vly_rsrc(A), rsW = vly_rsrc(W);
+    // ---- load cursor
+    uint32_t voA[PA], voW[PW];
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int sl = q * NT + tid, row = sl >> 3, cp = sl & 7;
+            voA[q] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3)) * 2u;
+        }
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int sl = q * NT + tid, row = sl >> 3, cp = sl & 7;
+            voW[q] = (w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3)) * 2u;
+        }
+    };
+    int lt = (int)blockIdx.x, lk = 0;                                // tile / K tile the load cursor points at
+    auto piece = [&](int buf, int q) {
+        char* st = smem + buf * STAGE;
+        if (q < PA) bglds16<VLY_A_CPOL>(rsA, voA[q < PA ? q : 0], (uint32_t)lk * (BK * 2u), st + (q * NT + wave * 64) * 16);
+        else bglds16<VLY_W_CPOL>(rsW, voW[q >= PA ? q - PA : 0], (uint32_t)lk * wk * 2u, st + A_BYTES + ((q - PA) * NT + wave * 64) * 16);
+    };
+    auto advance_load = [&]() {                                      // past the last tile: stay on its last K tile
+        if (lk + 1 < nk) { ++lk; return; }
+        if (lt + G >= ntiles) return;
+        lt += G;
+        lk = 0;
+        int m0, n0;
+        tile_origin(lt, m0, n0);
+        set_offsets(m0, n0);
+    };
+    int cm0, cn0;                                                    // compute cursor
+    int ct = (int)blockIdx.x;
+    tile_origin(ct, cm0, cn0);
+    set_offsets(cm0, cn0);
+
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
+    const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
+    bf16x8 a0[MI], w0[NI], a1[MI], w1[NI];
+    f32x4 acc[MI][NI];
+    auto rd_step1 = [&](const char* st) {
+        return [&, st](int k) {
+            if (k < NI) w1[k < NI ? k : 0] = *(const bf16x8*)(st + rdW + k * 2048 + sw1);
+            else a1[k >= NI ? k - NI : 0] = *(const bf16x8*)(st + rdA + (k - NI) * 2048 + sw1);
+        };
+    };
+    auto rd_step0 = [&](const char* st) {
+        return [&, st](int k) {
+            if (k < NI) w0[k < NI ? k : 0] = *(const bf16x8*)(st + rdW + k * 2048 + sw0);
+            else a0[k >= NI ? k - NI : 0] = *(const bf16x8*)(st + rdA + (k - NI) * 2048 + sw0);
+        };
+    };
+    auto bar_a = [](int) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue: the first two K tiles of the stream
+#pragma unroll
+    for (int q = 0; q < NS; ++q) piece(0, q);
+    advance_load();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) piece(1, q);
+    advance_load();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        auto r0 = rd_step0(smem);
+#pragma unroll
+        for (int k = 0; k < MI + NI; ++k) r0(k);
+    }
+    int buf = 0;                                                     // buffer of the K tile being computed
+    for (;;) {
+        const bool wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int kt = 0;
+        do {
+            const char* cur = smem + buf * STAGE;
+            const char* nxt = smem + (buf ^ 1) * STAGE;
+            // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
+            if (wave_live)
+                phase_4w3<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1>(
+                    acc, a0, w0, rd_step1(cur), [&](int q) { piece(buf, q); }, bar_a);
+            else {
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int q = 0; q < N1; ++q) piece(buf, q);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave_live)
+                phase_4w<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE>(
+                    acc, a1, w1, rd_step0(nxt), [&](int q) { piece(buf, N1 + q); });
+            else {
+#pragma unroll
+                for (int q = 0; q < N2; ++q) piece(buf, N1 + q);
+            }
+            advance_load();
+            buf ^= 1;
+        } while (++kt < nk);
+        // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
+        // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
+        if constexpr (OUT == VLY_OUT_BF16) {                           // the launcher guarantees 16-byte aligned rows, no residual
+            {
+                const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
+                f32x4 bv[NI];                                        // the bias of this lane's 4 columns per block: once per tile
+                if constexpr (EPI != VLY_EPI_SWIGLU) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int n = cn0 + wn0 + j * 16 + g * 4;
+                        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (bias) bv[j] = *(const f32x4*)(bias + min(n, N - 4));       // uniform branch, clamped (masked at the store)
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);               // row by row: keeps the accumulator reads from piling up
+                    const int m = cm0 + wm0 + i * 16 + l15;
+                    uint16_t* crow = (uint16_t*)Cv + (size_t)min(m, M - 1) * ldc;
+                    if constexpr (EPI == VLY_EPI_SWIGLU) {
+#pragma unroll
+                        for (int jq = 0; jq < NI / 4; ++jq) {
+                            uint32_t d[4];
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const f32x4 v = acc_read(acc[i][4 * jq + jj]);
+                                d[jj] = pack_bf16x2(x_sigmoid(v[0], 1.f) * v[1], x_sigmoid(v[2], 1.f) * v[3]);
+                            }
+                            const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                            const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+                            const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+                            const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+                            const u32x4 o = u32x4{q0[0], q1[0], q0[1], q1[1]};
+                            const int no = ((cn0 + wn0) >> 1) + (4 * jq + g) * 8;
+                            if (m < M) {
+                                if (no + 8 <= No) *(u32x4*)(crow + no) = o;
+                                else if (no + 4 <= No) *(u32x2*)(crow + no) = u32x2{o[0], o[1]};
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int jp = 0; jp < NI / 2; ++jp) {
+                            u32x2 pk[2];
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                f32x4 v = acc_read(acc[i][2 * jp + jj]) + bv[2 * jp + jj];
+                                if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
+                                }
+                                if constexpr (EPI == VLY_EPI_RELU) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                                }
+                                pk[jj][0] = pack_bf16x2(v[0], v[1]);
+                                pk[jj][1] = pack_bf16x2(v[2], v[3]);
+                            }
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                            const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                            const int n = cn0 + wn0 + (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
+                            if (m < M) {
+                                if (n + 8 <= N) *(u32x4*)(crow + n) = o;
+                                else if (n + 4 <= N) *(u32x2*)(crow + n) = u32x2{o[0], o[1]};
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (OUT == VLY_OUT_F32) {                            // 16 bytes per lane already: 64 contiguous bytes per row and block
+            static_assert(EPI == VLY_EPI_NONE, "fp32 outputs carry no activation");
+            f32x4 bv[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = cn0 + wn0 + j * 16 + g * 4;
+                bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (bias) bv[j] = *(const f32x4*)(bias + min(n, N - 4));
+            }
+            const int ncol = cn0 + wn0 + g * 4;                      // column of block 0; block j adds 16 j
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int m = cm0 + wm0 + i * 16 + l15;
+                if (m < M) {
+                    float* crow = (float*)Cv + (size_t)m * ldc + ncol;
+                    if (R) {
+                        const float* rrow = R + (size_t)m * ldr + ncol;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            if (ncol + j * 16 < N) *(f32x4*)(crow + j * 16) = acc_read(acc[i][j]) + bv[j] + *(const f32x4*)(rrow + j * 16);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            if (ncol + j * 16 < N) *(f32x4*)(crow + j * 16) = acc_read(acc[i][j]) + bv[j];
+                    }
+                }
+            }
+        }
+        if (ct + G >= ntiles) break;
+        ct += G;
+        tile_origin(ct, cm0, cn0);
+        {   // K step 0 of the next tile's first K tile: it landed before the last barrier B (same buffer rotation)
+            auto r0 = rd_step0(smem + buf * STAGE);
+#pragma unroll
+            for (int k = 0; k < MI + NI; ++k) r0(k);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+template <int BM, int BN>
+int launch_p4(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw,
+              int ldc, int ldr, int epi, int out, hipStream_t st) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, 1);
+    const int vec_ok = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !R) ? 1 : 0;
+    if (out == VLY_OUT_BF16 && !vec_ok) return 1;                       // caller falls back to the one-tile-per-workgroup kernel
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (getenv("VLY_P4_GRID")) n = atoi(getenv("VLY_P4_GRID"));
+        return n > 0 ? n / 8 * 8 : 256;                                // a multiple of the XCD count (tile -> XCD mapping)
+    }();
+    const int tiles = tm * tn;
+    dim3 grid(tiles < cus ? tiles : cus), block(256);
+#define VLY_P4_LAUNCH(E, O)                                                                                                  \
+    hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
+                       K, lda, ldw, ldc, ldr, tm, tn, gm, vec_ok)
+    if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
+    else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_RELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_RELU, VLY_OUT_BF16);
+    else {
+        vly_set_error("vly_gemm_bf16: unsupported epilogue/out_dtype combination (%d,%d) for the persistent tiles", epi, out);
+        return -22;
+    }
+#undef VLY_P4_LAUNCH
+    return vly_check_launch("vly_gemm_bf16");
+}
+
 template <int BM, int BN, int WM, int WN, int PIPE>
 int launch_tile(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K,
                 int lda, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st, void* C2 = nullptr,
@@ -1116,7 +1497,10 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
     const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, STAGE_B <= 80 * 1024 ? 2 : 1);
     // full-line stores through LDS need 16-byte aligned output rows (VLY_EPILOGUE=frag: A/B switch for measurements)
     static const bool frag_only = getenv("VLY_EPILOGUE") && !strcmp(getenv("VLY_EPILOGUE"), "frag");
-    const int wide = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !frag_only) ? 1 : 0;
+    // VLY_EPILOGUE=lds keeps the LDS image for the 4-wave tiles too (A/B); their default is the register-swap epilogue
+    static const bool lds_only = getenv("VLY_EPILOGUE") && !strcmp(getenv("VLY_EPILOGUE"), "lds");
+    int wide = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !frag_only) ? 1 : 0;
+    if (wide && PIPE == 8 && epi != VLY_EPI_QKV_ROPE && !lds_only) wide = 2;
     const int ksplit = C2 ? 2 : 1;
     dim3 grid(tm * tn * ksplit), block(NT);
 #define VLY_GEMM_LAUNCH(E, O)                                                                         \
@@ -1172,6 +1556,7 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
                     int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, hipStream_t st,
                     void* C2, const RopeArgs* rope = nullptr) {
 #define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
+#define VLY_TILE_ARGS_RAW A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
     if (ldw < 0 && ((t >= 11 && t <= 15) || (t >= 31 && t <= 35))) {
         vly_set_error("vly_gemm_bf16: the half-tile loops (tile_hint %d) read row-major weights only", tile_hint);
         return -22;
@@ -1181,6 +1566,8 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 97: return launch_tile<256, 256, 128, 128, 8>(VLY_TILE_ARGS);
         case 98: return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
+        case 197: return launch_p4<256, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        case 198: return launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
         default: vly_set_error("vly_gemm_bf16: tile_hint %d is not in this VLY_FEW_TILES build", tile_hint); return -22;
     }
 #else
@@ -1217,6 +1604,16 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 95: return launch_tile<224, 256, 112, 64, 0>(VLY_TILE_ARGS);
         case 96: return launch_tile<224, 256, 112, 64, 4>(VLY_TILE_ARGS);
         // 4 waves x (128 x 128): a quarter of the 16-wave tile's LDS fragment traffic (PIPE 8 comment)
+        case 197:                                           // persistent: one workgroup per CU walks the tiles (gemm_p4_kernel)
+        case 198:
+            if (C2 || rope) { vly_set_error("vly_gemm_bf16: tile_hint %d does not take the split-K pair / RoPE epilogue", tile_hint); return -22; }
+            if (K < 2 * BK) return run_tile(t - 100, tile_hint, VLY_TILE_ARGS_RAW);
+            {
+                const int rc = t == 197 ? launch_p4<256, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st)
+                                        : launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+                // 1: bf16 rows that are not 16-byte aligned, or bf16 + residual -> the LDS / fragment epilogues of tile 97 / 98
+                return rc == 1 ? run_tile(t - 100, tile_hint, VLY_TILE_ARGS_RAW) : rc;
+            }
         case 97:
         case 98:                                            // 224 x 256 (M = 2688 = 12 x 224), 112 x 128 per wave
             if (t == 97) return launch_tile<256, 256, 128, 128, 8>(VLY_TILE_ARGS);
@@ -1233,6 +1630,7 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
     }
 #endif
 #undef VLY_TILE_ARGS
+#undef VLY_TILE_ARGS_RAW
 }
 
 extern "C" int vly_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C,
