@@ -224,9 +224,13 @@ VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char*
 // does: ISA of the first version had nine ds_reads + lgkmcnt(0) ahead of the first MFMA of each phase).  One wave per
 // SIMD: nothing else hides a gap in this wave's MFMA stream.
 // f1(k), k < N1, goes after MFMA number S1 + k * D1 (row-major over the MI x NI MFMAs); f2 / f3 likewise
-template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3>
-VLY_DEVICE void phase_4w3(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3) {
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, int N4, int S4, int D4, typename F1,
+          typename F2, typename F3, typename F4>
+VLY_DEVICE void phase_4w4(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3, F4&& f4) {
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N4; ++k)
+        if (S4 + k * D4 < 0) f4(k);                                  // a slot in front of the first MFMA
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -241,6 +245,11 @@ VLY_DEVICE void phase_4w3(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf
             if (N3 > 0 && t >= S3 && (t - S3) % D3 == 0 && (t - S3) / D3 < N3) {
                 __builtin_amdgcn_sched_barrier(0);
                 f3((t - S3) / D3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (N4 > 0 && t >= S4 && (t - S4) % D4 == 0 && (t - S4) / D4 < N4) {
+                __builtin_amdgcn_sched_barrier(0);
+                f4((t - S4) / D4);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (N2 > 0 && t >= S2 && (t - S2) % D2 == 0 && (t - S2) / D2 < N2) {
@@ -259,12 +268,19 @@ VLY_DEVICE void phase_4w3(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf
         if (S3 + k * D3 >= MI * NI) f3(k);
 #pragma unroll
     for (int k = 0; k < N2; ++k)
-        if (S2 + k * D2 >= MI * NI) f2(k);
+        if (S2 + k * D2 >= MI * NI) {
+            if (k < N4 && S4 + k * D4 >= MI * NI) f4(k);
+            f2(k);
+        }
     __builtin_amdgcn_sched_barrier(0);
+}
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3>
+VLY_DEVICE void phase_4w3(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3) {
+    phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, N3, S3, D3, 0, 0, 1>(acc, af, wf, f1, f2, f3, [](int) {});
 }
 template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, typename F1, typename F2>
 VLY_DEVICE void phase_4w(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2) {
-    phase_4w3<MI, NI, N1, S1, D1, N2, S2, D2, 0, 0, 1>(acc, af, wf, f1, f2, [](int) {});
+    phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, 0, 0, 1, 0, 0, 1>(acc, af, wf, f1, f2, [](int) {}, [](int) {});
 }
 
 // arguments of the VLY_EPI_QKV_ROPE epilogue (kernel argument by value; unused by every other instantiation)
@@ -1207,6 +1223,12 @@ VLY_DEVICE f32x4 acc_read(const f32x4& a) {
 // vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads return in order,
 // so an older load (the K tile this barrier publishes) cannot be outstanding unless the N1 younger ones are — whatever the
 // stores issued in between do; they only make the wait conservative.
+#ifndef VLY_P4_DBG
+#define VLY_P4_DBG 0        // timing experiments only (WRONG results): 1 = no vmcnt wait before barrier B, 2 = no barrier A, 4 = no barrier B
+#endif
+#ifndef VLY_P4_M0_LEAD
+#define VLY_P4_M0_LEAD 2     // the M0 write of a piece sits this many MFMAs before its buffer_load
+#endif
 template <int BM, int BN, int EPI, int OUT>
 __global__ void __launch_bounds__(256)
 gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
@@ -1257,10 +1279,22 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         }
     };
     int lt = (int)blockIdx.x, lk = 0;                                // tile / K tile the load cursor points at
-    auto piece = [&](int buf, int q) {
-        char* st = smem + buf * STAGE;
-        if (q < PA) bglds16<VLY_A_CPOL>(rsA, voA[q < PA ? q : 0], (uint32_t)lk * (BK * 2u), st + (q * NT + wave * 64) * 16);
-        else bglds16<VLY_W_CPOL>(rsW, voW[q >= PA ? q - PA : 0], (uint32_t)lk * wk * 2u, st + A_BYTES + ((q - PA) * NT + wave * 64) * 16);
+    // A piece = M0 (its LDS destination) + one buffer_load ... lds.  Written as two asm statements so that the M0 write
+    // can sit in an EARLIER MFMA gap than the load (a 16x16x32 MFMA hides ~3 other issue slots; the builtin form puts
+    // s_add m0 + s_nop + buffer_load into one gap).  Nothing else in this kernel touches M0 between the two.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * 1024u;
+    auto piece_m0 = [&](int buf, int q) {
+        const uint32_t dst = lds0 + (uint32_t)buf * STAGE + (q < PA ? (uint32_t)q * (NT * 16) : (uint32_t)A_BYTES + (uint32_t)(q - PA) * (NT * 16));
+        asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
+    };
+    auto piece_ld = [&](int q) {
+        if (q < PA) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voA[q < PA ? q : 0]), "s"(rsA), "s"((uint32_t)lk * (BK * 2u)) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voW[q >= PA ? q - PA : 0]), "s"(rsW), "s"((uint32_t)lk * wk * 2u) : "memory");
+    };
+    auto piece = [&](int buf, int q) {                               // both at once (prologue, dead waves)
+        piece_m0(buf, q);
+        asm volatile("s_nop 0" ::: "memory");
+        piece_ld(q);
     };
     auto advance_load = [&]() {                                      // past the last tile: stay on its last K tile
         if (lk + 1 < nk) { ++lk; return; }
@@ -1293,9 +1327,11 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             else a0[k >= NI ? k - NI : 0] = *(const bf16x8*)(st + rdA + (k - NI) * 2048 + sw0);
         };
     };
+    // the BUILTIN waitcnt (0xc07f = lgkmcnt(0)): unlike an asm statement the compiler's own wait insertion sees it, and drops
+    // the ten-odd "lgkmcnt(14)" it otherwise puts in front of the MFMA rows of a phase (each one an issue slot of the wave)
     auto bar_a = [](int) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (!(VLY_P4_DBG & 2)) __builtin_amdgcn_s_barrier();
     };
 
     // ---- prologue: the first two K tiles of the stream
@@ -1324,19 +1360,20 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             const char* cur = smem + buf * STAGE;
             const char* nxt = smem + (buf ^ 1) * STAGE;
             // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
+            __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago
             if (wave_live)
-                phase_4w3<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1>(
-                    acc, a0, w0, rd_step1(cur), [&](int q) { piece(buf, q); }, bar_a);
+                phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - VLY_P4_M0_LEAD, GL_STRIDE>(
+                    acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
             else {
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
                 for (int q = 0; q < N1; ++q) piece(buf, q);
             }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(VLY_P4_DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
+            if (!(VLY_P4_DBG & 4)) __builtin_amdgcn_s_barrier();
             if (wave_live)
-                phase_4w<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE>(
-                    acc, a1, w1, rd_step0(nxt), [&](int q) { piece(buf, N1 + q); });
+                phase_4w4<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE, 0, 0, 1, N2, GL2_START - VLY_P4_M0_LEAD, GL_STRIDE>(
+                    acc, a1, w1, rd_step0(nxt), [&](int q) { piece_ld(N1 + q); }, [](int) {}, [&](int q) { piece_m0(buf, N1 + q); });
             else {
 #pragma unroll
                 for (int q = 0; q < N2; ++q) piece(buf, N1 + q);
@@ -1568,6 +1605,7 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 98: return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
         case 197: return launch_p4<256, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
         case 198: return launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+        case 199: return launch_p4<192, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
         default: vly_set_error("vly_gemm_bf16: tile_hint %d is not in this VLY_FEW_TILES build", tile_hint); return -22;
     }
 #else
@@ -1606,18 +1644,22 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         // 4 waves x (128 x 128): a quarter of the 16-wave tile's LDS fragment traffic (PIPE 8 comment)
         case 197:                                           // persistent: one workgroup per CU walks the tiles (gemm_p4_kernel)
         case 198:
+        case 199:
             if (C2 || rope) { vly_set_error("vly_gemm_bf16: tile_hint %d does not take the split-K pair / RoPE epilogue", tile_hint); return -22; }
             if (K < 2 * BK) return run_tile(t - 100, tile_hint, VLY_TILE_ARGS_RAW);
             {
                 const int rc = t == 197 ? launch_p4<256, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st)
-                                        : launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+                               : t == 198 ? launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st)
+                                          : launch_p4<192, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
                 // 1: bf16 rows that are not 16-byte aligned, or bf16 + residual -> the LDS / fragment epilogues of tile 97 / 98
                 return rc == 1 ? run_tile(t - 100, tile_hint, VLY_TILE_ARGS_RAW) : rc;
             }
         case 97:
         case 98:                                            // 224 x 256 (M = 2688 = 12 x 224), 112 x 128 per wave
+        case 99:                                            // 192 x 256 (M = 2688 = 14 x 192; 2688 x 27648: 1512 tiles = 5.9 rounds of 0.75)
             if (t == 97) return launch_tile<256, 256, 128, 128, 8>(VLY_TILE_ARGS);
-            return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
+            if (t == 98) return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
+            return launch_tile<192, 256, 96, 128, 8>(VLY_TILE_ARGS);
         case 51: return launch_tile<256, 256, 128, 64, 4>(VLY_TILE_ARGS);
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);

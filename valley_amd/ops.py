@@ -26,8 +26,9 @@ TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 6
               8: "192, 128, 96, 32", 9: "256, 256, 64, 64"}
 TILE_SPECIAL = {93: ("256, 128, 64, 32", 6), 94: ("128, 256, 32, 64", 6),       # 16-wave 3-stage variants
                 95: ("224, 256, 112, 64", 0), 96: ("224, 256, 112, 64", 4),     # 224-row tiles (M = 2688 = 12 x 224)
-                97: ("256, 256, 128, 128", 8), 98: ("224, 256, 112, 128", 8),   # 4 waves x (128 | 112) x 128
-                197: ("p4 256, 256", 8), 198: ("p4 224, 256", 8)}               # ... persistent (gemm_p4_kernel)
+                97: ("256, 256, 128, 128", 8), 98: ("224, 256, 112, 128", 8),   # 4 waves x (128 | 112 | 96) x 128
+                99: ("192, 256, 96, 128", 8),
+                197: ("p4 256, 256", 8), 198: ("p4 224, 256", 8), 199: ("p4 192, 256", 8)}   # ... persistent (gemm_p4_kernel)
 
 
 def set_recorder(rec):
@@ -117,10 +118,10 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
         e1.record()
         if sk:
             name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}, {sk_loop}>"
-        elif tile in (197, 198) and K >= 128 and (od == OUT_F32 or (residual is None and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0)):
+        elif tile in (197, 198, 199) and K >= 128 and (od == OUT_F32 or (residual is None and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0)):
             name = f"gemm_p4_kernel<{TILE_SPECIAL[tile][0][3:]}, {epilogue}, {od}>"
         elif tile in TILE_SPECIAL:
-            name = f"gemm_kernel<{TILE_SPECIAL[tile - 100 if tile in (197, 198) else tile][0]}, {epilogue}, {od}, {TILE_SPECIAL[tile][1]}>"
+            name = f"gemm_kernel<{TILE_SPECIAL[tile - 100 if tile in (197, 198, 199) else tile][0]}, {epilogue}, {od}, {TILE_SPECIAL[tile][1]}>"
         else:
             name = f"gemm_kernel<{TILE_NAMES[tile % 10]}, {epilogue}, {od}, {({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[tile // 10]}>"
         rec.append((name, 2.0 * M * N * K, e0, e1, (M, N, K, epilogue)))
@@ -369,7 +370,7 @@ def _flush_caches(device):
     buf.zero_()
 
 
-CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94, 95, 96, 97, 98, 197, 198)] + \
+CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94, 95, 96, 97, 98, 99, 197, 198, 199)] + \
              [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 TUNE_FINALISTS = 4   # after TUNE_TRIALS calls per candidate the best few are re-timed to 3 x TUNE_TRIALS calls each
