@@ -69,7 +69,12 @@ const char *vly_last_error(void);
  *   pipelines (the two waves of a SIMD run one phase apart; +50 keeps whole-K-tile staging with 128-byte LDS
  *   rows); +70 (tiles 3, 4, 6: stage <= 53 KB) THREE whole-K-tile stages, i.e. two K tiles of glds loads in
  *   flight (LDS-DMA issue -> landed is ~2600 clk, more than one K tile of MFMA work on these tiles); +80 =
- *   +70 with the role split of +50; 93 / 94 = 256x128 / 128x256 with 16 waves and three stages.
+ *   +70 with the role split of +50; 93 / 94 = 256x128 / 128x256 with 16 waves and three stages; 95 / 96 = 224x256
+ *   (8 waves; 2-stage / role split).  97 / 98 / 99 = 256x256 / 224x256 / 192x256 with FOUR waves (one per SIMD,
+ *   a (BM/2) x 128 accumulator block each, 512 registers per lane; DESIGN.md "the 4-wave kernels"); 197 / 198 / 199 =
+ *   the same tiles in the PERSISTENT kernel (one workgroup per CU walks the tiles, register-only epilogue; bf16
+ *   outputs whose rows are not 16-byte aligned, bf16 + residual and K < 128 fall back to 97 / 98 / 99; not for the
+ *   split-K pair or the RoPE epilogue).
  *   ldw = VLY_LDW_PACKED64: W points to the block layout written by vly_pack_weight_bf16 (not with the +10 / +30
  *   half-tile loops). */
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
