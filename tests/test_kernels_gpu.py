@@ -667,7 +667,7 @@ def test_gemm_skinny(M, N, K, epi):
         ops.gemm_skinny(rnd((300, K), 1, dtype=torch.bfloat16).to(d), w)     # M > 256 is not this kernel's job
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 8, 9, 51, 53, 54, 55, 73, 74, 83, 84, 93, 94, 95, 96, 97, 98, 99])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 8, 9, 51, 53, 54, 55, 73, 74, 83, 84, 93, 94, 95, 96, 97, 98, 99, 197, 198, 199])
 @pytest.mark.parametrize("B,S,heads,past", [(2, 75, 2, 0), (1, 336, 3, 0), (3, 40, 2, 100)])
 def test_gemm_qkv_rope_fused_bit_identical(tile, B, S, heads, past):
     """vly_gemm_bf16_qkv_rope (RoPE + KV append in the q|k|v GEMM epilogue) vs vly_gemm_bf16 followed by vly_rope_kv:

@@ -1233,7 +1233,7 @@ template <int BM, int BN, int EPI, int OUT>
 __global__ void __launch_bounds__(256)
 gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
                const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
-               int tiles_m, int tiles_n, int gm, int vec_ok) {
+               int tiles_m, int tiles_n, int gm, int vec_ok, RopeArgs rp) {
     constexpr int WM = BM / 2, WN = BN / 2, NT = 256;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -1387,7 +1387,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             {
                 const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
                 f32x4 bv[NI];                                        // the bias of this lane's 4 columns per block: once per tile
-                if constexpr (EPI != VLY_EPI_SWIGLU) {
+                if constexpr (EPI != VLY_EPI_SWIGLU && EPI != VLY_EPI_QKV_ROPE) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         const int n = cn0 + wn0 + j * 16 + g * 4;
@@ -1400,7 +1400,46 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                     __builtin_amdgcn_sched_barrier(0);               // row by row: keeps the accumulator reads from piling up
                     const int m = cm0 + wm0 + i * 16 + l15;
                     uint16_t* crow = (uint16_t*)Cv + (size_t)min(m, M - 1) * ldc;
-                    if constexpr (EPI == VLY_EPI_SWIGLU) {
+                    if constexpr (EPI == VLY_EPI_QKV_ROPE) {
+                        // RoPE + KV append on registers: a wave's 128 columns are ONE head (cn0 + wn0 is a multiple of 128),
+                        // the rotation partner of column c < 64 is c + 64 = block j + 4 of the SAME lane.  Same arithmetic
+                        // on the same bf16-rounded projections as rope_kv_kernel -> identical bits (tests compare them).
+                        static_assert(NI == 8, "one head per wave");
+                        const int nb = cn0 + wn0, Hq = rp.heads * 128, sect = nb / Hq, head = (nb - sect * Hq) >> 7;   // wave-uniform
+                        const int mc = min(m, M - 1), bq = mc / rp.S, pos = rp.past + (mc - bq * rp.S);
+                        u32x2 pk[NI];
+#pragma unroll
+                        for (int jl = 0; jl < 4; ++jl) {
+                            const f32x4 lo = acc_read(acc[i][jl]), hi = acc_read(acc[i][jl + 4]);
+                            const uint32_t l0 = pack_bf16x2(lo[0], lo[1]), l1 = pack_bf16x2(lo[2], lo[3]);
+                            const uint32_t h0 = pack_bf16x2(hi[0], hi[1]), h1 = pack_bf16x2(hi[2], hi[3]);
+                            if (sect < 2) {
+                                const f32x4 c = *(const f32x4*)(rp.cos_t + (size_t)pos * 64 + jl * 16 + g * 4);
+                                const f32x4 sn = *(const f32x4*)(rp.sin_t + (size_t)pos * 64 + jl * 16 + g * 4);
+                                const float xl[4] = {__uint_as_float(l0 << 16), __uint_as_float(l0 & 0xffff0000u), __uint_as_float(l1 << 16),
+                                                     __uint_as_float(l1 & 0xffff0000u)};
+                                const float xh[4] = {__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 << 16),
+                                                     __uint_as_float(h1 & 0xffff0000u)};
+                                pk[jl][0] = pack_bf16x2(rope_rot(xl[0], xh[0], c[0], sn[0], -1.f), rope_rot(xl[1], xh[1], c[1], sn[1], -1.f));
+                                pk[jl][1] = pack_bf16x2(rope_rot(xl[2], xh[2], c[2], sn[2], -1.f), rope_rot(xl[3], xh[3], c[3], sn[3], -1.f));
+                                pk[jl + 4][0] = pack_bf16x2(rope_rot(xh[0], xl[0], c[0], sn[0], 1.f), rope_rot(xh[1], xl[1], c[1], sn[1], 1.f));
+                                pk[jl + 4][1] = pack_bf16x2(rope_rot(xh[2], xl[2], c[2], sn[2], 1.f), rope_rot(xh[3], xl[3], c[3], sn[3], 1.f));
+                            } else {
+                                pk[jl] = u32x2{l0, l1};
+                                pk[jl + 4] = u32x2{h0, h1};
+                            }
+                        }
+                        uint16_t* drow = sect == 0 ? crow + nb
+                                                   : (sect == 1 ? rp.kc : rp.vc) + (((size_t)bq * rp.heads + head) * rp.ctx_max + pos) * 128;
+#pragma unroll
+                        for (int jp = 0; jp < NI / 2; ++jp) {
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
+                            const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                            const int dd = (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
+                            if (m < M && nb < N) *(u32x4*)(drow + dd) = o;
+                        }
+                    } else if constexpr (EPI == VLY_EPI_SWIGLU) {
 #pragma unroll
                         for (int jq = 0; jq < NI / 4; ++jq) {
                             uint32_t d[4];
@@ -1494,7 +1533,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 
 template <int BM, int BN>
 int launch_p4(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw,
-              int ldc, int ldr, int epi, int out, hipStream_t st) {
+              int ldc, int ldr, int epi, int out, hipStream_t st, const RopeArgs* rope = nullptr) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, 1);
     const int vec_ok = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !R) ? 1 : 0;
@@ -1510,12 +1549,13 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
     dim3 grid(tiles < cus ? tiles : cus), block(256);
 #define VLY_P4_LAUNCH(E, O)                                                                                                  \
     hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
-                       K, lda, ldw, ldc, ldr, tm, tn, gm, vec_ok)
+                       K, lda, ldw, ldc, ldr, tm, tn, gm, vec_ok, rope ? *rope : RopeArgs{})
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_SWIGLU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_RELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_RELU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_QKV_ROPE && out == VLY_OUT_BF16 && rope) VLY_P4_LAUNCH(VLY_EPI_QKV_ROPE, VLY_OUT_BF16);
     else {
         vly_set_error("vly_gemm_bf16: unsupported epilogue/out_dtype combination (%d,%d) for the persistent tiles", epi, out);
         return -22;
@@ -1645,12 +1685,12 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 197:                                           // persistent: one workgroup per CU walks the tiles (gemm_p4_kernel)
         case 198:
         case 199:
-            if (C2 || rope) { vly_set_error("vly_gemm_bf16: tile_hint %d does not take the split-K pair / RoPE epilogue", tile_hint); return -22; }
+            if (C2) { vly_set_error("vly_gemm_bf16: tile_hint %d does not take the split-K pair", tile_hint); return -22; }
             if (K < 2 * BK) return run_tile(t - 100, tile_hint, VLY_TILE_ARGS_RAW);
             {
-                const int rc = t == 197 ? launch_p4<256, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st)
-                               : t == 198 ? launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st)
-                                          : launch_p4<192, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+                const int rc = t == 197 ? launch_p4<256, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, rope)
+                               : t == 198 ? launch_p4<224, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, rope)
+                                          : launch_p4<192, 256>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, rope);
                 // 1: bf16 rows that are not 16-byte aligned, or bf16 + residual -> the LDS / fragment epilogues of tile 97 / 98
                 return rc == 1 ? run_tile(t - 100, tile_hint, VLY_TILE_ARGS_RAW) : rc;
             }

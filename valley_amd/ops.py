@@ -272,12 +272,15 @@ def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
         t = tile_hint or L.vly_gemm_tile_for(M, N)
         nm = TILE_SPECIAL[t][0] if t in TILE_SPECIAL else TILE_NAMES[t % 10]
         loop = TILE_SPECIAL[t][1] if t in TILE_SPECIAL else ({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[t // 10]
-        rec.append((f"gemm_kernel<{nm}, 4, 0, {loop}>", 2.0 * M * N * K, e0, e1, (M, N, K, EPI_QKV_ROPE)))
+        name = f"gemm_p4_kernel<{nm[3:]}, 4, 0>" if t in (197, 198, 199) else f"gemm_kernel<{nm}, 4, 0, {loop}>"
+        rec.append((name, 2.0 * M * N * K, e0, e1, (M, N, K, EPI_QKV_ROPE)))
     _lib.check(rc, "vly_gemm_bf16_qkv_rope")
     return qkv
 
 
-# Off by default: measured neutral (c3, same box, profiles/r02/r02_ab_rowsplit_rope.txt: q|k|v 355.7 us + rope_kv 27 us vs
+# Off by default: measured neutral twice — on the persistent 4-wave tiles (register epilogue: the rotation partner of a column is
+# in the same lane) q|k|v 304.8 us + rope_kv 27 us vs 327.3 us fused, c3 1652 -> 1656 frames/s; earlier on the LDS epilogue
+# (c3, same box, profiles/r02/r02_ab_rowsplit_rope.txt: q|k|v 355.7 us + rope_kv 27 us vs
 # 373.5 us fused, but the step moved 87.75 -> 88.22 ms, inside the noise) — the epilogue's 16 dependent cos / sin fetches
 # per thread cost what the removed pass over q|k|v saved.  Kept as a tested option (bit-identical to the unfused pair).
 FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "0") == "1"
