@@ -13,6 +13,10 @@
 //     up holding 4 consecutive n for one m: bias/residual are float4 loads and C is written as
 //     8-byte (bf16) or 16-byte (fp32) pieces along the row;
 //   * block id -> tile mapping gives each XCD (private 4 MiB L2) a contiguous run of tiles.
+// Two kernels live here: gemm_kernel (one tile per workgroup; 4 / 8 / 16 waves, the K-loop variants PIPE 0..8) and
+// gemm_p4_kernel (tile hints 197-199, the hot path's choice): ONE workgroup per CU walks its tiles, one wave per SIMD
+// with a (BM/2) x 128 accumulator block, software-pipelined fragment reads and LDS-DMA pieces across K-tile AND tile
+// boundaries, epilogue on registers only — see the comments at PIPE 8 and at gemm_p4_kernel, and DESIGN.md §4.
 // Algorithmic work: 2*M*N*K flop per launch; HBM traffic floor (M*K + N*K)*2 + M*N*out bytes.
 #include <cmath>
 #include <cstdlib>
