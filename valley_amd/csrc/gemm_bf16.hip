@@ -186,10 +186,10 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 #else
 #define VLY_SWZ_KEY(row) (row & 7)
 #endif
-#if VLY_MFMA32
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
 VLY_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+#if VLY_MFMA32
 
 // One K tile of a wave's MI2 x NI2 blocks of 32x32; sw[s] = swizzled byte offset of K step s inside a 128-byte row.
 // Step s+1's fragments are requested between step s's MFMAs (as in mma_ktile).
@@ -229,8 +229,8 @@ VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char*
 // SIMD: nothing else hides a gap in this wave's MFMA stream.
 // f1(k), k < N1, goes after MFMA number S1 + k * D1 (row-major over the MI x NI MFMAs); f2 / f3 likewise
 template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, int N4, int S4, int D4, typename F1,
-          typename F2, typename F3, typename F4>
-VLY_DEVICE void phase_4w4(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3, F4&& f4) {
+          typename F2, typename F3, typename F4, typename ACC>
+VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3, F4&& f4) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < N4; ++k)
@@ -239,7 +239,15 @@ VLY_DEVICE void phase_4w4(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            if constexpr (sizeof(acc[0][0]) == sizeof(f32x16)) {
+                // timing experiment only (WRONG results): half as many 32x32x16 MFMAs fed from the same fragment registers
+                if (j == 1) acc[i][0] = mfma32(wf[0], af[i], acc[i][0]);
+                if (j == 3) acc[i][1] = mfma32(wf[1], wf[2], acc[i][1]);
+                if (j == 5) acc[i][0] = mfma32(wf[3], wf[4], acc[i][0]);
+                if (j == 7) acc[i][1] = mfma32(wf[5], wf[6], acc[i][1]);
+            } else {
+                acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            }
             const int t = i * NI + j;
             if (N1 > 0 && t >= S1 && (t - S1) % D1 == 0 && (t - S1) / D1 < N1) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -278,12 +286,12 @@ VLY_DEVICE void phase_4w4(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf
         }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3>
-VLY_DEVICE void phase_4w3(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3) {
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3, typename ACC>
+VLY_DEVICE void phase_4w3(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3) {
     phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, N3, S3, D3, 0, 0, 1>(acc, af, wf, f1, f2, f3, [](int) {});
 }
-template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, typename F1, typename F2>
-VLY_DEVICE void phase_4w(f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2) {
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, typename F1, typename F2, typename ACC>
+VLY_DEVICE void phase_4w(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2) {
     phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, 0, 0, 1, 0, 0, 1>(acc, af, wf, f1, f2, [](int) {}, [](int) {});
 }
 
@@ -1227,11 +1235,22 @@ VLY_DEVICE f32x4 acc_read(const f32x4& a) {
 // vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads return in order,
 // so an older load (the K tile this barrier publishes) cannot be outstanding unless the N1 younger ones are — whatever the
 // stores issued in between do; they only make the wait conservative.
+#ifndef VLY_P4_TIMING
+#define VLY_P4_TIMING 0     // timing experiments only (WRONG results): 1 = no epilogue (a sink keeps the accumulators alive), 2 = 1 + 32x32x16 MFMAs, 3 = epilogue math without its stores, 4 = stores without the math (plain / gelu epilogues)
+#endif
 #ifndef VLY_P4_DBG
 #define VLY_P4_DBG 0        // timing experiments only (WRONG results): 1 = no vmcnt wait before barrier B, 2 = no barrier A, 4 = no barrier B
 #endif
 #ifndef VLY_P4_M0_LEAD
 #define VLY_P4_M0_LEAD 2     // the M0 write of a piece sits this many MFMAs before its buffer_load
+#endif
+#ifndef VLY_P4_NT_STORES
+#define VLY_P4_NT_STORES 0
+#endif
+#if VLY_P4_NT_STORES
+#define VLY_P4_STORE16(ptr, val) __builtin_nontemporal_store(val, (u32x4*)(ptr))
+#else
+#define VLY_P4_STORE16(ptr, val) (*(u32x4*)(ptr) = (val))
 #endif
 template <int BM, int BN, int EPI, int OUT>
 __global__ void __launch_bounds__(256)
@@ -1318,7 +1337,11 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
     const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
     bf16x8 a0[MI], w0[NI], a1[MI], w1[NI];
+#if VLY_P4_TIMING == 2
+    f32x16 acc[MI][2];
+#else
     f32x4 acc[MI][NI];
+#endif
     auto rd_step1 = [&](const char* st) {
         return [&, st](int k) {
             if (k < NI) w1[k < NI ? k : 0] = *(const bf16x8*)(st + rdW + k * 2048 + sw1);
@@ -1355,10 +1378,19 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     int buf = 0;                                                     // buffer of the K tile being computed
     for (;;) {
         const bool wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
+#if VLY_P4_TIMING == 2
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         int kt = 0;
         do {
             const char* cur = smem + buf * STAGE;
@@ -1385,6 +1417,18 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             advance_load();
             buf ^= 1;
         } while (++kt < nk);
+#if VLY_P4_TIMING == 1 || VLY_P4_TIMING == 2
+        {
+            float sink = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < (VLY_P4_TIMING == 2 ? 2 : NI); ++j)
+#pragma unroll
+                    for (int r = 0; r < (VLY_P4_TIMING == 2 ? 16 : 4); ++r) asm volatile("" ::"a"(acc[i][j][r]));   // alive, no code
+            (void)sink;
+        }
+#else
         // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
         // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
         if constexpr (OUT == VLY_OUT_BF16) {                           // the launcher guarantees 16-byte aligned rows, no residual
@@ -1459,7 +1503,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                             const u32x4 o = u32x4{q0[0], q1[0], q0[1], q1[1]};
                             const int no = ((cn0 + wn0) >> 1) + (4 * jq + g) * 8;
                             if (m < M) {
-                                if (no + 8 <= No) *(u32x4*)(crow + no) = o;
+                                if (no + 8 <= No) VLY_P4_STORE16(crow + no, o);
                                 else if (no + 4 <= No) *(u32x2*)(crow + no) = u32x2{o[0], o[1]};
                             }
                         }
@@ -1483,12 +1527,20 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                             }
                             const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                             const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+#if VLY_P4_TIMING == 4                                  /* stores without the math in front of them */
+                            const u32x4 o = __builtin_bit_cast(u32x4, acc_read(acc[i][2 * jp]));
+#else
                             const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+#endif
                             const int n = cn0 + wn0 + (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
+#if VLY_P4_TIMING == 3                                  /* the math without the stores */
+                            asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(n));
+#else
                             if (m < M) {
-                                if (n + 8 <= N) *(u32x4*)(crow + n) = o;
+                                if (n + 8 <= N) VLY_P4_STORE16(crow + n, o);
                                 else if (n + 4 <= N) *(u32x2*)(crow + n) = u32x2{o[0], o[1]};
                             }
+#endif
                         }
                     }
                 }
@@ -1523,6 +1575,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 }
             }
         }
+#endif
         if (ct + G >= ntiles) break;
         ct += G;
         tile_origin(ct, cm0, cn0);
