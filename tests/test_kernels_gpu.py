@@ -712,3 +712,27 @@ def test_gemm_qkv_rope_rejects_narrow_tiles_and_falls_back():
     k2 = torch.zeros_like(kc)
     ops.rope_kv(ref, k2, torch.zeros_like(kc), cos, sin, B, S, heads, 0)
     assert torch.equal(qkv[:, :heads * 128], ref[:, :heads * 128]) and torch.equal(kc, k2)
+
+
+@pytest.mark.parametrize("tile", [197, 198, 199])
+def test_gemm_persistent_many_tiles_bit_identical_to_tile9(tile):
+    """The persistent 4-wave kernel on a problem with MORE tiles than workgroups (several tiles per workgroup, a partial
+    last round, ragged last tile row and column, dead waves): same MFMA, same K order as the 16-wave tile -> identical bits,
+    for every epilogue, bf16 and fp32 outputs, fp32 residual, row-major and block-ordered weights."""
+    from valley_amd import ops
+    d = dev()
+    M, N, K = 4100, 4360, 320                                   # 17 x 18 tiles of 256 x 256 = 306 > 256 workgroups
+    a = rnd((M, K), 201, dtype=torch.bfloat16).to(d)
+    w = rnd((N, K), 202, 0.05, dtype=torch.bfloat16).to(d)
+    bias = rnd((N,), 203, 0.5).to(d)
+    res = rnd((M, N), 204).to(d)
+    for wt in (w, ops.PackedWeight(w)):
+        for kw in (dict(), dict(bias=bias), dict(bias=bias, epilogue=ops.EPI_QUICK_GELU), dict(epilogue=ops.EPI_SWIGLU),
+                   dict(bias=bias, epilogue=ops.EPI_RELU), dict(out_dtype=torch.float32), dict(bias=bias, residual=res, out_dtype=torch.float32)):
+            got = ops.gemm_mfma(a, wt, tile_hint=tile, **kw)
+            ref = ops.gemm_mfma(a, wt, tile_hint=9, **kw)
+            assert torch.equal(got, ref), (tile, sorted(kw))
+    # an output view whose rows are not 16-byte aligned falls back to the one-tile-per-workgroup kernel: same values
+    out = torch.full((M, N + 2), 7.0, dtype=torch.bfloat16, device=d)
+    ops.gemm_mfma(a, w, bias, out=out[:, :N], tile_hint=tile)
+    assert torch.equal(out[:, :N], ops.gemm_mfma(a, w, bias, tile_hint=9)) and float((out[:, N:].float() - 7.0).abs().max()) == 0.0
