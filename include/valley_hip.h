@@ -126,7 +126,8 @@ int    vly_gemm_bf16_streamk(const void *A, const void *W, const float *bias, co
 size_t vly_gemm_streamk_workspace_bytes(void);
 int    vly_gemm_streamk_tile_for(int M, int N, int K);
 
-/* The tile configuration vly_gemm_bf16 picks for (M,N) when tile_hint == 0 (1/2/3 as above); lets a
+/* The tile configuration vly_gemm_bf16 picks for (M,N) when tile_hint == 0 (1/2/3 as above, 197 when the
+ * problem has at least 192 tiles of 256x256); lets a
  *   caller label launches when it profiles (bench.py's per-kernel roofline). */
 int vly_gemm_tile_for(int M, int N);
 

@@ -1670,6 +1670,9 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
 // tiles to fill 256 CUs; 128x128 (4 waves, 2 blocks/CU) quantises better on small problems.
 static int pick_tile(int M, int N) {
     auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    // enough 256 x 256 tiles for (nearly) every CU: the persistent 4-wave kernel — 1.3-1.5 PFLOP/s in its loop against
+    // 0.6-1.2 of the others (same MFMA and K order as every other tile, so the static choice stays bit-identical across batch sizes)
+    if (tiles(256, 256) >= 192) return 197;
     // modelled time = waves-of-blocks * per-tile work / relative efficiency
     auto cost = [&](int bm, int bn, int per_cu, double eff) {
         const long t = tiles(bm, bn);
