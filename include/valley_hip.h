@@ -278,9 +278,10 @@ int vly_incr_i32(int32_t *p, int n, int delta, void *stream);
  *   serve/model_worker.py:389-391. */
 int vly_argmax(const float *x, int32_t *idx, int M, int N, int ld, void *stream);
 
-/* C[M,N] = epi(A[M,K] W[N,K]^T + bias), bf16 out, for FEW rows (M <= 256; N % 32 == 0; K % 128 == 0; epilogue NONE, QUICK_GELU or
+/* C[M,N] = epi(A[M,K] W[N,K]^T + bias), bf16 out, for FEW rows (M <= 256; N % 32 == 0; K % 128 == 0, K % 512 == 0 from
+ *   K = 2048 on; epilogue NONE, QUICK_GELU or
  *   RELU): the latency-optimised form of vly_gemm_bf16 for the F-row remainders of the tall ViT GEMMs — one 32x32 block
- *   of C per workgroup, K split over its four waves, fragments loaded straight from global memory (gemm_skinny.hip).
+ *   of C per workgroup, K split over its four (K >= 2048: sixteen) waves, fragments loaded straight from global memory (gemm_skinny.hip).
  *   Same math as vly_gemm_bf16 up to fp32 summation order. */
 int vly_gemm_skinny_bf16(const void *A_bf16, const void *W_bf16, const float *bias, void *C_bf16, int M, int N, int K,
                          int lda, int ldw, int ldc, int epilogue, void *stream);

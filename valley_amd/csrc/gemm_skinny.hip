@@ -9,6 +9,7 @@
 //   * no LDS staging: A is tiny (L2-resident), W is read exactly once per 32-row block of A, and every lane loads its
 //     MFMA fragment (16 bytes, K-contiguous) straight from global memory, UNROLL K steps of 32 in flight per wave.
 // Algorithmic work 2*M*N*K flop; the kernel is latency-, not throughput-bound by design (a few microseconds).
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -16,15 +17,17 @@ namespace {
 
 constexpr int SK_UNROLL = 4;       // K steps (of 32) whose four fragment loads are issued before the first MFMA of the group
 
-template <int EPI>
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-                                                          const float* __restrict__ bias, uint16_t* __restrict__ C, int M, int N,
-                                                          int K, int lda, int ldw, int ldc) {
-    __shared__ f32x4 red[4][4][64];                        // [wave][fragment][lane]
+// NWV waves split K: 4 for the K = 1024 remainders, 16 (1024 threads) when K >= 2048 — the fc2 remainder 128 x 1024 x 4096 is
+// only 128 workgroups, and with four waves each wave walks 32 dependent steps of ~1 us load latency
+template <int EPI, int NWV>
+__global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int M, int N,
+                                                               int K, int lda, int ldw, int ldc) {
+    __shared__ f32x4 red[NWV][4][64];                      // [wave][fragment][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const int kq = K >> 2, kbeg = wave * kq;               // this wave's quarter of K
+    const int kq = K / NWV, kbeg = wave * kq;              // this wave's share of K
     // fragment row pointers (rows past the edge re-read the last row; masked at the store)
     const uint16_t* a0 = A + (size_t)min(m0 + l15, M - 1) * lda + kbeg + g * 8;
     const uint16_t* a1 = A + (size_t)min(m0 + 16 + l15, M - 1) * lda + kbeg + g * 8;
@@ -56,13 +59,16 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const uint16_t* __rest
             }
         }
     }
-    // ---- four-way K reduction through LDS: wave w sums fragment (i, j) = (w >> 1, w & 1) of all four waves
+    // ---- K reduction through LDS: wave w < 4 sums fragment (i, j) = (w >> 1, w & 1) of all waves
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) red[wave][2 * i + j][lane] = acc[i][j];
     __syncthreads();
-    f32x4 v = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
+    if (wave >= 4) return;
+    f32x4 v = red[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) v += red[w][wave][lane];
     const int m = m0 + (wave >> 1) * 16 + l15, n = n0 + (wave & 1) * 16 + 4 * g;
     if (m >= M) return;
     if (bias) v += *(const f32x4*)(bias + n);
@@ -84,16 +90,24 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const uint16_t* __rest
 
 extern "C" int vly_gemm_skinny_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
                                     int ldc, int epilogue, void* stream) {
-    if (M <= 0 || M > 256 || N <= 0 || N % 32 || K < 128 || K % 128 || lda % 8 || ldw % 8 || ldc % 4 || ((uintptr_t)A & 15) ||
+    if (M <= 0 || M > 256 || N <= 0 || N % 32 || K < 128 || K % 128 || (K >= 2048 && K % 512) || lda % 8 || ldw % 8 || ldc % 4 || ((uintptr_t)A & 15) ||
         ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || (bias && ((uintptr_t)bias & 15))) {
         vly_set_error("vly_gemm_skinny_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
         return -22;
     }
-    dim3 grid(N / 32, (M + 31) / 32), block(256);
+    static const bool narrow_only = getenv("VLY_SKINNY_WAVES") && atoi(getenv("VLY_SKINNY_WAVES")) == 4;   // A/B switch
+    const bool wide = K >= 2048 && !narrow_only;            // 16 waves: kq = K / 16 is a multiple of 32 (K % 512 == 0)
+    dim3 grid(N / 32, (M + 31) / 32), block(wide ? 1024 : 256);
     hipStream_t st = (hipStream_t)stream;
 #define VLY_SKINNY(E)                                                                                                      \
-    hipLaunchKernelGGL((gemm_skinny_kernel<E>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, (uint16_t*)C, M, \
-                       N, K, lda, ldw, ldc)
+    do {                                                                                                                   \
+        if (wide)                                                                                                          \
+            hipLaunchKernelGGL((gemm_skinny_kernel<E, 16>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias,  \
+                               (uint16_t*)C, M, N, K, lda, ldw, ldc);                                                      \
+        else                                                                                                               \
+            hipLaunchKernelGGL((gemm_skinny_kernel<E, 4>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias,   \
+                               (uint16_t*)C, M, N, K, lda, ldw, ldc);                                                      \
+    } while (0)
     switch (epilogue) {
         case VLY_EPI_NONE: VLY_SKINNY(VLY_EPI_NONE); break;
         case VLY_EPI_QUICK_GELU: VLY_SKINNY(VLY_EPI_QUICK_GELU); break;

@@ -203,7 +203,7 @@ def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=to
 
 
 def skinny_ok(M: int, N: int, K: int, epilogue: int, out_dtype, residual) -> bool:
-    return 8 < M <= 256 and N % 32 == 0 and K % 128 == 0 and epilogue in (EPI_NONE, EPI_QUICK_GELU, EPI_RELU) and \
+    return 8 < M <= 256 and N % 32 == 0 and K % 128 == 0 and (K < 2048 or K % 512 == 0) and epilogue in (EPI_NONE, EPI_QUICK_GELU, EPI_RELU) and \
         out_dtype == torch.bfloat16 and residual is None
 
 
