@@ -188,7 +188,7 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 #endif
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
-VLY_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+[[maybe_unused]] VLY_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 #if VLY_MFMA32
 
 // One K tile of a wave's MI2 x NI2 blocks of 32x32; sw[s] = swizzled byte offset of K step s inside a 128-byte row.
