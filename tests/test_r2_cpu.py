@@ -245,3 +245,60 @@ def test_load_video_host_path_is_pillow_exact(shape):
     assert mx(got, ref) < 1e-6
     lv = video.load_video(frames, fixed_frame_number=T)
     assert mx(lv, ref) < 1e-6
+
+
+# ---- round 3: ADVICE r2 ---------------------------------------------------------------------------------------------
+def test_lora_adapter_saved_next_to_the_base_model(tmp_path):
+    """run_valley.py:27-29: a ``config.json`` inside the adapter directory means the base model IS that directory.  The
+    checkpoint reader must then read the MODEL shards only — with peft's default ``adapter_model.safetensors`` next to a
+    ``pytorch_model.bin`` base, and next to a safetensors base."""
+    from safetensors.torch import save_file
+    from valley_amd.checkpoint import _read_shards, merge_lora, read_lora_adapter
+    base, _, dims = delta_states()
+    sd = {k: t(v).clone() for k, v in base.items()}
+    H, r = dims["H"], 2
+    ad = {"base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight": torch.ones(r, H) * 0.01,
+          "base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight": torch.ones(H, r) * 0.01}
+    (tmp_path / "adapter_config.json").write_text(json.dumps(dict(r=r, lora_alpha=4, base_model_name_or_path=str(tmp_path))))
+    (tmp_path / "config.json").write_text("{}")
+    save_file(ad, str(tmp_path / "adapter_model.safetensors"))
+    torch.save(sd, str(tmp_path / "pytorch_model.bin"))
+    got = _read_shards(str(tmp_path))                       # .bin base + safetensors adapter
+    assert set(got) == set(sd)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    got = _read_shards(str(tmp_path))                       # safetensors base + safetensors adapter
+    assert set(got) == set(sd) and not any("lora" in k for k in got)
+    cfg, asd = read_lora_adapter(str(tmp_path))
+    out = merge_lora(got, cfg, asd)
+    k = "model.layers.0.self_attn.q_proj.weight"
+    assert mx(out[k], sd[k] + 2.0 * ad["base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight"]
+              @ ad["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"]) < 1e-6
+
+
+def test_merge_lora_consumes_every_adapter_tensor():
+    """peft strips ``modules_to_save.<adapter>.`` when it saves: a module saved whole arrives under its plain base key and
+    replaces the base tensor; tensors the merge does not understand (lora_embedding_*, DoRA magnitudes) raise."""
+    from valley_amd.checkpoint import merge_lora
+    base, _, dims = delta_states()
+    sd = {k: t(v).clone() for k, v in base.items()}
+    cfg = dict(r=2, lora_alpha=2)
+    new_head = torch.full_like(sd["lm_head.weight"], 0.5)
+    out = merge_lora(sd, cfg, {"base_model.model.lm_head.weight": new_head})
+    assert torch.equal(out["lm_head.weight"], new_head)
+    out = merge_lora(sd, cfg, {"base_model.model.lm_head.modules_to_save.default.weight": new_head})
+    assert torch.equal(out["lm_head.weight"], new_head)
+    with pytest.raises(KeyError, match="does not understand"):
+        merge_lora(sd, cfg, {"base_model.model.model.embed_tokens.lora_embedding_A": torch.zeros(2, 8)})
+    with pytest.raises(KeyError, match="does not understand"):
+        merge_lora(sd, cfg, {"base_model.model.model.layers.0.self_attn.q_proj.lora_magnitude_vector": torch.zeros(4)})
+
+
+def test_make_delta_asserts_like_the_reference():
+    """make_delta.py:28: a shape mismatch is allowed for the two vocabulary-sized matrices only."""
+    from valley_amd.checkpoint import make_delta
+    base, delta, dims = delta_states()
+    b = {k: t(v) for k, v in base.items()}
+    tgt = {k: t(v).clone() for k, v in base.items()}
+    tgt["model.norm.weight"] = torch.zeros(dims["H"] + 1)
+    with pytest.raises(AssertionError, match="model.norm.weight dimension mismatch"):
+        make_delta(b, tgt)

@@ -15,17 +15,23 @@ from typing import Dict, Tuple
 import torch
 
 
+def _model_shards(path: str, pattern: str):
+    """Model shards only: a peft adapter saved into the same directory (run_valley.py:27-29 — a ``config.json`` next to
+    ``adapter_config.json`` means the base model IS that directory) must not be read as model weights."""
+    return sorted(f for f in glob.glob(os.path.join(path, pattern)) if not os.path.basename(f).startswith("adapter_model"))
+
+
 def _read_shards(path: str) -> Dict[str, torch.Tensor]:
     sd: Dict[str, torch.Tensor] = {}
-    st = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    st = _model_shards(path, "*.safetensors")
     if st:
         from safetensors.torch import load_file
         for f in st:
             sd.update(load_file(f, device="cpu"))
         return sd
-    bins = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+    bins = _model_shards(path, "pytorch_model*.bin")
     if not bins:
-        raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {path}")
+        raise FileNotFoundError(f"no model *.safetensors or pytorch_model*.bin under {path}")
     for f in bins:
         sd.update(torch.load(f, map_location="cpu", weights_only=True))
     return sd
@@ -90,7 +96,8 @@ def make_delta(base_sd: Dict[str, torch.Tensor], target_sd: Dict[str, torch.Tens
         q = p.clone()
         if p.shape == b.shape:
             q -= b
-        else:                                            # the reference subtracts the overlapping rows unasserted (:29-31)
+        else:                                            # only the two vocabulary-sized matrices may differ (make_delta.py:28)
+            assert name in RESIZED_OK, f"{name} dimension mismatch: {p.shape} vs {b.shape}"
             q[:b.shape[0], :b.shape[1]] -= b
         out[name] = q
     return out
@@ -131,15 +138,36 @@ def merge_lora(sd: Dict[str, torch.Tensor], adapter_cfg: dict, adapter_sd: Dict[
                 break
         return mod + ".weight"
 
-    pairs = {}
+    def strip(k: str) -> str:
+        for pre in ("base_model.model.", "base_model."):
+            if k.startswith(pre):
+                return k[len(pre):]
+        return k
+
+    pairs, unused = {}, []
     for k, v in adapter_sd.items():
+        hit = False
         for tag in ("lora_A", "lora_B"):
             m = f".{tag}."
             if m in k and k.endswith("weight"):
                 pairs.setdefault(base_key(k, m), {})[tag] = v
-        if ".modules_to_save." in k:                      # e.g. ...embed_tokens.modules_to_save.default.weight
+                hit = True
+        if hit:
+            continue
+        if ".modules_to_save." in k:                      # in-memory key form: ...embed_tokens.modules_to_save.default.weight
             mod = base_key(k, ".modules_to_save.")[:-len(".weight")]
             out[mod + "." + k.rsplit(".", 1)[1]] = v
+        elif strip(k) in out and "lora_" not in k:
+            # peft's get_peft_model_state_dict strips ``modules_to_save.<adapter>.`` when it SAVES, so a module saved whole
+            # arrives as a plain base key (base_model.model.lm_head.weight): a whole-tensor replacement
+            out[strip(k)] = v
+        else:
+            unused.append(k)
+    if unused:
+        # lora_embedding_A/B, DoRA magnitudes, bias terms of an unknown module ...: merging around them would give a
+        # silently wrong model
+        raise KeyError(f"LoRA adapter tensors this merge does not understand: {sorted(unused)[:6]}"
+                       + (f" (+{len(unused) - 6} more)" if len(unused) > 6 else ""))
     for wkey, ab in pairs.items():
         if "lora_A" not in ab or "lora_B" not in ab:
             raise KeyError(f"LoRA adapter holds only one factor for {wkey}")

@@ -26,11 +26,22 @@ VLY_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vly_bf16x2));
 }
 
-// x * sigmoid(a*x) with one v_exp_f32 and one v_rcp_f32 (a full IEEE division costs ~10 VALU instructions,
-// which showed up as 4-5 us of un-overlapped epilogue on the 8224 x 4096 quick_gelu GEMM); 1 ulp, far below
-// the bf16 rounding of the result.  quick_gelu: a = 1.702 (hf activations.py QuickGELU); SiLU: a = 1.
+// x * sigmoid(a*x) = x / (1 + 2^(-a*log2(e)*x)) with one v_exp_f32 and one v_rcp_f32 (a full IEEE division costs ~10 VALU
+// instructions, which showed up as 4-5 us of un-overlapped epilogue on the 8224 x 4096 quick_gelu GEMM); 1 ulp, far below
+// the bf16 rounding of the result.  quick_gelu: a = 1.702 (hf activations.py QuickGELU); SiLU: a = 1.  The scale and
+// log2(e) are ONE constant (round 3: the two multiplies of -a*x and of __expf were 16 of the 75 instructions per 8
+// outputs of the persistent kernel's epilogue).  Every kernel evaluates exactly this expression, scalar or packed.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 VLY_DEVICE float x_sigmoid(float x, float a) {
-    return x * __builtin_amdgcn_rcpf(1.f + __expf(-a * x));
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (-1.4426950408889634f * a)));
+}
+// two values at once: v_pk_mul_f32 / v_pk_add_f32 around the two transcendentals (same bits as the scalar form)
+VLY_DEVICE f32x2 x_sigmoid2(f32x2 x, float a) {
+    const f32x2 t = x * (-1.4426950408889634f * a);
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e += 1.f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return x * r;
 }
 
 // Rotate-half RoPE of one element pair, written ONE way for every kernel that rotates (vly_rope_kv, the fused

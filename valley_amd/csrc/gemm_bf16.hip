@@ -221,6 +221,12 @@ VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char*
 }
 #endif
 
+// placement constants of the 4-wave loops (A/B of other placements: profiles/r02/r02_ab_4wave.txt)
+constexpr int P8_BAR_GAP = 8;       // barrier A this many MFMAs (~140 clk, a ds_read round trip) after the last read of phase 1
+constexpr int P8_RD2_START = 1;     // phase 2: reads of the next tile's K step 0 after MFMA 1, 3, 5, ...
+constexpr int P8_RD2_STRIDE = 2;
+constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MFMAs before its buffer_load
+
 // One phase of the 4-wave loop (PIPE 8): the MI x NI MFMAs of one 32-wide K step on fragments that are already in
 // registers, with up to three lists of other instructions (the NI + MI fragment reads of the NEXT step — W fragments
 // first, then A, the order the next phase consumes them —, the LDS-DMA pieces of a later K tile, a barrier) placed at fixed
@@ -684,16 +690,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         // slot arithmetic (T = MFMAs per phase): reads of phase 1 after MFMA 0 .. MI+NI-1, barrier A eight MFMAs (~140 clk, a
         // ds_read round trip) later, then one piece every STRIDE MFMAs until the end of phase 2.  256 x 256: barrier after
         // MFMA 24, 7 pieces after 26, 32 .. 62, 9 after 4, 10 .. 52 of phase 2; A/B of other placements: r02_ab_4wave.txt
-#ifndef VLY_P8_BAR_GAP
-#define VLY_P8_BAR_GAP 8
-#endif
-#ifndef VLY_P8_RD2_START
-#define VLY_P8_RD2_START 1       // phase 2: reads of the next tile's K step 0 after MFMA 1, 3, 5, ...
-#endif
-#ifndef VLY_P8_RD2_STRIDE
-#define VLY_P8_RD2_STRIDE 2
-#endif
-        constexpr int T = MI * NI, BAR_AT = MI + NI + VLY_P8_BAR_GAP, GL1_START = BAR_AT + 2;
+        constexpr int T = MI * NI, BAR_AT = MI + NI + P8_BAR_GAP, GL1_START = BAR_AT + 2;
         static_assert(GL1_START < T, "phase too short for the early release");
         constexpr int NS = PA + PW;
         constexpr int GL_STRIDE = (2 * T - GL1_START) / NS;                          // 102 / 16 = 6
@@ -774,7 +771,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
             __builtin_amdgcn_s_barrier();
             if (wave_live)
-                phase_4w<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE>(
+                phase_4w<MI, NI, MI + NI, P8_RD2_START, P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE>(
                     acc, a1, w1, rd_step0(nxt), [&](int q) { piece(kt + 2, kt & 1, N1 + q); });
             else {
 #pragma unroll
@@ -788,7 +785,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (wave_live) {
-                phase_4w<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, 0, 0, 1>(acc, a1, w1, rd_step0(nxt), none);
+                phase_4w<MI, NI, MI + NI, P8_RD2_START, P8_RD2_STRIDE, 0, 0, 1>(acc, a1, w1, rd_step0(nxt), none);
                 phase_4w<MI, NI, MI + NI, 0, 1, 0, 0, 1>(acc, a0, w0, rd_step1(nxt), none);
                 phase_4w<MI, NI, 0, 0, 1, 0, 0, 1>(acc, a1, w1, none, none);
             }
@@ -1220,6 +1217,12 @@ VLY_DEVICE f32x4 acc_read(const f32x4& a) {
                  : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]));
     return v;
 }
+// the same block as (even columns, odd columns) register pairs: the SwiGLU epilogue's gates and ups, ready for packed math
+VLY_DEVICE void acc_read_pairs(const f32x4& a, f32x2& even, f32x2& odd) {
+    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                 : "=v"(even[0]), "=v"(odd[0]), "=v"(even[1]), "=v"(odd[1])
+                 : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]));
+}
 
 // ================= persistent 4-wave kernel: the PIPE 8 loop running THROUGH tile boundaries ==========================
 // One workgroup per CU walks tiles bid, bid + G, bid + 2G, ...  Measured on the one-tile-per-workgroup kernel
@@ -1235,23 +1238,6 @@ VLY_DEVICE f32x4 acc_read(const f32x4& a) {
 // vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads return in order,
 // so an older load (the K tile this barrier publishes) cannot be outstanding unless the N1 younger ones are — whatever the
 // stores issued in between do; they only make the wait conservative.
-#ifndef VLY_P4_TIMING
-#define VLY_P4_TIMING 0     // timing experiments only (WRONG results): 1 = no epilogue (a sink keeps the accumulators alive), 2 = 1 + 32x32x16 MFMAs, 3 = epilogue math without its stores, 4 = stores without the math (plain / gelu epilogues)
-#endif
-#ifndef VLY_P4_DBG
-#define VLY_P4_DBG 0        // timing experiments only (WRONG results): 1 = no vmcnt wait before barrier B, 2 = no barrier A, 4 = no barrier B
-#endif
-#ifndef VLY_P4_M0_LEAD
-#define VLY_P4_M0_LEAD 2     // the M0 write of a piece sits this many MFMAs before its buffer_load
-#endif
-#ifndef VLY_P4_NT_STORES
-#define VLY_P4_NT_STORES 0
-#endif
-#if VLY_P4_NT_STORES
-#define VLY_P4_STORE16(ptr, val) __builtin_nontemporal_store(val, (u32x4*)(ptr))
-#else
-#define VLY_P4_STORE16(ptr, val) (*(u32x4*)(ptr) = (val))
-#endif
 template <int BM, int BN, int EPI, int OUT>
 __global__ void __launch_bounds__(256)
 gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
@@ -1262,7 +1248,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
     constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT, NS = PA + PW;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0 && NI % 4 == 0, "tile/threads mismatch");
-    constexpr int T = MI * NI, BAR_AT = MI + NI + VLY_P8_BAR_GAP, GL1_START = BAR_AT + 2;
+    constexpr int T = MI * NI, BAR_AT = MI + NI + P8_BAR_GAP, GL1_START = BAR_AT + 2;
     constexpr int GL_STRIDE = (2 * T - GL1_START) / NS;
     constexpr int N1 = (T - GL1_START + GL_STRIDE - 1) / GL_STRIDE, N2 = NS - N1;
     constexpr int GL2_START = GL1_START + N1 * GL_STRIDE - T;
@@ -1337,11 +1323,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
     const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
     bf16x8 a0[MI], w0[NI], a1[MI], w1[NI];
-#if VLY_P4_TIMING == 2
-    f32x16 acc[MI][2];
-#else
-    f32x4 acc[MI][NI];
-#endif
     auto rd_step1 = [&](const char* st) {
         return [&, st](int k) {
             if (k < NI) w1[k < NI ? k : 0] = *(const bf16x8*)(st + rdW + k * 2048 + sw1);
@@ -1358,7 +1339,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     // the ten-odd "lgkmcnt(14)" it otherwise puts in front of the MFMA rows of a phase (each one an issue slot of the wave)
     auto bar_a = [](int) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (!(VLY_P4_DBG & 2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
     };
 
     // ---- prologue: the first two K tiles of the stream
@@ -1375,40 +1356,40 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
         for (int k = 0; k < MI + NI; ++k) r0(k);
     }
+    // C through a buffer descriptor that ends with row M - 1: a 16-byte store whose row is past M (the padded rows of the last
+    // m-tile) or whose column block was flagged invalid (offset + 2 GB) is out of range and dropped by the hardware — no
+    // exec masking, no 64-bit address arithmetic: one v_add + one buffer_store per 16 bytes (round 2's epilogue spent 12 of
+    // its 84 instructions per 8 outputs on the two range checks).  launch_p4 guarantees M * ldc * 2 < 2^31 and No % 8 == 0.
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsC =
+        __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (uint32_t)M * (uint32_t)ldc * (OUT == VLY_OUT_BF16 ? 2u : 4u), 0x00020000);
     int buf = 0;                                                     // buffer of the K tile being computed
     for (;;) {
         const bool wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
-#if VLY_P4_TIMING == 2
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#else
+        // (clearing the accumulators = 256 v_accvgpr_write per tile.  Tried in round 3: a peeled first K step with C = 0 as the
+        // MFMA's inline constant — builtin or asm with an "=a" result — makes hipcc keep the accumulators in arch VGPRs inside
+        // the K loop and spill 213 registers; not shipped.)
+        f32x4 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-        int kt = 0;
-        do {
+        auto ktile = [&]() {                                         // one K tile = two phases
             const char* cur = smem + buf * STAGE;
             const char* nxt = smem + (buf ^ 1) * STAGE;
             // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
             __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago
             if (wave_live)
-                phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - VLY_P4_M0_LEAD, GL_STRIDE>(
+                phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE>(
                     acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
             else {
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
                 for (int q = 0; q < N1; ++q) piece(buf, q);
             }
-            if (!(VLY_P4_DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
-            if (!(VLY_P4_DBG & 4)) __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
+            __builtin_amdgcn_s_barrier();
             if (wave_live)
-                phase_4w4<MI, NI, MI + NI, VLY_P8_RD2_START, VLY_P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE, 0, 0, 1, N2, GL2_START - VLY_P4_M0_LEAD, GL_STRIDE>(
+                phase_4w4<MI, NI, MI + NI, P8_RD2_START, P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE, 0, 0, 1, N2, GL2_START - P4_M0_LEAD, GL_STRIDE>(
                     acc, a1, w1, rd_step0(nxt), [&](int q) { piece_ld(N1 + q); }, [](int) {}, [&](int q) { piece_m0(buf, N1 + q); });
             else {
 #pragma unroll
@@ -1416,132 +1397,151 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             }
             advance_load();
             buf ^= 1;
-        } while (++kt < nk);
-#if VLY_P4_TIMING == 1 || VLY_P4_TIMING == 2
+        };
         {
-            float sink = 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < (VLY_P4_TIMING == 2 ? 2 : NI); ++j)
-#pragma unroll
-                    for (int r = 0; r < (VLY_P4_TIMING == 2 ? 16 : 4); ++r) asm volatile("" ::"a"(acc[i][j][r]));   // alive, no code
-            (void)sink;
+            int kt = 0;
+            do ktile(); while (++kt < nk);
         }
-#else
         // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
         // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
-        if constexpr (OUT == VLY_OUT_BF16) {                           // the launcher guarantees 16-byte aligned rows, no residual
-            {
-                const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
-                f32x4 bv[NI];                                        // the bias of this lane's 4 columns per block: once per tile
-                if constexpr (EPI != VLY_EPI_SWIGLU && EPI != VLY_EPI_QKV_ROPE) {
+        {
+        if constexpr (OUT == VLY_OUT_BF16 && EPI == VLY_EPI_QKV_ROPE) {
+            // RoPE + KV append on registers: a wave's 128 columns are ONE head (cn0 + wn0 is a multiple of 128),
+            // the rotation partner of column c < 64 is c + 64 = block j + 4 of the SAME lane.  Same arithmetic
+            // on the same bf16-rounded projections as rope_kv_kernel -> identical bits (tests compare them).
+            static_assert(NI == 8, "one head per wave");
+            const int nb = cn0 + wn0, Hq = rp.heads * 128, sect = nb / Hq, head = (nb - sect * Hq) >> 7;   // wave-uniform
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int n = cn0 + wn0 + j * 16 + g * 4;
-                        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (bias) bv[j] = *(const f32x4*)(bias + min(n, N - 4));       // uniform branch, clamped (masked at the store)
+            for (int i = 0; i < MI; ++i) {
+                __builtin_amdgcn_sched_barrier(0);                   // row by row: keeps the accumulator reads from piling up
+                const int m = cm0 + wm0 + i * 16 + l15;
+                uint16_t* crow = (uint16_t*)Cv + (size_t)min(m, M - 1) * ldc;
+                const int mc = min(m, M - 1), bq = mc / rp.S, pos = rp.past + (mc - bq * rp.S);
+                u32x2 pk[NI];
+#pragma unroll
+                for (int jl = 0; jl < 4; ++jl) {
+                    const f32x4 lo = acc_read(acc[i][jl]), hi = acc_read(acc[i][jl + 4]);
+                    const uint32_t l0 = pack_bf16x2(lo[0], lo[1]), l1 = pack_bf16x2(lo[2], lo[3]);
+                    const uint32_t h0 = pack_bf16x2(hi[0], hi[1]), h1 = pack_bf16x2(hi[2], hi[3]);
+                    if (sect < 2) {
+                        const f32x4 c = *(const f32x4*)(rp.cos_t + (size_t)pos * 64 + jl * 16 + g * 4);
+                        const f32x4 sn = *(const f32x4*)(rp.sin_t + (size_t)pos * 64 + jl * 16 + g * 4);
+                        const float xl[4] = {__uint_as_float(l0 << 16), __uint_as_float(l0 & 0xffff0000u), __uint_as_float(l1 << 16),
+                                             __uint_as_float(l1 & 0xffff0000u)};
+                        const float xh[4] = {__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 << 16),
+                                             __uint_as_float(h1 & 0xffff0000u)};
+                        pk[jl][0] = pack_bf16x2(rope_rot(xl[0], xh[0], c[0], sn[0], -1.f), rope_rot(xl[1], xh[1], c[1], sn[1], -1.f));
+                        pk[jl][1] = pack_bf16x2(rope_rot(xl[2], xh[2], c[2], sn[2], -1.f), rope_rot(xl[3], xh[3], c[3], sn[3], -1.f));
+                        pk[jl + 4][0] = pack_bf16x2(rope_rot(xh[0], xl[0], c[0], sn[0], 1.f), rope_rot(xh[1], xl[1], c[1], sn[1], 1.f));
+                        pk[jl + 4][1] = pack_bf16x2(rope_rot(xh[2], xl[2], c[2], sn[2], 1.f), rope_rot(xh[3], xl[3], c[3], sn[3], 1.f));
+                    } else {
+                        pk[jl] = u32x2{l0, l1};
+                        pk[jl + 4] = u32x2{h0, h1};
                     }
                 }
+                uint16_t* drow = sect == 0 ? crow + nb
+                                           : (sect == 1 ? rp.kc : rp.vc) + (((size_t)bq * rp.heads + head) * rp.ctx_max + pos) * 128;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    __builtin_amdgcn_sched_barrier(0);               // row by row: keeps the accumulator reads from piling up
-                    const int m = cm0 + wm0 + i * 16 + l15;
-                    uint16_t* crow = (uint16_t*)Cv + (size_t)min(m, M - 1) * ldc;
-                    if constexpr (EPI == VLY_EPI_QKV_ROPE) {
-                        // RoPE + KV append on registers: a wave's 128 columns are ONE head (cn0 + wn0 is a multiple of 128),
-                        // the rotation partner of column c < 64 is c + 64 = block j + 4 of the SAME lane.  Same arithmetic
-                        // on the same bf16-rounded projections as rope_kv_kernel -> identical bits (tests compare them).
-                        static_assert(NI == 8, "one head per wave");
-                        const int nb = cn0 + wn0, Hq = rp.heads * 128, sect = nb / Hq, head = (nb - sect * Hq) >> 7;   // wave-uniform
-                        const int mc = min(m, M - 1), bq = mc / rp.S, pos = rp.past + (mc - bq * rp.S);
-                        u32x2 pk[NI];
+                for (int jp = 0; jp < NI / 2; ++jp) {
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
+                    const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    const int dd = (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
+                    if (m < M && nb < N) *(u32x4*)(drow + dd) = o;
+                }
+            }
+        } else if constexpr (OUT == VLY_OUT_BF16) {
+            constexpr int NST = EPI == VLY_EPI_SWIGLU ? NI / 4 : NI / 2;                // 16-byte stores per fragment row
+            const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
+            uint32_t vo[NST];                                        // byte offset of this lane's store s in fragment row i (advanced per row)
+            {
+                const uint32_t rowb = (uint32_t)(cm0 + wm0 + l15) * (uint32_t)ldc * 2u;
 #pragma unroll
-                        for (int jl = 0; jl < 4; ++jl) {
-                            const f32x4 lo = acc_read(acc[i][jl]), hi = acc_read(acc[i][jl + 4]);
-                            const uint32_t l0 = pack_bf16x2(lo[0], lo[1]), l1 = pack_bf16x2(lo[2], lo[3]);
-                            const uint32_t h0 = pack_bf16x2(hi[0], hi[1]), h1 = pack_bf16x2(hi[2], hi[3]);
-                            if (sect < 2) {
-                                const f32x4 c = *(const f32x4*)(rp.cos_t + (size_t)pos * 64 + jl * 16 + g * 4);
-                                const f32x4 sn = *(const f32x4*)(rp.sin_t + (size_t)pos * 64 + jl * 16 + g * 4);
-                                const float xl[4] = {__uint_as_float(l0 << 16), __uint_as_float(l0 & 0xffff0000u), __uint_as_float(l1 << 16),
-                                                     __uint_as_float(l1 & 0xffff0000u)};
-                                const float xh[4] = {__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 << 16),
-                                                     __uint_as_float(h1 & 0xffff0000u)};
-                                pk[jl][0] = pack_bf16x2(rope_rot(xl[0], xh[0], c[0], sn[0], -1.f), rope_rot(xl[1], xh[1], c[1], sn[1], -1.f));
-                                pk[jl][1] = pack_bf16x2(rope_rot(xl[2], xh[2], c[2], sn[2], -1.f), rope_rot(xl[3], xh[3], c[3], sn[3], -1.f));
-                                pk[jl + 4][0] = pack_bf16x2(rope_rot(xh[0], xl[0], c[0], sn[0], 1.f), rope_rot(xh[1], xl[1], c[1], sn[1], 1.f));
-                                pk[jl + 4][1] = pack_bf16x2(rope_rot(xh[2], xl[2], c[2], sn[2], 1.f), rope_rot(xh[3], xl[3], c[3], sn[3], 1.f));
-                            } else {
-                                pk[jl] = u32x2{l0, l1};
-                                pk[jl + 4] = u32x2{h0, h1};
-                            }
+                for (int s = 0; s < NST; ++s) {
+                    const int n = EPI == VLY_EPI_SWIGLU ? ((cn0 + wn0) >> 1) + (4 * s + g) * 8
+                                                        : cn0 + wn0 + (2 * s + (g & 1)) * 16 + (g & 2) * 4;
+                    vo[s] = rowb + (n + 8 <= No ? (uint32_t)n * 2u : 0x80000000u);
+                }
+            }
+            const uint32_t rstep = (uint32_t)ldc * 32u;              // 16 rows further down
+            f32x4 bv[NI];                                            // the bias of this lane's 4 columns per block: once per tile
+            if constexpr (EPI != VLY_EPI_SWIGLU) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = cn0 + wn0 + j * 16 + g * 4;
+                    bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (bias) bv[j] = *(const f32x4*)(bias + min(n, N - 4));           // uniform branch, clamped (dropped at the store)
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                __builtin_amdgcn_sched_barrier(0);                   // row by row: keeps the accumulator reads from piling up
+                if constexpr (EPI == VLY_EPI_SWIGLU) {
+#pragma unroll
+                    for (int jq = 0; jq < NI / 4; ++jq) {
+                        // gate = even columns, up = odd columns (row-interleaved weights); the four blocks of one 16-byte store go
+                        // through every step of x_sigmoid2(gate, 1) * up together (see the quick_gelu branch)
+                        f32x2 gt[4], up[4], e[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc_read_pairs(acc[i][4 * jq + jj], gt[jj], up[jj]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = gt[q] * -1.4426950408889634f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] += 1.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gt[q] *= e[q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gt[q] *= up[q];
+                        uint32_t d[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) d[jj] = pack_bf16x2(gt[jj][0], gt[jj][1]);
+                        const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                        const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+                        const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+                        const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{q0[0], q1[0], q0[1], q1[1]}, rsC, vo[jq], 0, 0);
+                        vo[jq] += rstep;
+                    }
+                } else {
+#pragma unroll
+                    for (int jp = 0; jp < NI / 2; ++jp) {
+                        // the four register pairs of two blocks go through every step TOGETHER: between a packed op and the
+                        // transcendental that consumes it (and back) the hardware wants a wait state, which independent
+                        // work fills (one chain at a time cost 487 s_nop per tile)
+                        const f32x4 v0 = acc_read(acc[i][2 * jp]) + bv[2 * jp], v1 = acc_read(acc[i][2 * jp + 1]) + bv[2 * jp + 1];
+                        f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
+                        if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+                            constexpr float c = -1.4426950408889634f * 1.702f;           // x_sigmoid2's arithmetic, step by step
+                            f32x2 e[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) e[q] = x[q] * c;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) e[q] += 1.f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) x[q] *= e[q];
                         }
-                        uint16_t* drow = sect == 0 ? crow + nb
-                                                   : (sect == 1 ? rp.kc : rp.vc) + (((size_t)bq * rp.heads + head) * rp.ctx_max + pos) * 128;
+                        if constexpr (EPI == VLY_EPI_RELU) {
 #pragma unroll
-                        for (int jp = 0; jp < NI / 2; ++jp) {
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
-                            const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                            const int dd = (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
-                            if (m < M && nb < N) *(u32x4*)(drow + dd) = o;
+                            for (int q = 0; q < 4; ++q) x[q] = f32x2{fmaxf(x[q][0], 0.f), fmaxf(x[q][1], 0.f)};
                         }
-                    } else if constexpr (EPI == VLY_EPI_SWIGLU) {
+                        u32x2 pk[2];
 #pragma unroll
-                        for (int jq = 0; jq < NI / 4; ++jq) {
-                            uint32_t d[4];
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const f32x4 v = acc_read(acc[i][4 * jq + jj]);
-                                d[jj] = pack_bf16x2(x_sigmoid(v[0], 1.f) * v[1], x_sigmoid(v[2], 1.f) * v[3]);
-                            }
-                            const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
-                            const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
-                            const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
-                            const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
-                            const u32x4 o = u32x4{q0[0], q1[0], q0[1], q1[1]};
-                            const int no = ((cn0 + wn0) >> 1) + (4 * jq + g) * 8;
-                            if (m < M) {
-                                if (no + 8 <= No) VLY_P4_STORE16(crow + no, o);
-                                else if (no + 4 <= No) *(u32x2*)(crow + no) = u32x2{o[0], o[1]};
-                            }
+                        for (int jj = 0; jj < 2; ++jj) {
+                            pk[jj][0] = pack_bf16x2(x[2 * jj][0], x[2 * jj][1]);
+                            pk[jj][1] = pack_bf16x2(x[2 * jj + 1][0], x[2 * jj + 1][1]);
                         }
-                    } else {
-#pragma unroll
-                        for (int jp = 0; jp < NI / 2; ++jp) {
-                            u32x2 pk[2];
-#pragma unroll
-                            for (int jj = 0; jj < 2; ++jj) {
-                                f32x4 v = acc_read(acc[i][2 * jp + jj]) + bv[2 * jp + jj];
-                                if constexpr (EPI == VLY_EPI_QUICK_GELU) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
-                                }
-                                if constexpr (EPI == VLY_EPI_RELU) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                                }
-                                pk[jj][0] = pack_bf16x2(v[0], v[1]);
-                                pk[jj][1] = pack_bf16x2(v[2], v[3]);
-                            }
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-#if VLY_P4_TIMING == 4                                  /* stores without the math in front of them */
-                            const u32x4 o = __builtin_bit_cast(u32x4, acc_read(acc[i][2 * jp]));
-#else
-                            const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
-#endif
-                            const int n = cn0 + wn0 + (2 * jp + (g & 1)) * 16 + (g & 2) * 4;
-#if VLY_P4_TIMING == 3                                  /* the math without the stores */
-                            asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(n));
-#else
-                            if (m < M) {
-                                if (n + 8 <= N) VLY_P4_STORE16(crow + n, o);
-                                else if (n + 4 <= N) *(u32x2*)(crow + n) = u32x2{o[0], o[1]};
-                            }
-#endif
-                        }
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsC, vo[jp], 0, 0);
+                        vo[jp] += rstep;
                     }
                 }
             }
@@ -1575,7 +1575,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 }
             }
         }
-#endif
+        }
         if (ct + G >= ntiles) break;
         ct += G;
         tile_origin(ct, cm0, cn0);
@@ -1593,7 +1593,10 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
               int ldc, int ldr, int epi, int out, hipStream_t st, const RopeArgs* rope = nullptr) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, 1);
-    const int vec_ok = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !R) ? 1 : 0;
+    // bf16 outputs leave as 16-byte buffer stores clipped by the descriptor: aligned rows, whole 8-column chunks, < 2 GB
+    const int No = epi == VLY_EPI_SWIGLU ? N >> 1 : N;
+    const int vec_ok = (out == VLY_OUT_BF16 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && !R && No % 8 == 0 &&
+                        (size_t)M * (size_t)ldc * 2 < ((size_t)1 << 31)) ? 1 : 0;
     if (out == VLY_OUT_BF16 && !vec_ok) return 1;                       // caller falls back to the one-tile-per-workgroup kernel
     static const int cus = [] {
         int dev = 0, n = 0;

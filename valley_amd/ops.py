@@ -467,10 +467,11 @@ def row_split(M: int) -> int:
     with 4, 12 or 16 n-tiles the main launch is a whole number of rounds on 256 CUs) and the remaining F rows run as
     their own small launch right behind it.  Tall problems only; VALLEY_ROW_SPLIT=0 disables.
 
-    Measured at F = 128 (c3, profiles/r02_rowsplit_ab.txt): the main launches speed up — fc1 793 -> 899, fc2 990 -> 1158,
-    out-proj 778 -> 897 TFLOP/s, q|k|v unchanged — but the F-row remainder is a latency-bound launch (one tile's K loop:
-    14-17 us at K = 1024, 33 us at K = 4096), so only the MLP pair nets a gain (fc1 347 -> 322 us, fc2 276 -> 270 us per
-    layer); q|k|v and out-proj lose 2-13 us and are therefore not split (the callers decide: vision_tower.layer_forward)."""
+    Measured at F = 128 (c3, profiles/r02/r02_ab_rowsplit_rope.txt): the main launches speed up — fc1 793 -> 899, fc2 990 -> 1158,
+    out-proj 778 -> 897 TFLOP/s, q|k|v unchanged.  On the tile kernels the F-row remainder is one tile row's latency-bound
+    K loop (14-17 us at K = 1024, 33 us at K = 4096: all of the gain); on vly_gemm_skinny_bf16 it costs 12 (fc1), 22 (fc2)
+    and 9 us (out-proj), which nets a gain for all three — so vision_tower.layer_forward splits fc1, fc2 AND out-proj, and
+    leaves q|k|v (224-row tiles: 147 x 12 tiles, nothing to gain) in one launch."""
     if not ROW_SPLIT or GEMM_MODE != "tuned" or M < 32768 or M % 4096 == 0:
         return M                 # F = 32 / 64 frames (M = 8224 / 16448): the latency-bound remainder costs more than the round saved
     return M // 4096 * 4096
@@ -847,6 +848,11 @@ def decode_attention_rows(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch
     _chk(pos_rows, torch.int32, "pos_rows")
     assert pos_rows.numel() == B
     ctx_max = kcache.shape[2]
+    # the kernel clamps a row's position to ctx_max - 1 and indexes the RoPE tables with it
+    _chk(cos, torch.float32, "cos")
+    _chk(sin, torch.float32, "sin")
+    if cos.shape[0] < ctx_max or sin.shape[0] < ctx_max or cos.shape[-1] != 64 or sin.shape[-1] != 64:
+        raise ValueError(f"RoPE tables {tuple(cos.shape)} / {tuple(sin.shape)} do not cover ctx_max = {ctx_max} positions x 64")
     kv_stride = 0
     if key_valid is not None:
         _chk(key_valid, torch.uint8, "key_valid")

@@ -109,7 +109,11 @@ class ContinuousBatcher:
         if not 1 <= slots <= 8:
             raise ValueError("1 <= slots <= 8 (the decode step streams weights with the GEMV kernels)")
         self.model, self.ll = model, model.get_model().llama
+        if ctx_max > self.ll.max_positions:
+            # positions index the RoPE tables, which hold max_position_embeddings rows
+            raise ValueError(f"ctx_max {ctx_max} exceeds the model's {self.ll.max_positions} positions")
         self.slots, self.ctx_max = slots, ctx_max
+        self.full = []                                           # slots released by step() because their cache rows filled up
         self.cache = self.ll.new_cache(slots, ctx_max)
         self.cache.key_valid = torch.ones((slots, ctx_max), dtype=torch.uint8, device=self.ll.device)
         self.sess = DecodeSession(self.ll, self.cache, use_graph=use_graph, per_row_positions=True)
@@ -147,9 +151,13 @@ class ContinuousBatcher:
         if not self._captured:
             self.sess.begin()
             self._captured = True
-        for i in range(self.slots):
-            if self.live[i] and self.length[i] + 1 > self.ctx_max:
-                raise ValueError(f"slot {i}: KV cache full")
+        # a slot whose cache rows are full leaves the batch here (reported in self.full) instead of failing the shared
+        # step of every other live request
+        self.full = [i for i in range(self.slots) if self.live[i] and self.length[i] + 1 > self.ctx_max]
+        for i in self.full:
+            self.release(i)
+        if not any(self.live):
+            return {}
         self.sess.step()
         toks = self.sess.tok.tolist()                            # one D2H read per step for all requests
         out = {}

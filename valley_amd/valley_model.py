@@ -380,11 +380,24 @@ class ValleyLlamaForCausalLM:
     def eval(self):
         return self
 
-    def to(self, *a, **k):
+    def to(self, *args, **kwargs):
+        """``model.to(device)`` / ``.to(dtype)`` of the entry points (run_valley.py:39): the engines were built on their
+        device in their storage dtype, so a matching request is a no-op — and a request for ANOTHER device raises instead
+        of silently answering from the old one."""
+        want = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device, int)):
+                want = a
+        if want is not None:
+            want = torch.device("cuda", want) if isinstance(want, int) else torch.device(want)
+            have = self.device
+            if want.type != have.type or (want.index is not None and have.index is not None and want.index != have.index):
+                raise ValueError(f"this model was built on {have}; build it with device={want!s} instead of moving it "
+                                 f"(from_pretrained(..., device=...) / ValleyLlamaForCausalLM(config, device=...))")
         return self
 
     def half(self):
-        return self
+        return self                                      # storage dtype is fixed at construction (VALLEY_PRECISION)
 
     @property
     def lm_head(self):
