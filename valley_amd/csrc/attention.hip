@@ -13,6 +13,7 @@
 //                     flop/frame/layer = 4*257*257*64*16 = 0.271 GFLOP.
 //   llama_attention : flash-style over KV-cache tiles of 64 keys with online softmax, causal +
 //                     key-validity mask, head_dim 128; also serves decode (S = 1).
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -226,6 +227,169 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         }
         if (q < VN) {
             const float inv = 1.f / l;
+            uint16_t* op = out + ((size_t)f * VN + q) * 1024 + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+                pk[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+                *(u32x2*)(op + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+// ---- round 3: the same kernel with its staging and softmax rebuilt -------------------------------------------------
+// What the round-2 kernel spent its 96 us per layer (F = 128) on, from its ISA (tools/isa_blocks.py): the K staging loop
+// issued ONE global load per iteration and waited for it — 4.25 dependent HBM round trips per workgroup before the first
+// MFMA, the V staging another two —, and a query tile cost 310 VALU + 66 transcendental instructions for its 70 MFMAs
+// (scale, max, subtract, exponential, sum, convert: one instruction per score each).  Here
+//   * K goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, the chunk swizzle on the SOURCE address): 34 pieces of
+//     1 KB, 4-5 per wave, no registers, all in flight at once; padded key rows re-read token 256 (their scores are
+//     overwritten with -1e30, their probabilities are exact zeros);
+//   * all of a lane's V loads (and the first Q fragments) are issued before the first wait;
+//   * the softmax works on register PAIRS: exp2(s * c - m * c) as one v_pk_fma_f32 per two scores (the scale is folded
+//     into the exponent), row sums by v_pk_add_f32, the maximum by v_max3_f32.
+typedef __attribute__((ext_vector_type(2))) float vf2;
+VLY_DEVICE float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // hipcc fuses to v_max3_f32
+
+__global__ void __launch_bounds__(VNW * 64, 2) vit_attn2_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int skew) {
+    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2];
+    char* sK = smem;
+    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
+    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
+
+    // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7; piece pc = rows 8 pc .. 8 pc + 7
+    for (int pc = wave; pc < VNT * 2; pc += VNW) {
+        const int sl = pc * 64 + lane, row = sl >> 3, cp = sl & 7;
+        glds16(base + (size_t)min(row, VN - 1) * VLD + 1024 + ((cp ^ (row & 7)) << 3), sK + pc * 1024);
+    }
+    // ---- V: every load of this lane first (wave w: d = 16 (w & 3) .. +15; key pairs pg = w >> 2, + 2)
+    const int dq = wave & 3;
+    u32x4 va[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pg = (wave >> 2) + 2 * it, p = pg * 64 + lane;
+        if (pg < 3 && p < VNC * 16) {                                   // pg is wave-uniform
+            const uint16_t* r0 = base + (size_t)min(2 * p, VN - 1) * VLD + 2048 + dq * 16;
+            const uint16_t* r1 = base + (size_t)min(2 * p + 1, VN - 1) * VLD + 2048 + dq * 16;
+            va[it][0] = *(const u32x4*)r0;
+            va[it][1] = *(const u32x4*)(r0 + 8);
+            va[it][2] = *(const u32x4*)r1;
+            va[it][3] = *(const u32x4*)(r1 + 8);
+        }
+    }
+    bf16x8 qn[2];
+    {
+        const int qc0 = min(wave * 16 + l15, VN - 1);
+        qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
+        qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
+    }
+    // V^T: [64 d][288 kv]: the lane's two keys side by side in one 32-bit word per d (keys past 256 hold token 256: finite)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pg = (wave >> 2) + 2 * it, p = pg * 64 + lane;
+        if (pg < 3 && p < VNC * 16) {
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const uint32_t w = sel16(va[it][0], va[it][1], dd) | (sel16(va[it][2], va[it][3], dd) << 16);
+                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + 2 * p) = w;
+            }
+        }
+    }
+    __syncthreads();                                                     // (carries the vmcnt(0) of the LDS-DMA pieces)
+    // Phase skew: every wave runs QK^T (matrix pipe + LDS) -> softmax (VALU, 60 % of a query tile's cycles) -> PV (matrix
+    // pipe + LDS).  Released together by the barrier, the waves of a SIMD stay in the SAME phase — each phase bound by one
+    // pipe while the others idle (the kernel's time was the SUM of its MFMA, VALU and LDS times).  The second half of the
+    // workgroup (waves 4-7: the SIMD partners of waves 0-3) therefore starts `skew` x 512 cycles late.
+    if (wave >= VNW / 2)
+        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(8);
+
+    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
+    for (int qt = wave; qt < VNT; qt += VNW) {
+        const int q = qt * 16 + l15;
+        bf16x8 qf[2] = {qn[0], qn[1]};
+        if (qt + VNW < VNT) {
+            const int qc1 = min((qt + VNW) * 16 + l15, VN - 1);
+            qn[0] = *(const bf16x8*)(base + (size_t)qc1 * VLD + g * 8);
+            qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
+        }
+        f32x4 s[VNT];                                       // raw scores K . q (the scale rides in the exponent)
+#pragma unroll
+        for (int t = 0; t < VNT; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                acc = mfma16(kf, qf[kk], acc);
+            }
+            s[t] = acc;
+            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
+        }
+        // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
+
+        float m = max3f(s[0][0], s[0][1], max3f(s[0][2], s[0][3], NEG_BIG));
+#pragma unroll
+        for (int t = 1; t < VNT; ++t) m = max3f(max3f(m, s[t][0], s[t][1]), s[t][2], s[t][3]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const vf2 sc2 = {sc, sc}, nm2 = {-m * sc, -m * sc};
+        uint32_t pb[VNT][2];                                // the probabilities as bf16 pairs, in the second MFMA's k-slot order
+        vf2 l2 = {0.f, 0.f};
+        // step by step over ALL pairs (a packed op feeding a transcendental, or back, costs a wait state that independent
+        // work fills: pair-at-a-time order had 112 s_nop per query tile)
+        vf2 e[VNT][2];
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) e[t][hh] = __builtin_elementwise_fma(vf2{s[t][2 * hh], s[t][2 * hh + 1]}, sc2, nm2);
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) e[t][hh] = vf2{sm_exp2(e[t][hh][0]), sm_exp2(e[t][hh][1])};
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                l2 += e[t][hh];
+                pb[t][hh] = pack_bf16x2(e[t][hh][0], e[t][hh][1]);
+            }
+        float l = l2[0] + l2[1];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < VNC; ++c) {
+            u32x4 pk;
+            pk[0] = pb[2 * c][0];
+            pk[1] = pb[2 * c][1];
+            pk[2] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][0] : 0u;
+            pk[3] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][1] : 0u;
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 32 * c + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + 16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
+            }
+            asm volatile("" ::: "memory");
+        }
+        if (q < VN) {
+            const float inv = __builtin_amdgcn_rcpf(l);
             uint16_t* op = out + ((size_t)f * VN + q) * 1024 + h * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -667,7 +831,13 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
-    hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    // VLY_VIT_ATTN=1 launches the round-2 kernel (A/B measurements)
+    static const bool v1 = getenv("VLY_VIT_ATTN") && atoi(getenv("VLY_VIT_ATTN")) == 1;
+    if (v1) hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    else {
+        static const int skew = getenv("VLY_VIT_SKEW") ? atoi(getenv("VLY_VIT_SKEW")) : 0;       // measurement switch
+        hipLaunchKernelGGL(vit_attn2_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, skew);
+    }
     return vly_check_launch("vly_vit_attention");
 }
 

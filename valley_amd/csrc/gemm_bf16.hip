@@ -1242,7 +1242,7 @@ template <int BM, int BN, int EPI, int OUT>
 __global__ void __launch_bounds__(256)
 gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
                const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
-               int tiles_m, int tiles_n, int gm, int vec_ok, RopeArgs rp) {
+               int tiles_m, int tiles_n, int gm, RopeArgs rp) {
     constexpr int WM = BM / 2, WN = BN / 2, NT = 256;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -1273,6 +1273,9 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         n0 = (rr / gh) * BN;
     };
     const __amdgpu_buffer_rsrc_t rsA = vly_rsrc(A), rsW = vly_rsrc(W);
+    // (Tried in round 3 and removed: starting the four workgroup phases (id / 8) % 4 of an XCD 2 / 4 / 8 us apart, so that
+    // only a quarter of the XCD is in its store burst or VALU-only epilogue at a time — every shape but one lost 0.5-23 %,
+    // profiles/r03/r03_ab_stagger.jsonl: the idle head costs more than the lockstep does.)
     // ---- load cursor
     uint32_t voA[PA], voW[PW];
     auto set_offsets = [&](int m0, int n0) {
@@ -1609,7 +1612,7 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
     dim3 grid(tiles < cus ? tiles : cus), block(256);
 #define VLY_P4_LAUNCH(E, O)                                                                                                  \
     hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
-                       K, lda, ldw, ldc, ldr, tm, tn, gm, vec_ok, rope ? *rope : RopeArgs{})
+                       K, lda, ldw, ldc, ldr, tm, tn, gm, rope ? *rope : RopeArgs{})
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);

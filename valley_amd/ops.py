@@ -455,6 +455,7 @@ def gemm2(a, w, out, out2, bias=None) -> int:
 
 
 ROW_SPLIT = os.environ.get("VALLEY_ROW_SPLIT", "1") == "1"
+ROW_SPLIT_MIN = int(os.environ.get("VALLEY_ROW_SPLIT_MIN", "32768"))      # smallest M that is split (measurements)
 
 
 def row_split(M: int) -> int:
@@ -472,7 +473,7 @@ def row_split(M: int) -> int:
     K loop (14-17 us at K = 1024, 33 us at K = 4096: all of the gain); on vly_gemm_skinny_bf16 it costs 12 (fc1), 22 (fc2)
     and 9 us (out-proj), which nets a gain for all three — so vision_tower.layer_forward splits fc1, fc2 AND out-proj, and
     leaves q|k|v (224-row tiles: 147 x 12 tiles, nothing to gain) in one launch."""
-    if not ROW_SPLIT or GEMM_MODE != "tuned" or M < 32768 or M % 4096 == 0:
+    if not ROW_SPLIT or GEMM_MODE != "tuned" or M < ROW_SPLIT_MIN or M % 4096 == 0:
         return M                 # F = 32 / 64 frames (M = 8224 / 16448): the latency-bound remainder costs more than the round saved
     return M // 4096 * 4096
 
