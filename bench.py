@@ -305,8 +305,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from valley_amd import ops, parallel
+    from valley_amd import ops, parallel, runtime
     from valley_amd import valley_model as vm
+    # compute dtype of the line: the library's 16-bit storage / MFMA operand type (bf16 default; VALLEY_PRECISION=fp16 runs
+    # the same step on libvalley_hip_f16.so — the reference's own inference dtype)
+    DT = "fp16" if runtime.PRECISION == "fp16" else "bf16"
     from valley_amd import weights as W
 
     cfg = CONFIGS[args.config]
@@ -328,7 +331,7 @@ def main():
 
     # synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    frames = torch.randn((B, T, 3, 224, 224), generator=g, device=dev).to(torch.bfloat16)
+    frames = torch.randn((B, T, 3, 224, 224), generator=g, device=dev).to(runtime.HALF)
     ids = torch.from_numpy(W.synthetic_prompt(7, T, VOCAB_TEXT)).view(1, S)
     Bp = B * world if args.prefill == "replicated" else B
     input_ids = ids.repeat(Bp, 1)
@@ -366,7 +369,7 @@ def main():
         print(json.dumps({
             "metric": "decode tokens/sec (KV-cache, greedy, hipGraph step)", "value": round(1e3 / ms_tok, 2), "unit": "tokens/s",
             "n_gpus": 1, "steps": n_new, "warmup": args.warmup, "ms_per_step": round(ms_tok, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DT, "data": "synthetic",
             "config": {"workload": f"{cfg['label']} -> autoregressive decode, B=1, prefix S={S}, {n_new} tokens", "name": args.config},
             "wall_ms_per_token": round(wall / n_new * 1e3, 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
@@ -487,7 +490,7 @@ def main():
             "metric": "frames/sec ViT-L/14 encode + prefill tokens/sec" + (" (13B)" if H == 5120 else " (7B)" if H == 4096 else ""),
             "value": round(frames_total / (elapsed / args.steps), 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DT, "data": "synthetic",
             "config": {"workload": cfg["label"] + f", S={S}, end-to-end hot path (encode+pool+project+splice+prefill+lm_head)",
                        "name": args.config, "clips_per_gpu": B, "frames_per_clip": T, "prefill_batch_per_gpu": Bp,
                        "seq_len": S, "tune_passes": tune_passes, "streams": NS, "weights": "row-major + packed64" if args.pack_weights else "row-major", "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},

@@ -13,7 +13,9 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in practice);
  *     nothing is allocated, freed or retained; no global state; thread-safe per distinct stream.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised.
- *   - bf16 = raw uint16_t storage; the residual stream and norm parameters are fp32.
+ *   - "bf16" in a name or comment = the library's 16-bit STORAGE type, raw uint16_t: bfloat16 in libvalley_hip.so, IEEE
+ *     fp16 in libvalley_hip_f16.so (the same sources built with -DVLY_FP16=1: the reference infers in fp16,
+ *     valley/inference/run_valley.py:39) — vly_storage_dtype() tells which; the residual stream and norm parameters are fp32.
  *   - row-major everywhere; leading dimensions are in ELEMENTS.
  *   - return 0 on success, -22 (EINVAL) for unsupported shapes/alignments,
  *     -(1000+hipError_t) if a launch failed.  vly_last_error() gives a thread-local message.
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 2   /* 2: + the fp32 "precise" entry points (vly_*_f32) */
+#define VLY_ABI_VERSION 3   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -53,6 +55,12 @@ extern "C" {
 
 int         vly_abi_version(void);
 const char *vly_last_error(void);
+/* 16-bit storage type of every half-precision tensor this library reads and writes: VLY_STORAGE_BF16 (libvalley_hip.so)
+ * or VLY_STORAGE_FP16 (libvalley_hip_f16.so).  The host must allocate and convert accordingly (torch.bfloat16 /
+ * torch.float16 behind run_valley.py:39's ``model.to(torch.float16)``). */
+#define VLY_STORAGE_BF16 0
+#define VLY_STORAGE_FP16 1
+int         vly_storage_dtype(void);
 
 /* GEMM with fused epilogue:  C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) + residual[M,N]
  *   A, W bf16; bias fp32 or NULL; residual fp32 or NULL (ldr); C bf16 or fp32 (out_dtype).

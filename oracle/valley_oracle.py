@@ -97,25 +97,31 @@ def _t(w: Dict, k: str) -> torch.Tensor:
 # fp32 mode measures the cost of bf16 storage itself.  Norm parameters, biases, position / class embeddings and RoPE
 # tables stay fp32 in both.
 _ROUND = False
+_ROUND_DTYPE = torch.bfloat16
 
 
 class rounding:
-    """Context manager: ``with oracle.rounding(): ...`` evaluates the path with bf16 storage rounding."""
+    """Context manager: ``with oracle.rounding(): ...`` evaluates the path with 16-bit storage rounding — bf16 by default,
+    ``rounding(torch.float16)`` for the fp16 library (VALLEY_PRECISION=fp16, the reference's own inference dtype)."""
+
+    def __init__(self, dtype: torch.dtype = torch.bfloat16):
+        self._dtype = dtype
 
     def __enter__(self):
-        global _ROUND
-        self._old, _ROUND = _ROUND, True
+        global _ROUND, _ROUND_DTYPE
+        self._old, _ROUND = (_ROUND, _ROUND_DTYPE), True
+        _ROUND_DTYPE = self._dtype
         return self
 
     def __exit__(self, *exc):
-        global _ROUND
-        _ROUND = self._old
+        global _ROUND, _ROUND_DTYPE
+        _ROUND, _ROUND_DTYPE = self._old
         return False
 
 
 def _q(x: torch.Tensor) -> torch.Tensor:
-    """Round to bf16 (nearest-even) and back when the same-dtype mode is on; identity otherwise."""
-    return x.to(torch.bfloat16).float() if _ROUND else x
+    """Round to the storage type (nearest-even) and back when the same-dtype mode is on; identity otherwise."""
+    return x.to(_ROUND_DTYPE).float() if _ROUND else x
 
 
 def _tw(w: Dict, k: str) -> torch.Tensor:

@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol():
     assert handle.vly_abi_version() == lib.ABI_VERSION
 
 
+def test_fp16_library_exports_the_same_abi():
+    """libvalley_hip_f16.so (the same sources with -DVLY_FP16=1) exports every declared symbol and reports fp16 storage;
+    the default library reports bf16 (host-side functions: no GPU needed)."""
+    import ctypes
+    from valley_amd import build, lib
+    build.build(verbose=False)
+    h16, hbf = ctypes.CDLL(build.LIB_F16), ctypes.CDLL(build.LIB)
+    for n in header_symbols():
+        assert hasattr(h16, n), n
+    assert h16.vly_abi_version() == hbf.vly_abi_version() == lib.ABI_VERSION
+    assert h16.vly_storage_dtype() == 1 and hbf.vly_storage_dtype() == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from valley_amd import lib
     monkeypatch.setattr(lib, "_LIB", None)

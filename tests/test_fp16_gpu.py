@@ -1,0 +1,57 @@
+"""fp16-operand mode (VALLEY_PRECISION=fp16 -> libvalley_hip_f16.so).
+
+The reference infers in fp16 (/root/reference/valley/inference/run_valley.py:39 ``model.to(torch.float16)``,
+valley/model/valley_model.py:430).  libvalley_hip_f16.so is the same kernel source compiled with -DVLY_FP16=1: IEEE-half
+storage, v_mfma_f32_16x16x32_f16 (the bf16 MFMA rate), fp32 accumulation / statistics / residual stream as before.  The
+16-bit type is a property of the loaded library, so every check runs in a child process with VALLEY_PRECISION set:
+  * the reference-fixture tests of tests/test_model_gpu.py (tower, four pooling variants, splice cases, greedy decode,
+    exact reference tokens, streaming, continuous batching ...) pass UNCHANGED on the fp16 library, at the bf16 tolerances;
+  * tests/precision_worker.py measures the same quantities under both storage types: fp16 must be at least 4x closer to
+    the fp32 references than bf16 (3 more mantissa bits = 8x per rounding; measured 7-8x) — printed side by side."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, precision, timeout=900):
+    env = dict(os.environ, VALLEY_PRECISION=precision)
+    env.pop("VALLEY_HIP_LIB", None)
+    return subprocess.run([sys.executable, *args], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+
+
+def test_fp16_library_passes_the_reference_fixture_tests():
+    r = _run(["-m", "pytest", "tests/test_model_gpu.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+              "-k", "golden or decode or generate or splice or list_of_clips or stream or batching or roundtrip"], "fp16", timeout=1200)
+    tail = r.stdout.decode(errors="replace")[-1500:]
+    print(tail)
+    assert r.returncode == 0, tail
+
+
+def test_fp16_is_closer_to_fp32_than_bf16():
+    res = {}
+    for prec in ("bf16", "fp16"):
+        r = _run(["tests/precision_worker.py"], prec)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, out[-2000:]
+        res[prec] = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    b, f = res["bf16"], res["fp16"]
+    assert b["vly_storage_dtype"] == 0 and f["vly_storage_dtype"] == 1 and f["library"] == "libvalley_hip_f16.so"
+    assert b["greedy_tokens_match_reference"] and f["greedy_tokens_match_reference"]
+    print(f"{'quantity':42s} {'bf16':>11s} {'fp16':>11s}  ratio")
+    for k in sorted(b):
+        if isinstance(b[k], float):
+            print(f"{k:42s} {b[k]:11.3e} {f[k]:11.3e}  {b[k] / max(f[k], 1e-30):5.1f}x")
+    for k in ("golden_logits_maxabs", "golden_logits_rel", "embeds_rel", "tower_rel", "shape13b_hidden_rel", "shape13b_logits_rel",
+              "shape13b_decode_step_rel"):
+        assert f[k] < 0.25 * b[k], (k, b[k], f[k])
+    for k in b:
+        if k.startswith("gemm_"):
+            assert f[k] < 0.25 * b[k] and f[k] < 6e-4, (k, b[k], f[k])           # one fp16 rounding of the result: 2^-12 rms
+    # stated fp16 tolerances (~1.5x the measurement, see the print): the golden model's logits and the 13B-shape layers
+    assert f["golden_logits_maxabs"] < 8e-3 and f["shape13b_logits_rel"] < 3.5e-3

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvalley_hip.so")
+LIB_F16 = os.path.join(LIBDIR, "libvalley_hip_f16.so")      # the same sources with -DVLY_FP16=1 (IEEE fp16 storage)
 SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip"]
 
 
@@ -21,36 +22,43 @@ def hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "valley_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for lib in (LIB, LIB_F16):
+        if not os.path.exists(lib):
+            return True
+        t = os.path.getmtime(lib)
+        if any(os.path.getmtime(d) > t for d in deps):
+            return True
+    return False
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Both libraries (bf16 and fp16 storage), every translation unit compiled in parallel."""
     os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(os.path.join(LIBDIR, "f16"), exist_ok=True)
     if not force and not needs_build():
         return LIB
-    objs = []
+    variants = [(LIB, LIBDIR, []), (LIB_F16, os.path.join(LIBDIR, "f16"), ["-DVLY_FP16=1"])]
     procs = []
-    for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        objs.append(o)
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for lib, odir, flags in variants:
+        for s in SOURCES:
+            o = os.path.join(odir, s.replace(".hip", ".o"))
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c", os.path.join(CSRC, s), "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for lib, odir, _ in variants:
+        objs = [os.path.join(odir, s.replace(".hip", ".o")) for s in SOURCES]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

@@ -15,6 +15,7 @@ from typing import Optional, Sequence
 
 import torch
 
+from .runtime import HALF
 from .valley_model import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_VI_END_TOKEN,
                            DEFAULT_VI_START_TOKEN, DEFAULT_VIDEO_FRAME_TOKEN, ValleyLlamaForCausalLM)
 
@@ -78,7 +79,7 @@ def load(model_name: str):
     else:
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(path)
-        model = ValleyLlamaForCausalLM.from_pretrained(path, torch_dtype=torch.bfloat16)
+        model = ValleyLlamaForCausalLM.from_pretrained(path, torch_dtype=HALF)
     init_vision_token(model, tokenizer)
     return model.to(device).eval(), tokenizer
 
@@ -192,7 +193,7 @@ def conv_inference(args, read_line=input, emit=print):
     random.seed(42)
     device = _require_gpu()
     tokenizer = LlamaTokenizer.from_pretrained(args.model_name)
-    model = ValleyLlamaForCausalLM.from_pretrained(os.path.expanduser(args.model_name), torch_dtype=torch.bfloat16).to(device)
+    model = ValleyLlamaForCausalLM.from_pretrained(os.path.expanduser(args.model_name), torch_dtype=HALF).to(device)
     image_token_len = conv_bind_tokens(model, tokenizer)
     use_se = getattr(model.config, "mm_use_im_start_end", False)
     video_path, conv, image_tensor = "", None, None

@@ -204,11 +204,11 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 #pragma unroll
         for (int c = 0; c < VNC; ++c) {
             u32x4 pk;
-            pk[0] = pack_bf16x2(s[2 * c][0], s[2 * c][1]);
-            pk[1] = pack_bf16x2(s[2 * c][2], s[2 * c][3]);
+            pk[0] = pack_h2(s[2 * c][0], s[2 * c][1]);
+            pk[1] = pack_h2(s[2 * c][2], s[2 * c][3]);
             if (2 * c + 1 < VNT) {
-                pk[2] = pack_bf16x2(s[2 * c + 1][0], s[2 * c + 1][1]);
-                pk[3] = pack_bf16x2(s[2 * c + 1][2], s[2 * c + 1][3]);
+                pk[2] = pack_h2(s[2 * c + 1][0], s[2 * c + 1][1]);
+                pk[3] = pack_h2(s[2 * c + 1][2], s[2 * c + 1][3]);
             } else {
                 pk[2] = 0u;
                 pk[3] = 0u;
@@ -231,8 +231,8 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 u32x2 pk;
-                pk[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-                pk[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+                pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
+                pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
                 *(u32x2*)(op + dt * 16) = pk;
             }
         }
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn2_kernel(const uint16_t* 
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 l2 += e[t][hh];
-                pb[t][hh] = pack_bf16x2(e[t][hh][0], e[t][hh][1]);
+                pb[t][hh] = pack_h2(e[t][hh][0], e[t][hh][1]);
             }
         float l = l2[0] + l2[1];
         l += __shfl_xor(l, 16, 64);
@@ -394,8 +394,8 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn2_kernel(const uint16_t* 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 u32x2 pk;
-                pk[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-                pk[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+                pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
+                pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
                 *(u32x2*)(op + dt * 16) = pk;
             }
         }
@@ -557,10 +557,10 @@ __global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             u32x4 pk;
-            pk[0] = pack_bf16x2(s[2 * c][0], s[2 * c][1]);
-            pk[1] = pack_bf16x2(s[2 * c][2], s[2 * c][3]);
-            pk[2] = pack_bf16x2(s[2 * c + 1][0], s[2 * c + 1][1]);
-            pk[3] = pack_bf16x2(s[2 * c + 1][2], s[2 * c + 1][3]);
+            pk[0] = pack_h2(s[2 * c][0], s[2 * c][1]);
+            pk[1] = pack_h2(s[2 * c][2], s[2 * c][3]);
+            pk[2] = pack_h2(s[2 * c + 1][0], s[2 * c + 1][1]);
+            pk[3] = pack_h2(s[2 * c + 1][2], s[2 * c + 1][3]);
             const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
@@ -581,8 +581,8 @@ __global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-            pk[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+            pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
+            pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
             *(u32x2*)(op + dt * 16) = pk;
         }
     }
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     if (past_dev) past = min(*past_dev, ctx_max - 1);
     const int kv_len = past + 1;
     const uint16_t* qp = qkv + (size_t)b * 3 * Hq + h * 128;
-    if (tid < 128) qs[tid] = bf16_to_f32(qp[tid]) * (0.08838834764831845f * LOG2E);
+    if (tid < 128) qs[tid] = h2f(qp[tid]) * (0.08838834764831845f * LOG2E);
     __syncthreads();
     const uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
     const uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
@@ -626,10 +626,10 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
             for (int c = 0; c < 16; ++c) {
                 const u32x4 kk = kr[c];
                 const f32x4 q0 = *(const f32x4*)(qs + 8 * c), q1 = *(const f32x4*)(qs + 8 * c + 4);
-                a = fmaf(__uint_as_float(kk[0] << 16), q0[0], a); a = fmaf(__uint_as_float(kk[0] & 0xffff0000u), q0[1], a);
-                a = fmaf(__uint_as_float(kk[1] << 16), q0[2], a); a = fmaf(__uint_as_float(kk[1] & 0xffff0000u), q0[3], a);
-                a = fmaf(__uint_as_float(kk[2] << 16), q1[0], a); a = fmaf(__uint_as_float(kk[2] & 0xffff0000u), q1[1], a);
-                a = fmaf(__uint_as_float(kk[3] << 16), q1[2], a); a = fmaf(__uint_as_float(kk[3] & 0xffff0000u), q1[3], a);
+                a = fmaf(h_lo(kk[0]), q0[0], a); a = fmaf(h_hi(kk[0]), q0[1], a);
+                a = fmaf(h_lo(kk[1]), q0[2], a); a = fmaf(h_hi(kk[1]), q0[3], a);
+                a = fmaf(h_lo(kk[2]), q1[0], a); a = fmaf(h_hi(kk[2]), q1[1], a);
+                a = fmaf(h_lo(kk[3]), q1[2], a); a = fmaf(h_hi(kk[3]), q1[3], a);
             }
             s = a;
         }
@@ -669,10 +669,10 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float p = pp[u];
-            o[0] = fmaf(p, __uint_as_float(vv[u][0] << 16), o[0]); o[1] = fmaf(p, __uint_as_float(vv[u][0] & 0xffff0000u), o[1]);
-            o[2] = fmaf(p, __uint_as_float(vv[u][1] << 16), o[2]); o[3] = fmaf(p, __uint_as_float(vv[u][1] & 0xffff0000u), o[3]);
-            o[4] = fmaf(p, __uint_as_float(vv[u][2] << 16), o[4]); o[5] = fmaf(p, __uint_as_float(vv[u][2] & 0xffff0000u), o[5]);
-            o[6] = fmaf(p, __uint_as_float(vv[u][3] << 16), o[6]); o[7] = fmaf(p, __uint_as_float(vv[u][3] & 0xffff0000u), o[7]);
+            o[0] = fmaf(p, h_lo(vv[u][0]), o[0]); o[1] = fmaf(p, h_hi(vv[u][0]), o[1]);
+            o[2] = fmaf(p, h_lo(vv[u][1]), o[2]); o[3] = fmaf(p, h_hi(vv[u][1]), o[3]);
+            o[4] = fmaf(p, h_lo(vv[u][2]), o[4]); o[5] = fmaf(p, h_hi(vv[u][2]), o[5]);
+            o[6] = fmaf(p, h_lo(vv[u][3]), o[6]); o[7] = fmaf(p, h_hi(vv[u][3]), o[7]);
         }
     }
 #pragma unroll
@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
         float t = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) t += acc_s[k2][tid];
-        out[(size_t)b * Hq + h * 128 + tid] = f32_to_bf16(t / l);
+        out[(size_t)b * Hq + h * 128 + tid] = f2h(t / l);
     }
 }
 
@@ -723,20 +723,20 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
     // ---- RoPE on q, k (pair d, d+64) + append; v append -------------------------------------------------
     if (tid < 64) {
         const float cs = cos_t[(size_t)pos * 64 + tid], sn = sin_t[(size_t)pos * 64 + tid];
-        const float q0 = bf16_to_f32(qp[tid]), q1 = bf16_to_f32(qp[tid + 64]);
-        const float k0 = bf16_to_f32(qp[Hq + tid]), k1 = bf16_to_f32(qp[Hq + tid + 64]);
+        const float q0 = h2f(qp[tid]), q1 = h2f(qp[tid + 64]);
+        const float k0 = h2f(qp[Hq + tid]), k1 = h2f(qp[Hq + tid + 64]);
         const float scale = 0.08838834764831845f * LOG2E;
-        qs[tid] = bf16_to_f32(f32_to_bf16(rope_rot(q0, q1, cs, sn, -1.f))) * scale;
-        qs[tid + 64] = bf16_to_f32(f32_to_bf16(rope_rot(q1, q0, cs, sn, 1.f))) * scale;
-        const uint16_t r0 = f32_to_bf16(rope_rot(k0, k1, cs, sn, -1.f)), r1 = f32_to_bf16(rope_rot(k1, k0, cs, sn, 1.f));
-        knew[tid] = bf16_to_f32(r0);
-        knew[tid + 64] = bf16_to_f32(r1);
+        qs[tid] = h2f(f2h(rope_rot(q0, q1, cs, sn, -1.f))) * scale;
+        qs[tid + 64] = h2f(f2h(rope_rot(q1, q0, cs, sn, 1.f))) * scale;
+        const uint16_t r0 = f2h(rope_rot(k0, k1, cs, sn, -1.f)), r1 = f2h(rope_rot(k1, k0, cs, sn, 1.f));
+        knew[tid] = h2f(r0);
+        knew[tid + 64] = h2f(r1);
         kbase[(size_t)pos * 128 + tid] = r0;
         kbase[(size_t)pos * 128 + tid + 64] = r1;
     } else if (tid < 192) {
         const int d = tid - 64;
         const uint16_t v = qp[2 * Hq + d];
-        vnew[d] = bf16_to_f32(v);
+        vnew[d] = h2f(v);
         vbase[(size_t)pos * 128 + d] = v;
     }
     __syncthreads();
@@ -767,10 +767,10 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const f32x4 q0 = *(const f32x4*)(qs + 8 * c), q1 = *(const f32x4*)(qs + 8 * c + 4);
-                    a = fmaf(__uint_as_float(kk[c][0] << 16), q0[0], a); a = fmaf(__uint_as_float(kk[c][0] & 0xffff0000u), q0[1], a);
-                    a = fmaf(__uint_as_float(kk[c][1] << 16), q0[2], a); a = fmaf(__uint_as_float(kk[c][1] & 0xffff0000u), q0[3], a);
-                    a = fmaf(__uint_as_float(kk[c][2] << 16), q1[0], a); a = fmaf(__uint_as_float(kk[c][2] & 0xffff0000u), q1[1], a);
-                    a = fmaf(__uint_as_float(kk[c][3] << 16), q1[2], a); a = fmaf(__uint_as_float(kk[c][3] & 0xffff0000u), q1[3], a);
+                    a = fmaf(h_lo(kk[c][0]), q0[0], a); a = fmaf(h_hi(kk[c][0]), q0[1], a);
+                    a = fmaf(h_lo(kk[c][1]), q0[2], a); a = fmaf(h_hi(kk[c][1]), q0[3], a);
+                    a = fmaf(h_lo(kk[c][2]), q1[0], a); a = fmaf(h_hi(kk[c][2]), q1[1], a);
+                    a = fmaf(h_lo(kk[c][3]), q1[2], a); a = fmaf(h_hi(kk[c][3]), q1[3], a);
                 }
             } else {                                             // the new token's key: still in LDS
 #pragma unroll 8
@@ -808,10 +808,10 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = fmaf(pj, vnew[8 * dc + i], o[i]);
             } else {
-                o[0] = fmaf(pj, __uint_as_float(vv[u][0] << 16), o[0]); o[1] = fmaf(pj, __uint_as_float(vv[u][0] & 0xffff0000u), o[1]);
-                o[2] = fmaf(pj, __uint_as_float(vv[u][1] << 16), o[2]); o[3] = fmaf(pj, __uint_as_float(vv[u][1] & 0xffff0000u), o[3]);
-                o[4] = fmaf(pj, __uint_as_float(vv[u][2] << 16), o[4]); o[5] = fmaf(pj, __uint_as_float(vv[u][2] & 0xffff0000u), o[5]);
-                o[6] = fmaf(pj, __uint_as_float(vv[u][3] << 16), o[6]); o[7] = fmaf(pj, __uint_as_float(vv[u][3] & 0xffff0000u), o[7]);
+                o[0] = fmaf(pj, h_lo(vv[u][0]), o[0]); o[1] = fmaf(pj, h_hi(vv[u][0]), o[1]);
+                o[2] = fmaf(pj, h_lo(vv[u][1]), o[2]); o[3] = fmaf(pj, h_hi(vv[u][1]), o[3]);
+                o[4] = fmaf(pj, h_lo(vv[u][2]), o[4]); o[5] = fmaf(pj, h_hi(vv[u][2]), o[5]);
+                o[6] = fmaf(pj, h_lo(vv[u][3]), o[6]); o[7] = fmaf(pj, h_hi(vv[u][3]), o[7]);
             }
         }
         __syncthreads();                                         // sc[] / red[] are rewritten by the next chunk
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
         float t = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < 32; ++k2) t += acc_s[k2][tid];
-        out[(size_t)b * Hq + h * 128 + tid] = f32_to_bf16(t / l_run);
+        out[(size_t)b * Hq + h * 128 + tid] = f2h(t / l_run);
     }
 }
 

@@ -24,3 +24,4 @@ int vly_check_launch(const char* what) {
 
 extern "C" int vly_abi_version(void) { return VLY_ABI_VERSION; }
 extern "C" const char* vly_last_error(void) { return g_err; }
+extern "C" int vly_storage_dtype(void) { return VLY_FP16 ? VLY_STORAGE_FP16 : VLY_STORAGE_BF16; }

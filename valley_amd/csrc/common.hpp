@@ -1,4 +1,4 @@
-// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 bf16).
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 on the 16-bit storage type: bf16 or fp16).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,19 +11,36 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define VLY_DEVICE __device__ __forceinline__
 
-VLY_DEVICE float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
-// fp32 -> bf16, round-to-nearest-even: the native conversion lowers to ONE v_cvt_pk_bf16_f32 per pair
-// on gfx950 (a hand-written integer RNE costs ~6 VALU ops per value, which showed up in the attention
-// softmax and in every GEMM epilogue).
+// ---- the 16-bit storage type ----------------------------------------------------------------------------------------
+// Every "half" tensor of the C ABI (GEMM operands, activations, KV cache) is bf16 in libvalley_hip.so and IEEE fp16 in
+// libvalley_hip_f16.so, which is this same source tree compiled with -DVLY_FP16=1 (VALLEY_PRECISION=fp16 on the host):
+// fp16 is the reference's own inference dtype (valley/inference/run_valley.py:39, valley_model.py:430), runs on the same
+// MFMA at the same rate (v_mfma_f32_16x16x32_f16) and keeps 3 more mantissa bits.  The kernels never touch the bits
+// themselves: they go through h2f / f2h / h_lo / h_hi / pack_h2 / mfma16 below; vly_storage_dtype() reports which
+// library one holds.  Accumulation, softmax / norm statistics and the residual stream are fp32 in both.
+#ifndef VLY_FP16
+#define VLY_FP16 0
+#endif
 typedef __attribute__((ext_vector_type(2))) float vly_f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 vly_bf16x2;
-
-VLY_DEVICE uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
-
-VLY_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+#if VLY_FP16
+typedef __attribute__((ext_vector_type(2))) _Float16 vly_h2;
+typedef __attribute__((ext_vector_type(8))) _Float16 vly_h8;
+VLY_DEVICE float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+VLY_DEVICE float h_lo(uint32_t w) { return (float)__builtin_bit_cast(vly_h2, w)[0]; }      // element 0 / 1 of a packed pair
+VLY_DEVICE float h_hi(uint32_t w) { return (float)__builtin_bit_cast(vly_h2, w)[1]; }
+VLY_DEVICE uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round-to-nearest-even
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 vly_h2;
+VLY_DEVICE float h2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+VLY_DEVICE float h_lo(uint32_t w) { return __uint_as_float(w << 16); }
+VLY_DEVICE float h_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+VLY_DEVICE uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+#endif
+// fp32 pair -> packed storage pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950 (a hand-written
+// integer RNE costs ~6 VALU ops per value, which showed up in the attention softmax and in every GEMM epilogue).
+VLY_DEVICE uint32_t pack_h2(float lo, float hi) {
     const vly_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vly_bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vly_h2));
 }
 
 // x * sigmoid(a*x) = x / (1 + 2^(-a*log2(e)*x)) with one v_exp_f32 and one v_rcp_f32 (a full IEEE division costs ~10 VALU
@@ -53,8 +70,12 @@ VLY_DEVICE float rope_rot(float x, float partner, float c, float s, float sign) 
 
 // D(16x16) += A(16x32) * B(32x16).  Lane l supplies A[row = l&15][k = 8*(l>>4) .. +7] and
 // B[k = 8*(l>>4) .. +7][col = l&15]; it receives D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
-VLY_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+VLY_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {            // (bf16x8 = 8 storage elements = 4 VGPRs, either dtype)
+#if VLY_FP16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vly_h8, a), __builtin_bit_cast(vly_h8, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 VLY_DEVICE float wave_sum(float v) {

@@ -1019,7 +1019,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             const f32x4 v = acc[i][4 * jq + jj];
-                            d[jj] = pack_bf16x2(x_sigmoid(v[0], 1.f) * v[1], x_sigmoid(v[2], 1.f) * v[3]);
+                            d[jj] = pack_h2(x_sigmoid(v[0], 1.f) * v[1], x_sigmoid(v[2], 1.f) * v[3]);
                         }
                         const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
                         const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
@@ -1051,8 +1051,8 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                             }
                             if (R && in) v += *(const f32x4*)(R + (size_t)m * ldr + n);
-                            pk[jj][0] = pack_bf16x2(v[0], v[1]);
-                            pk[jj][1] = pack_bf16x2(v[2], v[3]);
+                            pk[jj][0] = pack_h2(v[0], v[1]);
+                            pk[jj][1] = pack_h2(v[2], v[3]);
                         }
                         const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -1100,12 +1100,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                         if constexpr (EPI == VLY_EPI_SWIGLU) {
                             const float o0 = x_sigmoid(v[0], 1.f) * v[1];
                             const float o1 = x_sigmoid(v[2], 1.f) * v[3];
-                            *(uint32_t*)(smem + row * C_ROW + (col >> 1) * 2) = pack_bf16x2(o0, o1);
+                            *(uint32_t*)(smem + row * C_ROW + (col >> 1) * 2) = pack_h2(o0, o1);
                         } else {
                             if (R && in) v += *(const f32x4*)(R + (size_t)m * ldr + n);
                             u32x2 pk;
-                            pk[0] = pack_bf16x2(v[0], v[1]);
-                            pk[1] = pack_bf16x2(v[2], v[3]);
+                            pk[0] = pack_h2(v[0], v[1]);
+                            pk[1] = pack_h2(v[2], v[3]);
                             *(u32x2*)(smem + row * C_ROW + col * 2) = pk;
                         }
                     }
@@ -1134,11 +1134,11 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                             const float sign = dd < 64 ? -1.f : 1.f;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float x0 = __uint_as_float(d[e] << 16), x1 = __uint_as_float(d[e] & 0xffff0000u);
-                                const float y0 = __uint_as_float(pd[e] << 16), y1 = __uint_as_float(pd[e] & 0xffff0000u);
+                                const float x0 = h_lo(d[e]), x1 = h_hi(d[e]);
+                                const float y0 = h_lo(pd[e]), y1 = h_hi(pd[e]);
                                 const float cc0 = e < 2 ? c0[2 * e] : c1[2 * e - 4], cc1 = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
                                 const float ss0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], ss1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
-                                d[e] = pack_bf16x2(rope_rot(x0, y0, cc0, ss0, sign), rope_rot(x1, y1, cc1, ss1, sign));
+                                d[e] = pack_h2(rope_rot(x0, y0, cc0, ss0, sign), rope_rot(x1, y1, cc1, ss1, sign));
                             }
                         }
                         if (sect > 0)
@@ -1177,7 +1177,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 const float o1 = x_sigmoid(v[2], 1.f) * v[3];
                 const size_t o = (size_t)m * ldc + (n >> 1);
                 if constexpr (OUT == VLY_OUT_BF16) {
-                    *(uint32_t*)((uint16_t*)Cv + o) = pack_bf16x2(o0, o1);
+                    *(uint32_t*)((uint16_t*)Cv + o) = pack_h2(o0, o1);
                 } else {
                     *(float2*)((float*)Cv + o) = make_float2(o0, o1);
                 }
@@ -1189,8 +1189,8 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 const size_t o = (size_t)m * ldc + n;
                 if constexpr (OUT == VLY_OUT_BF16) {
                     u32x2 pk;
-                    pk[0] = pack_bf16x2(v[0], v[1]);
-                    pk[1] = pack_bf16x2(v[2], v[3]);
+                    pk[0] = pack_h2(v[0], v[1]);
+                    pk[1] = pack_h2(v[2], v[3]);
                     *(u32x2*)((uint16_t*)Cv + o) = pk;
                 } else {
                     *(f32x4*)((float*)Cv + o) = v;
@@ -1424,19 +1424,19 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
                 for (int jl = 0; jl < 4; ++jl) {
                     const f32x4 lo = acc_read(acc[i][jl]), hi = acc_read(acc[i][jl + 4]);
-                    const uint32_t l0 = pack_bf16x2(lo[0], lo[1]), l1 = pack_bf16x2(lo[2], lo[3]);
-                    const uint32_t h0 = pack_bf16x2(hi[0], hi[1]), h1 = pack_bf16x2(hi[2], hi[3]);
+                    const uint32_t l0 = pack_h2(lo[0], lo[1]), l1 = pack_h2(lo[2], lo[3]);
+                    const uint32_t h0 = pack_h2(hi[0], hi[1]), h1 = pack_h2(hi[2], hi[3]);
                     if (sect < 2) {
                         const f32x4 c = *(const f32x4*)(rp.cos_t + (size_t)pos * 64 + jl * 16 + g * 4);
                         const f32x4 sn = *(const f32x4*)(rp.sin_t + (size_t)pos * 64 + jl * 16 + g * 4);
-                        const float xl[4] = {__uint_as_float(l0 << 16), __uint_as_float(l0 & 0xffff0000u), __uint_as_float(l1 << 16),
-                                             __uint_as_float(l1 & 0xffff0000u)};
-                        const float xh[4] = {__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 << 16),
-                                             __uint_as_float(h1 & 0xffff0000u)};
-                        pk[jl][0] = pack_bf16x2(rope_rot(xl[0], xh[0], c[0], sn[0], -1.f), rope_rot(xl[1], xh[1], c[1], sn[1], -1.f));
-                        pk[jl][1] = pack_bf16x2(rope_rot(xl[2], xh[2], c[2], sn[2], -1.f), rope_rot(xl[3], xh[3], c[3], sn[3], -1.f));
-                        pk[jl + 4][0] = pack_bf16x2(rope_rot(xh[0], xl[0], c[0], sn[0], 1.f), rope_rot(xh[1], xl[1], c[1], sn[1], 1.f));
-                        pk[jl + 4][1] = pack_bf16x2(rope_rot(xh[2], xl[2], c[2], sn[2], 1.f), rope_rot(xh[3], xl[3], c[3], sn[3], 1.f));
+                        const float xl[4] = {h_lo(l0), h_hi(l0), h_lo(l1),
+                                             h_hi(l1)};
+                        const float xh[4] = {h_lo(h0), h_hi(h0), h_lo(h1),
+                                             h_hi(h1)};
+                        pk[jl][0] = pack_h2(rope_rot(xl[0], xh[0], c[0], sn[0], -1.f), rope_rot(xl[1], xh[1], c[1], sn[1], -1.f));
+                        pk[jl][1] = pack_h2(rope_rot(xl[2], xh[2], c[2], sn[2], -1.f), rope_rot(xl[3], xh[3], c[3], sn[3], -1.f));
+                        pk[jl + 4][0] = pack_h2(rope_rot(xh[0], xl[0], c[0], sn[0], 1.f), rope_rot(xh[1], xl[1], c[1], sn[1], 1.f));
+                        pk[jl + 4][1] = pack_h2(rope_rot(xh[2], xl[2], c[2], sn[2], 1.f), rope_rot(xh[3], xl[3], c[3], sn[3], 1.f));
                     } else {
                         pk[jl] = u32x2{l0, l1};
                         pk[jl + 4] = u32x2{h0, h1};
@@ -1501,7 +1501,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         for (int q = 0; q < 4; ++q) gt[q] *= up[q];
                         uint32_t d[4];
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) d[jj] = pack_bf16x2(gt[jj][0], gt[jj][1]);
+                        for (int jj = 0; jj < 4; ++jj) d[jj] = pack_h2(gt[jj][0], gt[jj][1]);
                         const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
                         const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
                         const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
@@ -1538,8 +1538,8 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         u32x2 pk[2];
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj) {
-                            pk[jj][0] = pack_bf16x2(x[2 * jj][0], x[2 * jj][1]);
-                            pk[jj][1] = pack_bf16x2(x[2 * jj + 1][0], x[2 * jj + 1][1]);
+                            pk[jj][0] = pack_h2(x[2 * jj][0], x[2 * jj][1]);
+                            pk[jj][1] = pack_h2(x[2 * jj + 1][0], x[2 * jj + 1][1]);
                         }
                         const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);

@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(const uint16_t* _
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
     u32x2 pk;
-    pk[0] = pack_bf16x2(v[0], v[1]);
-    pk[1] = pack_bf16x2(v[2], v[3]);
+    pk[0] = pack_h2(v[0], v[1]);
+    pk[1] = pack_h2(v[2], v[3]);
     *(u32x2*)(C + (size_t)m * ldc + n) = pk;
 }
 

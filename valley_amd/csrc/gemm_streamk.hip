@@ -304,15 +304,15 @@ gemm_sk_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         const float o0 = x_sigmoid(v[0], 1.f) * v[1];
                         const float o1 = x_sigmoid(v[2], 1.f) * v[3];
                         const size_t o = (size_t)m * ldc + (n >> 1);
-                        if constexpr (OUT == VLY_OUT_BF16) *(uint32_t*)((uint16_t*)Cv + o) = pack_bf16x2(o0, o1);
+                        if constexpr (OUT == VLY_OUT_BF16) *(uint32_t*)((uint16_t*)Cv + o) = pack_h2(o0, o1);
                         else *(float2*)((float*)Cv + o) = make_float2(o0, o1);
                     } else {
                         if (R) v += *(const f32x4*)(R + (size_t)m * ldr + n);
                         const size_t o = (size_t)m * ldc + n;
                         if constexpr (OUT == VLY_OUT_BF16) {
                             u32x2 pk;
-                            pk[0] = pack_bf16x2(v[0], v[1]);
-                            pk[1] = pack_bf16x2(v[2], v[3]);
+                            pk[0] = pack_h2(v[0], v[1]);
+                            pk[1] = pack_h2(v[2], v[3]);
                             *(u32x2*)((uint16_t*)Cv + o) = pk;
                         } else {
                             *(f32x4*)((float*)Cv + o) = v;

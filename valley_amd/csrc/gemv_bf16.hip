@@ -12,8 +12,8 @@ VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        s = fmaf(__uint_as_float(w[i] << 16), __uint_as_float(a[i] << 16), s);
-        s = fmaf(__uint_as_float(w[i] & 0xffff0000u), __uint_as_float(a[i] & 0xffff0000u), s);
+        s = fmaf(h_lo(w[i]), h_lo(a[i]), s);
+        s = fmaf(h_hi(w[i]), h_hi(a[i]), s);
     }
     return s;
 }
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
         if constexpr (EPI == VLY_EPI_SWIGLU) {
             const float o = x_sigmoid(v0, 1.f) * v1;
             const size_t off = (size_t)m * ldc + (n0 >> 1);
-            if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f32_to_bf16(o);
+            if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f2h(o);
             else ((float*)Cv)[off] = o;
         } else {
             if (R) {
@@ -87,8 +87,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
             }
             const size_t off = (size_t)m * ldc + n0;
             if constexpr (OUT == VLY_OUT_BF16) {
-                ((uint16_t*)Cv)[off] = f32_to_bf16(v0);
-                if (has1) ((uint16_t*)Cv)[off + 1] = f32_to_bf16(v1);
+                ((uint16_t*)Cv)[off] = f2h(v0);
+                if (has1) ((uint16_t*)Cv)[off + 1] = f2h(v1);
             } else {
                 ((float*)Cv)[off] = v0;
                 if (has1) ((float*)Cv)[off + 1] = v1;

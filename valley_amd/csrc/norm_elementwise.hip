@@ -36,12 +36,12 @@ __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const 
         if constexpr (ADD) {
             if (c < nvec) {
                 const u32x2 dk = *(const u32x2*)(delta + (size_t)row * D + 4 * c);
-                v[i].x += __uint_as_float(dk[0] << 16); v[i].y += __uint_as_float(dk[0] & 0xffff0000u);
-                v[i].z += __uint_as_float(dk[1] << 16); v[i].w += __uint_as_float(dk[1] & 0xffff0000u);
+                v[i].x += h_lo(dk[0]); v[i].y += h_hi(dk[0]);
+                v[i].z += h_lo(dk[1]); v[i].w += h_hi(dk[1]);
                 if (delta2) {                                   // second split-K partial of the sub-layer GEMM
                     const u32x2 d2 = *(const u32x2*)(delta2 + (size_t)row * D + 4 * c);
-                    v[i].x += __uint_as_float(d2[0] << 16); v[i].y += __uint_as_float(d2[0] & 0xffff0000u);
-                    v[i].z += __uint_as_float(d2[1] << 16); v[i].w += __uint_as_float(d2[1] & 0xffff0000u);
+                    v[i].x += h_lo(d2[0]); v[i].y += h_hi(d2[0]);
+                    v[i].z += h_lo(d2[1]); v[i].w += h_hi(d2[1]);
                 }
                 xr[c] = v[i];
             }
@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const 
         }
         if (y16) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(o.x, o.y);
-            pk[1] = pack_bf16x2(o.z, o.w);
+            pk[0] = pack_h2(o.x, o.y);
+            pk[1] = pack_h2(o.z, o.w);
             *(u32x2*)(y16 + (size_t)row * D + 4 * c) = pk;
         }
         if (y32) ((float4*)(y32 + (size_t)row * D))[c] = o;
@@ -114,12 +114,12 @@ __global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, co
         if constexpr (ADD) {
             if (c < nvec) {
                 const u32x2 dk = *(const u32x2*)(delta + (size_t)row * D + 4 * c);
-                v[i].x += __uint_as_float(dk[0] << 16); v[i].y += __uint_as_float(dk[0] & 0xffff0000u);
-                v[i].z += __uint_as_float(dk[1] << 16); v[i].w += __uint_as_float(dk[1] & 0xffff0000u);
+                v[i].x += h_lo(dk[0]); v[i].y += h_hi(dk[0]);
+                v[i].z += h_lo(dk[1]); v[i].w += h_hi(dk[1]);
                 if (delta2) {
                     const u32x2 d2 = *(const u32x2*)(delta2 + (size_t)row * D + 4 * c);
-                    v[i].x += __uint_as_float(d2[0] << 16); v[i].y += __uint_as_float(d2[0] & 0xffff0000u);
-                    v[i].z += __uint_as_float(d2[1] << 16); v[i].w += __uint_as_float(d2[1] & 0xffff0000u);
+                    v[i].x += h_lo(d2[0]); v[i].y += h_hi(d2[0]);
+                    v[i].z += h_lo(d2[1]); v[i].w += h_hi(d2[1]);
                 }
                 xr[c] = v[i];
             }
@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, co
         }
         if (y16) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(o.x, o.y);
-            pk[1] = pack_bf16x2(o.z, o.w);
+            pk[0] = pack_h2(o.x, o.y);
+            pk[1] = pack_h2(o.z, o.w);
             *(u32x2*)(y16 + (size_t)row * D + 4 * c) = pk;
         }
         if (y32) ((float4*)(y32 + (size_t)row * D))[c] = o;
@@ -322,8 +322,8 @@ __global__ void __launch_bounds__(256) pool_kernel(const float* __restrict__ fea
         o = ((const float4*)(fb + (size_t)(r - 256) * 257 * W))[c];
     }
     u32x2 pk;
-    pk[0] = pack_bf16x2(o.x, o.y);
-    pk[1] = pack_bf16x2(o.z, o.w);
+    pk[0] = pack_h2(o.x, o.y);
+    pk[1] = pack_h2(o.z, o.w);
     *(u32x2*)(out + ((size_t)b * (256 + T) + r) * W + 4 * c) = pk;
 }
 
@@ -342,10 +342,10 @@ __global__ void __launch_bounds__(256) embed_splice_kernel(const int32_t* __rest
     for (int c = lane; c < (H >> 3); c += 64) {
         const u32x4 pk = *(const u32x4*)(src + 8 * c);
         float4 a, b;
-        a.x = __uint_as_float(pk[0] << 16); a.y = __uint_as_float(pk[0] & 0xffff0000u);
-        a.z = __uint_as_float(pk[1] << 16); a.w = __uint_as_float(pk[1] & 0xffff0000u);
-        b.x = __uint_as_float(pk[2] << 16); b.y = __uint_as_float(pk[2] & 0xffff0000u);
-        b.z = __uint_as_float(pk[3] << 16); b.w = __uint_as_float(pk[3] & 0xffff0000u);
+        a.x = h_lo(pk[0]); a.y = h_hi(pk[0]);
+        a.z = h_lo(pk[1]); a.w = h_hi(pk[1]);
+        b.x = h_lo(pk[2]); b.y = h_hi(pk[2]);
+        b.z = h_lo(pk[3]); b.w = h_hi(pk[3]);
         ((float4*)o)[2 * c] = a;
         ((float4*)o)[2 * c + 1] = b;
     }
@@ -382,10 +382,10 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(uint16_t* __restrict__ qkv
     auto rot = [&](const u32x4 lo, const u32x4 hi, u32x4& olo, u32x4& ohi) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float a0 = __uint_as_float(lo[i] << 16), a1 = __uint_as_float(lo[i] & 0xffff0000u);
-            const float b0 = __uint_as_float(hi[i] << 16), b1 = __uint_as_float(hi[i] & 0xffff0000u);
-            olo[i] = pack_bf16x2(rope_rot(a0, b0, cs[2 * i], sn[2 * i], -1.f), rope_rot(a1, b1, cs[2 * i + 1], sn[2 * i + 1], -1.f));
-            ohi[i] = pack_bf16x2(rope_rot(b0, a0, cs[2 * i], sn[2 * i], 1.f), rope_rot(b1, a1, cs[2 * i + 1], sn[2 * i + 1], 1.f));
+            const float a0 = h_lo(lo[i]), a1 = h_hi(lo[i]);
+            const float b0 = h_lo(hi[i]), b1 = h_hi(hi[i]);
+            olo[i] = pack_h2(rope_rot(a0, b0, cs[2 * i], sn[2 * i], -1.f), rope_rot(a1, b1, cs[2 * i + 1], sn[2 * i + 1], -1.f));
+            ohi[i] = pack_h2(rope_rot(b0, a0, cs[2 * i], sn[2 * i], 1.f), rope_rot(b1, a1, cs[2 * i + 1], sn[2 * i + 1], 1.f));
         }
     };
     u32x4 olo, ohi;
@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ x, 
     if (i >= n8) return;
     const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
     u32x4 pk;
-    pk[0] = pack_bf16x2(a.x, a.y); pk[1] = pack_bf16x2(a.z, a.w);
-    pk[2] = pack_bf16x2(b.x, b.y); pk[3] = pack_bf16x2(b.z, b.w);
+    pk[0] = pack_h2(a.x, a.y); pk[1] = pack_h2(a.z, a.w);
+    pk[2] = pack_h2(b.x, b.y); pk[3] = pack_h2(b.z, b.w);
     ((u32x4*)y)[i] = pk;
 }
 

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) resize_v_norm_kernel(const uint8_t* __res
     for (int c = 0; c < 3; ++c) {
         const float v = ((float)clip8(a[c]) / 255.0f - mean[c]) / stdv[c];
         const size_t o = (((size_t)t * 3 + c) * OS + oy) * OS + ox;
-        if constexpr (sizeof(OT) == 2) out[o] = f32_to_bf16(v);
+        if constexpr (sizeof(OT) == 2) out[o] = f2h(v);
         else out[o] = v;
     }
 }

@@ -30,8 +30,8 @@ __global__ void __launch_bounds__(256) delta_prep_kernel(const float* __restrict
         m.x += a.x; m.y += a.y; m.z += a.z; m.w += a.w;
         const float4 x = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
         u32x2 pk;
-        pk[0] = pack_bf16x2(x.x, x.y);
-        pk[1] = pack_bf16x2(x.z, x.w);
+        pk[0] = pack_h2(x.x, x.y);
+        pk[1] = pack_h2(x.z, x.w);
         *(u32x2*)(x_all + ((size_t)bp * T + t) * H + 4 * c) = pk;
         if (t == T - 1) {
             *(u32x2*)(x_last16 + (size_t)bp * H + 4 * c) = pk;
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int d = lane + 64 * e;
-        qv[e] = d < hd ? bf16_to_f32(q[(size_t)s * H + h * hd + d]) * scale : 0.f;
+        qv[e] = d < hd ? h2f(q[(size_t)s * H + h * hd + d]) * scale : 0.f;
     }
     float sc[32];
     float mx = -1e30f;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int d = lane + 64 * e;
-                if (d < hd) a = fmaf(qv[e], bf16_to_f32(kr[d]), a);
+                if (d < hd) a = fmaf(qv[e], h2f(kr[d]), a);
             }
             a = wave_sum(a);
             sc[t] = a;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int d = lane + 64 * e;
-                if (d < hd) o[e] = fmaf(sc[t], bf16_to_f32(vr[d]), o[e]);
+                if (d < hd) o[e] = fmaf(sc[t], h2f(vr[d]), o[e]);
             }
         }
     }
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int d = lane + 64 * e;
-        if (d < hd) out[(size_t)s * H + h * hd + d] = f32_to_bf16(o[e] * inv);
+        if (d < hd) out[(size_t)s * H + h * hd + d] = f2h(o[e] * inv);
     }
 }
 
@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(256) delta_finish_kernel(const float* __restri
         o = ((const float4*)(feats + ((size_t)b * T + (r - 256)) * 257 * H))[c];
     }
     u32x2 pk;
-    pk[0] = pack_bf16x2(o.x, o.y);
-    pk[1] = pack_bf16x2(o.z, o.w);
+    pk[0] = pack_h2(o.x, o.y);
+    pk[1] = pack_h2(o.z, o.w);
     *(u32x2*)(out + ((size_t)b * (256 + T) + r) * H + 4 * c) = pk;
 }
 

@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
+
+import torch
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 from . import build as _build
@@ -18,6 +20,7 @@ _P = c_void_p
 _SIGS = {
     "vly_abi_version": (c_int, []),
     "vly_last_error": (c_char_p, []),
+    "vly_storage_dtype": (c_int, []),
     "vly_gemm_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemm_tile_for": (c_int, [c_int, c_int]),
     "vly_gemm_bf16_streamk": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -65,7 +68,7 @@ _SIGS = {
     "vly_embed_splice_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ValleyHipError(RuntimeError):
@@ -73,7 +76,9 @@ class ValleyHipError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.environ.get("VALLEY_HIP_LIB", _build.LIB)
+    """libvalley_hip.so (bf16 storage) or libvalley_hip_f16.so (VALLEY_PRECISION=fp16); VALLEY_HIP_LIB overrides."""
+    from . import runtime
+    return os.environ.get("VALLEY_HIP_LIB", _build.LIB_F16 if runtime.PRECISION == "fp16" else _build.LIB)
 
 
 def load():
@@ -104,6 +109,11 @@ def _load_locked():
         fn.argtypes = args
     if lib.vly_abi_version() != ABI_VERSION:
         raise ValleyHipError(f"ABI mismatch: library {lib.vly_abi_version()} vs binding {ABI_VERSION}")
+    from . import runtime
+    want = 1 if runtime.HALF == torch.float16 else 0
+    if lib.vly_storage_dtype() != want:
+        raise ValleyHipError(f"{path} stores {'fp16' if lib.vly_storage_dtype() else 'bf16'} but VALLEY_PRECISION asks for "
+                             f"{'fp16' if want else 'bf16'} tensors")
     _LIB = lib
     return lib
 

@@ -21,6 +21,8 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+from .runtime import HALF
+
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, balanced split of n items: the first n % world ranks get one extra."""
@@ -78,7 +80,7 @@ def encode_clips_dp(encode_pool: Callable[[list], Tuple[torch.Tensor, List[int]]
             dist.all_reduce(wt, op=dist.ReduceOp.MAX, group=group)
             width = int(wt.item())
         if local is None:
-            local = torch.empty((0, width), dtype=torch.bfloat16, device=device)
+            local = torch.empty((0, width), dtype=HALF, device=device)
     return all_gather_rows(local, rows, group), Ts
 
 

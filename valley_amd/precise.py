@@ -72,6 +72,25 @@ class PreciseCLIPVisionTower:
         self.loaded = True
         return self
 
+    def init_random(self, seed: int = 0, layers: Optional[int] = None) -> "PreciseCLIPVisionTower":
+        """Random fp32 weights generated on the device (bench only: what the 1e-3 mode costs in throughput)."""
+        c = self.config
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        rn = lambda shape, std: torch.randn(shape, generator=g, device=self.device, dtype=F32) * std  # noqa: E731
+        H, I = c.hidden_size, c.intermediate_size
+        self.w_patch = torch.zeros((1024, 592), dtype=F32, device=self.device)
+        self.w_patch[:, :588] = rn((1024, 588), 0.02)
+        self.cls, self.pos = rn((H,), H ** -0.5), rn((257, H), 0.02)
+        self.pre_g, self.pre_b = torch.ones(H, device=self.device), torch.zeros(H, device=self.device)
+        in_std = H ** -0.5 * (2 * c.num_hidden_layers) ** -0.5
+        one, zero = torch.ones(H, device=self.device), torch.zeros(H, device=self.device)
+        self.layers = [dict(ln1_g=one, ln1_b=zero, ln2_g=one, ln2_b=zero, w_qkv=rn((3 * H, H), 0.02), b_qkv=rn((3 * H,), 0.02),
+                            w_o=rn((H, H), H ** -0.5), b_o=rn((H,), 0.02), w_fc1=rn((I, H), (2 * H) ** -0.5), b_fc1=rn((I,), 0.02),
+                            w_fc2=rn((H, I), in_std * 2), b_fc2=rn((H,), 0.02))
+                       for _ in range(c.num_hidden_layers if layers is None else layers)]
+        self.loaded = True
+        return self
+
     def n_layers_for(self, select_layer: int) -> int:
         n = self.config.num_hidden_layers
         idx = select_layer if select_layer >= 0 else n + 1 + select_layer
@@ -208,6 +227,20 @@ class PreciseLlama:
         self.norm = _dev(sd["model.norm.weight"], d)
         self.lm_head = torch.zeros((self.Vpad, self.H), dtype=F32, device=d)
         self.lm_head[:self.V] = _dev(sd["lm_head.weight"], d)
+        self.loaded = True
+        return self
+
+    def init_random(self, seed: int = 0, std: float = 0.02) -> "PreciseLlama":
+        """Random fp32 weights generated on the device (bench only)."""
+        d = self.device
+        g = torch.Generator(device=d).manual_seed(seed)
+        rn = lambda shape: torch.randn(shape, generator=g, device=d, dtype=F32) * std  # noqa: E731
+        self.embed = rn((self.V, self.H))
+        self.layers = [dict(ln1=torch.ones(self.H, device=d), ln2=torch.ones(self.H, device=d), w_qkv=rn((3 * self.H, self.H)),
+                            w_o=rn((self.H, self.H)), w_gu=rn((2 * self.I, self.H)), w_down=rn((self.H, self.I))) for _ in range(self.L)]
+        self.norm = torch.ones(self.H, device=d)
+        self.lm_head = torch.zeros((self.Vpad, self.H), dtype=F32, device=d)
+        self.lm_head[:self.V] = rn((self.V, self.H))
         self.loaded = True
         return self
 

@@ -8,9 +8,18 @@ concurrently, each with its own workspaces (`stream_key()` is part of every work
 uses that to run two half-batches side by side, so the tail of one GEMM is filled by the other's tiles."""
 from __future__ import annotations
 
+import os
 import threading
 
 import torch
+
+# Storage dtype of the half-precision tensors (VALLEY_PRECISION, read once at import): "bf16" (default) and "fp32" (the
+# validation engines of valley_amd/precise.py; everything else stays bf16) use libvalley_hip.so, "fp16" — the reference's own
+# inference dtype, run_valley.py:39 — uses libvalley_hip_f16.so, the same kernels compiled for IEEE half storage.
+PRECISION = os.environ.get("VALLEY_PRECISION", "bf16").lower()
+if PRECISION not in ("bf16", "fp16", "fp32"):
+    raise ValueError(f"VALLEY_PRECISION must be bf16, fp16 or fp32, got {PRECISION!r}")
+HALF = torch.float16 if PRECISION == "fp16" else torch.bfloat16
 
 _locks = {}
 _glock = threading.Lock()

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import ops, ops_f32, runtime
+from .runtime import HALF
 from .llama import HipKVCache, HipLlama
 from .precise import F32KVCache, PreciseCLIPVisionTower, PreciseLlama
 from .splice import build_row_map
@@ -63,12 +64,11 @@ else:                                                    # pragma: no cover
 
 
 def default_precision() -> str:
-    """"bf16" (production: bf16 MFMA operands, fp32 accumulation and residual stream) or "fp32" (validation: every tensor
-    fp32, exact f32 MFMA — valley_amd/precise.py), from VALLEY_PRECISION."""
-    p = os.environ.get("VALLEY_PRECISION", "bf16").lower()
-    if p not in ("bf16", "fp32"):
-        raise ValueError(f"VALLEY_PRECISION must be bf16 or fp32, got {p!r}")
-    return p
+    """"bf16" / "fp16" (production engines: 16-bit MFMA operands in the library's storage type — bf16, or IEEE fp16 like the
+    reference's own ``model.to(torch.float16)`` — fp32 accumulation and residual stream) or "fp32" (validation: every tensor
+    fp32, exact f32 MFMA — valley_amd/precise.py), from VALLEY_PRECISION (read once, valley_amd/runtime.py: the 16-bit
+    storage type is a property of the loaded library, not of a model object)."""
+    return runtime.PRECISION
 
 
 def build_vision_tower(config_or_name=None, device="cuda:0", state_dict: Optional[Dict] = None, precision: Optional[str] = None,
@@ -106,7 +106,7 @@ class HipLinear:
         if self.weight.dtype == torch.float32:               # fp32 "precise" mode
             y = ops_f32.gemm(x.reshape(-1, shp[-1]).to(torch.float32).contiguous(), self.weight, self.bias)
         else:
-            y = ops.gemm(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous(), self.weight, self.bias)
+            y = ops.gemm(x.reshape(-1, shp[-1]).to(HALF).contiguous(), self.weight, self.bias)
         return y.view(*shp[:-1], self.out_features)
 
 
@@ -121,7 +121,7 @@ class ValleyLlamaModel:
         self.patch_pooling_method = "mean"                   # :27
         c = config
         self.precision = getattr(config, "valley_precision", None) or default_precision()
-        self.wdtype = torch.float32 if self.precision == "fp32" else torch.bfloat16      # dtype of GEMM weights / activations
+        self.wdtype = torch.float32 if self.precision == "fp32" else HALF      # dtype of GEMM weights / activations
         engine = PreciseLlama if self.precision == "fp32" else HipLlama
         self.llama = engine(c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers,
                             c.vocab_size, c.rms_norm_eps, getattr(c, "rope_theta", None) or _rope_theta(c),
@@ -417,7 +417,7 @@ class ValleyLlamaForCausalLM:
                 bias=_dev(sd["model.pooling_layer.bias"], self.device, torch.float32).reshape(-1))
         pfx = "model.transformer_delta_encoder.layers.0."
         if pfx + "self_attn.in_proj_weight" in sd:            # v3 temporal transformer (valley_model.py:45-52)
-            d, bf, f32 = self.device, torch.bfloat16, torch.float32
+            d, bf, f32 = self.device, HALF, torch.float32
             H = self.config.hidden_size
             win, bin_ = _dev(sd[pfx + "self_attn.in_proj_weight"], d, bf), _dev(sd[pfx + "self_attn.in_proj_bias"], d, f32)
             self.model.delta_encoder = dict(
