@@ -309,7 +309,7 @@ def main():
     from valley_amd import valley_model as vm
     # compute dtype of the line: the library's 16-bit storage / MFMA operand type (bf16 default; VALLEY_PRECISION=fp16 runs
     # the same step on libvalley_hip_f16.so — the reference's own inference dtype)
-    DT = "fp16" if runtime.PRECISION == "fp16" else "bf16"
+    DT = runtime.PRECISION                                    # "bf16" | "fp16" | "fp32" (the validation engines)
     from valley_amd import weights as W
 
     cfg = CONFIGS[args.config]

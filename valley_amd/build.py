@@ -68,7 +68,8 @@ ABI_SMOKE = os.path.join(LIBDIR, "abi_smoke")
 
 def build_abi_smoke(verbose: bool = True) -> str:
     """The torch-free C++ host program of tests/c_abi (dlopens the library; tests/test_kernels_gpu.py runs it)."""
-    if os.path.exists(ABI_SMOKE) and os.path.getmtime(ABI_SMOKE) >= os.path.getmtime(ABI_SMOKE_SRC):
+    hdr = os.path.join(HERE, "..", "include", "valley_hip.h")          # VLY_ABI_VERSION is compiled in
+    if os.path.exists(ABI_SMOKE) and os.path.getmtime(ABI_SMOKE) >= max(os.path.getmtime(ABI_SMOKE_SRC), os.path.getmtime(hdr)):
         return ABI_SMOKE
     cmd = [hipcc(), "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", ABI_SMOKE_SRC, "-o", ABI_SMOKE, "-ldl"]
     if verbose:

@@ -42,6 +42,7 @@ def _dev(t, device, dtype):
 
 
 VIT_CHUNK = int(os.environ.get("VALLEY_VIT_CHUNK", "256"))
+QKV_SPLIT = os.environ.get("VALLEY_VIT_QKV_SPLIT", "0") == "1"      # measurement switch: row split (ops.row_split) for q|k|v too
 
 
 class HipCLIPVisionTower:
@@ -177,7 +178,10 @@ class HipCLIPVisionTower:
             ops.add_norm(h, ws["delta"], L["ln1_g"], L["ln1_b"], eps, out=ws["x"], delta2=d2)
         else:
             ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
-        ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        if QKV_SPLIT:
+            ops.gemm_split(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        else:
+            ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
         # M = F*257 rows: the *_split forms cut a launch at a multiple of 4096 rows so that the main launch is a whole
         # number of workgroup rounds and hand the F-row remainder to the latency-optimised skinny kernel (ops.row_split;
