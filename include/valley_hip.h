@@ -70,21 +70,19 @@ int         vly_storage_dtype(void);
  *   (hf:clip/modeling_clip.py:148-154,209), q/k/v/out_proj (:293-296), fc1/fc2 (:343-344),
  *   mm_projector (valley_model.py:54-55,190), Llama q/k/v/o (hf:llama/modeling_llama.py:230-241),
  *   gate/up/down (:166-168), lm_head (valley_model.py:264,305).
- *   tile_hint: 0 = auto, 1 = 256x256, 2 = 128x128, 3 = 256x128, 4 = 128x256, 5 = 192x256, 6 = 192x192,
- *   7 = 128x192, 8 = 192x128, 9 = 256x256 with 16 waves (BM x BN).  Tiles 7 and 8 use 80 KB of LDS so that TWO workgroups share a CU and
- *   cover each other's prologue and epilogue: the fastest choice for the K = 1024 ViT GEMMs.
- *   Loop variants (tuning / tests): +10 counted-vmcnt half-tile pipeline; +30 / +50 (8-wave tiles) role-split
- *   pipelines (the two waves of a SIMD run one phase apart; +50 keeps whole-K-tile staging with 128-byte LDS
- *   rows); +70 (tiles 3, 4, 6: stage <= 53 KB) THREE whole-K-tile stages, i.e. two K tiles of glds loads in
- *   flight (LDS-DMA issue -> landed is ~2600 clk, more than one K tile of MFMA work on these tiles); +80 =
- *   +70 with the role split of +50; 93 / 94 = 256x128 / 128x256 with 16 waves and three stages; 95 / 96 = 224x256
- *   (8 waves; 2-stage / role split).  97 / 98 / 99 = 256x256 / 224x256 / 192x256 with FOUR waves (one per SIMD,
- *   a (BM/2) x 128 accumulator block each, 512 registers per lane; DESIGN.md "the 4-wave kernels"); 197 / 198 / 199 =
- *   the same tiles in the PERSISTENT kernel (one workgroup per CU walks the tiles, register-only epilogue; bf16
- *   outputs whose rows are not 16-byte aligned, bf16 + residual and K < 128 fall back to 97 / 98 / 99; not for the
- *   split-K pair or the RoPE epilogue).
- *   ldw = VLY_LDW_PACKED64: W points to the block layout written by vly_pack_weight_bf16 (not with the +10 / +30
- *   half-tile loops). */
+ *   tile_hint: 0 = auto, otherwise the kernel a tuner picked (valley_amd/tuned/gfx950.json; every hint computes the same
+ *   product up to fp32 summation order).  BM x BN tiles, K tile 64:
+ *     1 = 256x256, 2 = 128x128, 3 = 256x128, 4 = 128x256, 5 = 192x256, 6 = 192x192 (8 waves, two LDS stages);
+ *     7 = 128x192, 8 = 192x128 (80 KB of LDS: TWO workgroups share a CU and cover each other's prologue / epilogue);
+ *     9 = 256x256 with 16 waves;   51, 53, 54, 55 = tiles 1, 3, 4, 5 with the wave role split (the two waves of a SIMD run
+ *     one phase apart);   73, 74, 76 = tiles 3, 4, 6 with THREE stages (two K tiles of LDS-DMA in flight), 83, 84, 86 = the
+ *     same with the role split;   93 / 94 = 256x128 / 128x256, 16 waves, three stages;
+ *     97 / 98 / 99 = 256x256 / 224x256 / 192x256 with FOUR waves (one per SIMD, a (BM/2) x 128 accumulator block each, 512
+ *     registers per lane; DESIGN.md "the 4-wave kernels");   197 / 198 / 199 = the same tiles in the PERSISTENT kernel (one
+ *     workgroup per CU walks the tiles, register-only epilogue, outputs through a clipping buffer descriptor — the hot
+ *     path's kernel; bf16 outputs whose rows are not 16-byte aligned or whose width is not a multiple of 8, bf16 +
+ *     residual, outputs of 2 GB or more and K < 128 fall back to 97 / 98 / 99; not for the split-K pair).
+ *   ldw = VLY_LDW_PACKED64: W points to the block layout written by vly_pack_weight_bf16. */
 int vly_gemm_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, int tile_hint, void *stream);

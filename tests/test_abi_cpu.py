@@ -83,7 +83,7 @@ def test_shipped_tuning_table_is_consistent():
     path = os.path.join(os.path.dirname(ops.__file__), "tuned", "gfx950.json")
     ents = json.load(open(path))
     assert len(ents) >= 11
-    known = set(ops.CANDIDATES) | set(ops.SPLIT_CANDIDATES) | {("tile", 57), ("tile", 56)}
+    known = set(ops.CANDIDATES) | set(ops.SPLIT_CANDIDATES)
     for e in ents:
         assert (e["kind"], e["tile"]) in known, e
         assert e["key"][4] in ("torch.bfloat16", "torch.float32")

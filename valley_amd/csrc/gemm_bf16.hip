@@ -64,43 +64,24 @@ namespace {
 
 constexpr int BK = 64;            // K tile (elements) = 128 bytes per row = 8 chunks of 16 B
 
-// One K tile (BK = 64 = two MFMA K steps) of a wave's MI x NI fragments from a 128-byte-row LDS stage.
-// VLY_FRAG_ORDER (kept switchable for tools/ab_lib.py A/B builds):
-//   0  reads and MFMAs in source order, scheduled by the compiler — it settles on {2 reads, lgkmcnt(0), 4 MFMAs} x 6
-//      per K tile: six exposed LDS round trips per wave and K tile;
-//   1  all reads of a K step, then its MFMAs: two exposed round trips;
-//   2  the reads of both K steps first: one round trip but 64 fragment VGPRs (the 2-per-CU tiles lose their second
-//      workgroup, the 16-wave tile spills);
-//   3  (default) K step 1's fragments are requested BETWEEN K step 0's MFMAs, each into the registers the finished
-//      MFMAs freed: one exposed round trip, +8..11 VGPRs.  Interleaved A/B against 0 on cold weights (tools/ab_lib.py):
-//      +1.0..2.7 % on the 2-stage loops, +5.9 % on the 3-stage 192x192 loop; 1 is within noise of 0.
-#ifndef VLY_A_CPOL
-#define VLY_A_CPOL 0      // cache policy of the activation / weight staging loads (glds16_cp)
-#endif
-#ifndef VLY_W_CPOL
-#define VLY_W_CPOL 0
-#endif
-#ifndef VLY_MMA_PRIO
-#define VLY_MMA_PRIO 0    // 1: s_setprio 1 over the MFMAs of mma_ktile (the role-split loops always do)
-#endif
+// One K tile (BK = 64 = two MFMA K steps) of a wave's MI x NI fragments from a 128-byte-row LDS stage: K step 1's fragments
+// are requested BETWEEN K step 0's MFMAs, each into the registers the finished MFMAs freed — one exposed LDS round trip per
+// K tile instead of the six the compiler's own order ({2 reads, lgkmcnt(0), 4 MFMAs} x 6) leaves; +1.0..2.7 % on the
+// 2-stage loops, +5.9 % on the 3-stage 192x192 loop (interleaved A/B on cold weights, round 1; the other orders that were
+// tried — source order, all reads of a step first, both steps first — are in the history of this file and DESIGN.md §4).
 // ldw == VLY_LDW_PACKED64: W is stored as [K/64][ceil(N/64)][64 rows][64 k] blocks (vly_pack_weight_bf16) — every K
 // tile of a weight panel is one contiguous run in HBM instead of one 128-byte line out of each 2*K-byte row
 VLY_DEVICE uint32_t w_row_off(int n, int ldw) {
     return ldw < 0 ? (uint32_t)(n >> 6) * 4096u + (uint32_t)(n & 63) * 64u : (uint32_t)n * (uint32_t)ldw;
 }
-#ifndef VLY_FRAG_ORDER
-#define VLY_FRAG_ORDER 3
-#endif
 template <int MI, int NI>
 VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, int sw0, int sw1) {
-#if VLY_FRAG_ORDER == 3
     bf16x8 a0[MI], w0[NI], a1[MI], w1[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) w0[j] = *(const bf16x8*)(pw + j * 2048 + sw0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(pa + i * 2048 + sw0);
     __builtin_amdgcn_sched_barrier(0);
-    if (VLY_MMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -116,110 +97,13 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(w1[j], a1[i], acc[i][j]);
-    if (VLY_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-#elif VLY_FRAG_ORDER == 2
-    bf16x8 af[2][MI], wf[2][NI];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int sw = kk ? sw1 : sw0;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) wf[kk][j] = *(const bf16x8*)(pw + j * 2048 + sw);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[kk][i] = *(const bf16x8*)(pa + i * 2048 + sw);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[kk][j], af[kk][i], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#else
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int sw = kk ? sw1 : sw0;
-        bf16x8 af[MI], wf[NI];
-#if VLY_FRAG_ORDER == 1
-#pragma unroll
-        for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(pw + j * 2048 + sw);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(pa + i * 2048 + sw);
-        __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(pa + i * 2048 + sw);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(pw + j * 2048 + sw);
-#endif
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-#if VLY_FRAG_ORDER == 1
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-#endif
 }
 
-// VLY_MFMA32=1 (A/B builds, tools/ab_lib.py; written at the end of round 1, one hardware run: correct, 9-14 % slower
-// than the 16x16x32 loops — see VLY_SWZ_KEY below; the default build does not contain a single token of it): wave tiles that are multiples of 32 in both dimensions run
-// on v_mfma_f32_32x32x16_bf16 — half the operand-register reads per flop, 1.9 instead of 1.5 PFLOP/s sustained on
-// random operands (tools/probes/mfma_shapes.hip).  Fragment = 32 rows x 16 k: lane <-> row (lane & 31) and K group
-// (lane >> 5) of 8 elements; four K steps per 64-wide K tile, chunk = 2*step + (lane >> 5).  Result block: register
-// r of the 16 holds C[m = lane & 31][n = 8*(r/4) + 4*(lane >> 5) + r % 4] (operands swapped as in the 16x16 path:
-// the W fragment is the MFMA's first operand).
-#ifndef VLY_MFMA32
-#define VLY_MFMA32 0
-#endif
-// Chunk swizzle key of the LDS stage rows (applied to the staging SOURCE address and to the fragment reads).  row & 7 is
-// conflict-free for the 16-row fragments; the 32-row fragments of the 32x32x16 path see 2-way bank conflicts with it
-// (ds_read_b128 serves lanes {0-3, 12-15, 20-27} together: rows 12 and 20 share row & 7 and row parity) — first
-// hardware run of VLY_MFMA32=1: bit-compatible results, but 9-14 % SLOWER than the 16x16x32 kernels
-// (profiles/r01_ab_lib_v17.jsonl).  VLY_MFMA32=2 switches those instantiations to (row >> 1) & 7, which is distinct
-// over every lane group of the 32-row read; that variant has not run on hardware yet.
-#if VLY_MFMA32 == 2
-#define VLY_SWZ_KEY(row) (M32 ? ((row) >> 1) & 7 : (row) & 7)
-#else
-#define VLY_SWZ_KEY(row) (row & 7)
-#endif
-typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
-
-[[maybe_unused]] VLY_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-#if VLY_MFMA32
-
-// One K tile of a wave's MI2 x NI2 blocks of 32x32; sw[s] = swizzled byte offset of K step s inside a 128-byte row.
-// Step s+1's fragments are requested between step s's MFMAs (as in mma_ktile).
-template <int MI2, int NI2>
-VLY_DEVICE void mma_ktile32(f32x16 (&acc)[MI2][NI2], const char* pa, const char* pw, const int (&sw)[4]) {
-    bf16x8 af[2][MI2], wf[2][NI2];
-#pragma unroll
-    for (int j = 0; j < NI2; ++j) wf[0][j] = *(const bf16x8*)(pw + j * 4096 + sw[0]);
-#pragma unroll
-    for (int i = 0; i < MI2; ++i) af[0][i] = *(const bf16x8*)(pa + i * 4096 + sw[0]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-#pragma unroll
-        for (int i = 0; i < MI2; ++i) {
-#pragma unroll
-            for (int j = 0; j < NI2; ++j) acc[i][j] = mfma32(wf[cur][j], af[cur][i], acc[i][j]);
-            if (s < 3) {
-                if (i == 0) {
-#pragma unroll
-                    for (int j = 0; j < NI2; ++j) wf[nxt][j] = *(const bf16x8*)(pw + j * 4096 + sw[s + 1]);
-                }
-                af[nxt][i] = *(const bf16x8*)(pa + i * 4096 + sw[s + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-#endif
+// (The 32x32x16 MFMA variants of these loops — half the operand reads per flop — measured 7-10 % SLOWER in rounds 1 and 2,
+// with and without a conflict-free swizzle for their 32-row fragments: DESIGN.md §4; the code is in the round-2 history.)
+// Chunk swizzle of the LDS stage rows, applied to the staging SOURCE address and to the fragment reads: chunk ^= row & 7,
+// conflict-free for the 16-row fragments of the 16x16x32 MFMA.
 
 // placement constants of the 4-wave loops (A/B of other placements: profiles/r02/r02_ab_4wave.txt)
 constexpr int P8_BAR_GAP = 8;       // barrier A this many MFMAs (~140 clk, a ds_read round trip) after the last read of phase 1
@@ -245,15 +129,7 @@ VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[N
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            if constexpr (sizeof(acc[0][0]) == sizeof(f32x16)) {
-                // timing experiment only (WRONG results): half as many 32x32x16 MFMAs fed from the same fragment registers
-                if (j == 1) acc[i][0] = mfma32(wf[0], af[i], acc[i][0]);
-                if (j == 3) acc[i][1] = mfma32(wf[1], wf[2], acc[i][1]);
-                if (j == 5) acc[i][0] = mfma32(wf[3], wf[4], acc[i][0]);
-                if (j == 7) acc[i][1] = mfma32(wf[5], wf[6], acc[i][1]);
-            } else {
-                acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-            }
+            acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
             const int t = i * NI + j;
             if (N1 > 0 && t >= S1 && (t - S1) % D1 == 0 && (t - S1) / D1 < N1) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -364,24 +240,6 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     // M = 2688 or F*257) keeps staging and meeting the barriers but skips its fragment reads and MFMAs: the tile then
     // costs its SIMD partner's share only, and the last round of a launch is shorter
     const bool wave_live = __builtin_amdgcn_readfirstlane((m0 + wm0 < M && n0 + wn0 < N) ? 1 : 0) != 0;
-#if VLY_MFMA32
-    // 32x32x16 path: whole-K-tile loops only, wave tile a multiple of 32 both ways
-    constexpr bool M32 = WM % 32 == 0 && WN % 32 == 0 && (PIPE == 0 || PIPE == 4 || PIPE == 6 || PIPE == 7);
-    constexpr int MI2 = M32 ? WM / 32 : 1, NI2 = M32 ? WN / 32 : 1;
-    const int l31 = lane & 31, hk = lane >> 5;
-    [[maybe_unused]] f32x16 acc32[MI2][NI2];
-    [[maybe_unused]] int sw32[4];
-    if constexpr (M32) {
-#pragma unroll
-        for (int i = 0; i < MI2; ++i)
-#pragma unroll
-            for (int j = 0; j < NI2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) sw32[st] = ((2 * st + hk) ^ (VLY_MFMA32 == 2 ? (l31 >> 1) & 7 : l31 & 7)) << 4;
-    }
-#endif
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -401,13 +259,13 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
             const int gr = min(m0 + row, M - 1);
-            offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offA[p] = (uint32_t)gr * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
             const int gr = min(n0 + row, N - 1);
-            offW[p] = w_row_off(gr, ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offW[p] = w_row_off(gr, ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -416,9 +274,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
             for (int p = 0; p < PA; ++p)
                 if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
-                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+                    glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         // row & 7 == l15 & 7 for every fragment row (all bases are multiples of 16)
         const int rdA = (wm0 + l15) * 128, rdW = (wn0 + l15) * 128;
@@ -431,91 +289,8 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sW = sA + A_BYTES;
             if (!wave_live) continue;
-#if VLY_MFMA32
-            if constexpr (M32) mma_ktile32<MI2, NI2>(acc32, sA + (wm0 + l31) * 128, sW + (wn0 + l31) * 128, sw32);
-            else
-#endif
             mma_ktile<MI, NI>(acc, sA + rdA, sW + rdW, sw0, sw1);
         }
-    } else if constexpr (PIPE == 3) {
-        // ================= role-split half-tile pipeline (8 waves) ==========================================
-        // PMC on the 2-stage loop: MFMA pipe busy 50 %, waves parked 36 % — every wave of the workgroup is in
-        // the same state at the same time (all loading after the barrier, then all multiplying), so the
-        // two waves that share a SIMD cannot cover for each other.  Here waves 0-3 (group 0) and waves 4-7
-        // (group 1: same SIMDs) run the SAME phase sequence  R(p) = {issue loads of half-tile p+3, ds_read
-        // fragments of p},  M(p) = {MFMAs of p}  but group 1 runs one phase behind (one extra barrier up
-        // front, one extra at the end for group 0): while one wave of a SIMD multiplies, its partner loads.
-        // LDS = 4 half-tile regions (as PIPE 1), loads 1.5 K tiles ahead, counted vmcnt, raw barriers.
-        static_assert(NW == 8, "role-split pipeline needs two waves per SIMD");
-        constexpr int HA = BM * 64, REGION = (BM + BN) * 64;
-        constexpr int PAH = (BM * 4 + NT - 1) / NT, PWH = (BN * 4 + NT - 1) / NT, LPH = PAH + PWH;
-        uint32_t offA[PAH], offW[PWH];
-        int dstA[PAH], dstW[PWH];
-#pragma unroll
-        for (int p = 0; p < PAH; ++p) {
-            int sb = p * NT + wave * 64;
-            if (sb >= BM * 4) sb -= (PAH * NT - BM * 4);
-            const int s = sb + lane, row = s >> 2, cp = s & 3;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
-            dstA[p] = sb * 16;
-        }
-#pragma unroll
-        for (int p = 0; p < PWH; ++p) {
-            int sb = p * NT + wave * 64;
-            if (sb >= BN * 4) sb -= (PWH * NT - BN * 4);
-            const int s = sb + lane, row = s >> 2, cp = s & 3;
-            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
-            dstW[p] = HA + sb * 16;
-        }
-        auto stage_half = [&](int p) {
-            char* reg = smem + (p & 3) * REGION;
-            const int k0 = p * 32;
-#pragma unroll
-            for (int q = 0; q < PAH; ++q) glds16_cp<VLY_A_CPOL>(A + offA[q] + k0, reg + dstA[q]);
-#pragma unroll
-            for (int q = 0; q < PWH; ++q) glds16_cp<VLY_W_CPOL>(W + offW[q] + k0, reg + dstW[q]);
-        };
-        auto wait_ahead = [&](int ahead) {                       // leave `ahead` half tiles of my loads in flight
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPH) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPH) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        const int swz = (g ^ ((l15 >> 2) & 2)) << 4;
-        const int rdA = (wm0 + l15) * 64 + swz, rdW = HA + (wn0 + l15) * 64 + swz;
-        const int P = 2 * nk;
-        const int grp = wave >> 2;                                  // wave-uniform (readfirstlane'd above)
-
-        stage_half(0);
-        if (P > 1) stage_half(1);
-        if (P > 2) stage_half(2);
-        wait_ahead(min(2, P - 1));                                  // half tile 0 landed (mine)
-        __builtin_amdgcn_s_barrier();                               // ... and everyone's
-        if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 starts one phase late
-        for (int p = 0; p < P; ++p) {
-            // ---------------- R(p)
-            if (p + 3 < P) stage_half(p + 3);
-            const char* reg = smem + (p & 3) * REGION;
-            bf16x8 af[MI], wf[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(reg + rdW + j * 1024);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(reg + rdA + i * 1024);
-            if (grp == 1) wait_ahead(min(2, P - 2 - p));            // my loads of half tile p+1 landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---------------- M(p)
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            if (grp == 0) wait_ahead(min(2, P - 2 - p));
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (grp == 0) __builtin_amdgcn_s_barrier();
     } else if constexpr (PIPE == 4) {
         // ================= role-split over the 2-stage full-tile buffers (8 waves) ==========================
         // Same staging as PIPE 0 (whole K tiles, 128-byte LDS rows -> full-line global reads), but the K tile
@@ -528,12 +303,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -542,9 +317,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
             for (int p = 0; p < PA; ++p)
                 if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
-                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+                    glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
         const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
@@ -562,23 +337,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 if (kk == 0 && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
                 const int sw = kk ? sw1 : sw0;
                 bf16x8 af[MI], wf[NI];
-#if VLY_MFMA32
-                [[maybe_unused]] bf16x8 af2[2][MI2], wf2[2][NI2];           // two K steps of 16 per phase
-#endif
                 if (wave_live) {
-#if VLY_MFMA32
-                if constexpr (M32) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                        for (int j = 0; j < NI2; ++j)
-                            wf2[st][j] = *(const bf16x8*)(cur + A_BYTES + (wn0 + l31) * 128 + j * 4096 + sw32[2 * kk + st]);
-#pragma unroll
-                        for (int i = 0; i < MI2; ++i)
-                            af2[st][i] = *(const bf16x8*)(cur + (wm0 + l31) * 128 + i * 4096 + sw32[2 * kk + st]);
-                    }
-                } else
-#endif
                 {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
@@ -593,16 +352,6 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 // ---------------- M phase
                 __builtin_amdgcn_s_setprio(1);
                 if (wave_live) {
-#if VLY_MFMA32
-                if constexpr (M32) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-#pragma unroll
-                        for (int i = 0; i < MI2; ++i)
-#pragma unroll
-                            for (int j = 0; j < NI2; ++j) acc32[i][j] = mfma32(wf2[st][j], af2[st][i], acc32[i][j]);
-                } else
-#endif
                 {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -628,12 +377,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -642,9 +391,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
             for (int p = 0; p < PA; ++p)
                 if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
-                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+                    glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
         const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
@@ -660,10 +409,6 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
             if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);                           // (kt+2) % 3
             const char* cur = smem + buf * STAGE;
             if (wave_live) {
-#if VLY_MFMA32
-            if constexpr (M32) mma_ktile32<MI2, NI2>(acc32, cur + (wm0 + l31) * 128, cur + A_BYTES + (wn0 + l31) * 128, sw32);
-            else
-#endif
             mma_ktile<MI, NI>(acc, cur + rdA, cur + rdW, sw0, sw1);
             }
             buf = buf == 2 ? 0 : buf + 1;
@@ -701,18 +446,18 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             const int sl = q * NT + tid, row = sl >> 3, cp = sl & 7;
-            voA[q] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3)) * 2u;
+            voA[q] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3)) * 2u;
         }
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
             const int sl = q * NT + tid, row = sl >> 3, cp = sl & 7;
-            voW[q] = (w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3)) * 2u;
+            voW[q] = (w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3)) * 2u;
         }
         const __amdgpu_buffer_rsrc_t rsA = vly_rsrc(A), rsW = vly_rsrc(W);
         auto piece = [&](int kt, int buf, int q) {
             char* st = smem + buf * STAGE;
-            if (q < PA) bglds16<VLY_A_CPOL>(rsA, voA[q < PA ? q : 0], (uint32_t)kt * (BK * 2u), st + (q * NT + wave * 64) * 16);
-            else bglds16<VLY_W_CPOL>(rsW, voW[q >= PA ? q - PA : 0], (uint32_t)kt * wk * 2u, st + A_BYTES + ((q - PA) * NT + wave * 64) * 16);
+            if (q < PA) bglds16<0>(rsA, voA[q < PA ? q : 0], (uint32_t)kt * (BK * 2u), st + (q * NT + wave * 64) * 16);
+            else bglds16<0>(rsW, voW[q >= PA ? q - PA : 0], (uint32_t)kt * wk * 2u, st + A_BYTES + ((q - PA) * NT + wave * 64) * 16);
         };
         const int rdA = (wm0 + l15) * 128, rdW = A_BYTES + (wn0 + l15) * 128;
         const int sw0 = ((0 + g) ^ (l15 & 7)) << 4, sw1 = ((4 + g) ^ (l15 & 7)) << 4;
@@ -799,12 +544,12 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ (row & 7)) << 3);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int s = p * NT + tid, row = s >> 3, cp = s & 7;
-            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ VLY_SWZ_KEY(row)) << 3);
+            offW[p] = w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3);
         }
         auto stage = [&](int kt, int buf) {
             char* sA = smem + buf * STAGE;
@@ -813,9 +558,9 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 #pragma unroll
             for (int p = 0; p < PA; ++p)
                 if (!A_RAGGED || p + 1 < PA || (p * NT + wave * 64) < BM * 8)
-                    glds16_cp<VLY_A_CPOL>(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
+                    glds16(A + offA[p] + k0, sA + (p * NT + wave * 64) * 16);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) glds16_cp<VLY_W_CPOL>(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
+            for (int p = 0; p < PW; ++p) glds16(W + offW[p] + kt * wk, sW + (p * NT + wave * 64) * 16);
         };
         auto wait_next = [&](int kt) {                              // my loads of tile kt+1 landed; kt+2 may fly
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PA + PW) : "memory");
@@ -839,23 +584,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 if (kk == 0 && kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);
                 const int sw = kk ? sw1 : sw0;
                 bf16x8 af[MI], wf[NI];
-#if VLY_MFMA32
-                [[maybe_unused]] bf16x8 af2[2][MI2], wf2[2][NI2];           // two K steps of 16 per phase
-#endif
                 if (wave_live) {
-#if VLY_MFMA32
-                if constexpr (M32) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                        for (int j = 0; j < NI2; ++j)
-                            wf2[st][j] = *(const bf16x8*)(cur + A_BYTES + (wn0 + l31) * 128 + j * 4096 + sw32[2 * kk + st]);
-#pragma unroll
-                        for (int i = 0; i < MI2; ++i)
-                            af2[st][i] = *(const bf16x8*)(cur + (wm0 + l31) * 128 + i * 4096 + sw32[2 * kk + st]);
-                    }
-                } else
-#endif
                 {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(cur + rdW + j * 2048 + sw);
@@ -870,16 +599,6 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                 // ---------------- M phase
                 __builtin_amdgcn_s_setprio(1);
                 if (wave_live) {
-#if VLY_MFMA32
-                if constexpr (M32) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-#pragma unroll
-                        for (int i = 0; i < MI2; ++i)
-#pragma unroll
-                            for (int j = 0; j < NI2; ++j) acc32[i][j] = mfma32(wf2[st][j], af2[st][i], acc32[i][j]);
-                } else
-#endif
                 {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -896,70 +615,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
     } else {
-        // ================= 4-region half-tile pipeline: counted vmcnt, raw barrier ======================
-        // The K loop advances in HALF tiles (32 k = one MFMA k-step = 64-byte LDS rows).  LDS holds four
-        // half-tile regions; the loads of half-tile p+3 are issued while half-tile p is computed, so 1.5
-        // K tiles are always in flight and vmcnt never drains inside the loop.  Per phase:
-        //     s_waitcnt vmcnt(2*LPH)   this lane's loads of half-tile p have landed
-        //     s_barrier                everyone's have, and everyone finished reading region (p-1)&3
-        //     issue loads of p+3 into region (p+3)&3 == (p-1)&3
-        //     ds_read_b128 fragments of p, MFMAs.
-        // 64-byte rows: chunk' = chunk ^ ((row >> 2) & 2) is conflict-free for ds_read_b128's lane groups.
-        constexpr int HA = BM * 64, REGION = (BM + BN) * 64;      // bytes
-        constexpr int PAH = (BM * 4 + NT - 1) / NT, PWH = (BN * 4 + NT - 1) / NT, LPH = PAH + PWH;
-        static_assert(4 * REGION == 2 * STAGE, "LDS budget");
-        uint32_t offA[PAH], offW[PWH];
-        int dstA[PAH], dstW[PWH];
-#pragma unroll
-        for (int p = 0; p < PAH; ++p) {
-            int sb = p * NT + wave * 64;                           // wave-uniform slot base
-            if (sb >= BM * 4) sb -= (PAH * NT - BM * 4);            // surplus waves repeat earlier rows (same data)
-            const int s = sb + lane, row = s >> 2, cp = s & 3;
-            offA[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
-            dstA[p] = sb * 16;
-        }
-#pragma unroll
-        for (int p = 0; p < PWH; ++p) {
-            int sb = p * NT + wave * 64;
-            if (sb >= BN * 4) sb -= (PWH * NT - BN * 4);
-            const int s = sb + lane, row = s >> 2, cp = s & 3;
-            offW[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + (uint32_t)((cp ^ ((row >> 2) & 2)) << 3);
-            dstW[p] = HA + sb * 16;
-        }
-        auto stage_half = [&](int p) {
-            char* reg = smem + (p & 3) * REGION;
-            const int k0 = p * 32;
-#pragma unroll
-            for (int q = 0; q < PAH; ++q) glds16_cp<VLY_A_CPOL>(A + offA[q] + k0, reg + dstA[q]);
-#pragma unroll
-            for (int q = 0; q < PWH; ++q) glds16_cp<VLY_W_CPOL>(W + offW[q] + k0, reg + dstW[q]);
-        };
-        const int swz = (g ^ ((l15 >> 2) & 2)) << 4;
-        const int rdA = (wm0 + l15) * 64 + swz, rdW = HA + (wn0 + l15) * 64 + swz;
-        const int P = 2 * nk;                                      // half tiles
-
-        stage_half(0);
-        if (P > 1) stage_half(1);
-        if (P > 2) stage_half(2);
-        for (int p = 0; p < P; ++p) {
-            const int ahead = min(2, P - 1 - p);                   // half tiles allowed to stay in flight
-            if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPH) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPH) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (p + 3 < P) stage_half(p + 3);
-            const char* reg = smem + (p & 3) * REGION;
-            bf16x8 af[MI], wf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(reg + rdA + i * 1024);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(reg + rdW + j * 1024);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-        }
+        static_assert(PIPE == 0, "unknown K-loop variant");   // (the half-tile loops of rounds 1-2, tile hints +10 / +30, never won a shape and are gone)
     }
 
     // ---- epilogue: lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g ----------------------
@@ -967,35 +623,10 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
     // 128-byte line per instruction; tools/probes/store_pattern.hip: 3.0 TB/s for the 67 MB ViT fc1 output),
     // so the tile is first assembled in LDS and then written as full lines, 16 bytes per lane with
     // consecutive lanes along the row (4.6 TB/s).  The fused bias / activation / residual math is unchanged.
-#if VLY_MFMA32
-    // hand the 32x32 result blocks to the epilogue as the f32x4 groups it works on — group q of block (I, J) becomes
-    // acc[2I + (q >> 1)][2J + (q & 1)]; its row is lane & 31 of block I, its 4 columns start at 8q + 4*(lane >> 5)
-    if constexpr (M32) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int q = ((i & 1) << 1) | (j & 1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][4 * q + r];
-            }
-    }
-    auto frag_row = [&](int i) { return M32 ? wm0 + (i >> 1) * 32 + l31 : wm0 + i * 16 + l15; };
-    auto frag_col = [&](int i, int j) {
-        return M32 ? wn0 + (j >> 1) * 32 + ((((i & 1) << 1) | (j & 1)) << 3) + (hk << 2) : wn0 + j * 16 + g * 4;
-    };
-    constexpr int EPI_NH = (M32 && MI % 4 != 0) ? 1 : 2;      // an odd number of 32-row blocks leaves in one pass
-#define VLY_FRAG_ROW(i) frag_row(i)
-#define VLY_FRAG_COL(i, j) frag_col(i, j)
-#else
 #define EPI_NH (MI % 2 == 0 ? 2 : 1)        /* an odd number of 16-row fragments per wave leaves in one pass */
 #define VLY_FRAG_ROW(i) wm0 + i * 16 + l15
 #define VLY_FRAG_COL(i, j) wn0 + j * 16 + g * 4
-#endif
-#ifdef VLY_DBG_NO_EPILOGUE                                    /* timing experiment (WRONG results): what do the stores cost? */
-    if (PIPE == 8 && acc[0][0][0] != 12345.678f) return;
-#endif
-    if constexpr (OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE && NI % 4 == 0 && !VLY_MFMA32) {
+    if constexpr (OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE && NI % 4 == 0) {
         if (wide == 2) {
             // ---- full-line stores WITHOUT LDS: the four lanes that hold a row (g = 0 .. 3, sixteen lanes apart) trade
             // register halves with v_permlane16_swap / v_permlane32_swap (gfx950) until each holds 16 contiguous bytes:
@@ -1202,10 +833,7 @@ gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
 
 #undef VLY_FRAG_ROW
 #undef VLY_FRAG_COL
-#undef VLY_SWZ_KEY
-#if !VLY_MFMA32
 #undef EPI_NH
-#endif
 
 // Read one accumulator block where it is USED: the "a" constraint keeps the value in the accumulation registers up to this
 // point (left alone, hipcc copies half of the 256 accumulators into VGPRs at the top of the epilogue and spills the K loop's
@@ -1654,7 +1282,7 @@ int launch_tile(const void* A, const void* W, const float* bias, const float* R,
     else if (epi == VLY_EPI_QKV_ROPE && out == VLY_OUT_BF16 && rope) {
         // a head's two halves must sit in one tile (BN % 128 == 0) and the epilogue works on the LDS image (wide);
         // PIPE 1 / 3 (half-tile loops) are not instantiated for it
-        if constexpr (BN % 128 == 0 && PIPE != 1 && PIPE != 3) {
+        if constexpr (BN % 128 == 0) {
             if (!wide) { vly_set_error("vly_gemm_bf16_qkv_rope: qkv rows must be 16-byte aligned"); return -22; }
             VLY_GEMM_LAUNCH(VLY_EPI_QKV_ROPE, VLY_OUT_BF16);
         } else {
@@ -1700,10 +1328,6 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
                     void* C2, const RopeArgs* rope = nullptr) {
 #define VLY_TILE_ARGS A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
 #define VLY_TILE_ARGS_RAW A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
-    if (ldw < 0 && ((t >= 11 && t <= 15) || (t >= 31 && t <= 35))) {
-        vly_set_error("vly_gemm_bf16: the half-tile loops (tile_hint %d) read row-major weights only", tile_hint);
-        return -22;
-    }
 #ifdef VLY_FEW_TILES                                        /* fast A/B builds (tools/ab_lib.py): only the tiles under study */
     switch (t) {
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
@@ -1715,18 +1339,12 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         default: vly_set_error("vly_gemm_bf16: tile_hint %d is not in this VLY_FEW_TILES build", tile_hint); return -22;
     }
 #else
-    switch (t) {                                          // 1..5: 2-stage loop; 11..15: counted-vmcnt half-tile pipeline; 31..35: role-split over half tiles;
-                                                          // 51..55: role-split over the full-tile 2-stage buffers
+    switch (t) {                                          // 1..9: 2-stage loop; 51..55: role split over the 2-stage buffers; 7x / 8x: three stages
         case 1: return launch_tile<256, 256, 128, 64, 0>(VLY_TILE_ARGS);
         case 2: return launch_tile<128, 128, 64, 64, 0>(VLY_TILE_ARGS);
         case 3: return launch_tile<256, 128, 64, 64, 0>(VLY_TILE_ARGS);
         case 4: return launch_tile<128, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 5: return launch_tile<192, 256, 96, 64, 0>(VLY_TILE_ARGS);
-        case 11: return launch_tile<256, 256, 128, 64, 1>(VLY_TILE_ARGS);
-        case 12: return launch_tile<128, 128, 64, 64, 1>(VLY_TILE_ARGS);
-        case 13: return launch_tile<256, 128, 64, 64, 1>(VLY_TILE_ARGS);
-        case 14: return launch_tile<128, 256, 64, 64, 1>(VLY_TILE_ARGS);
-        case 15: return launch_tile<192, 256, 96, 64, 1>(VLY_TILE_ARGS);
         case 73: return launch_tile<256, 128, 64, 64, 6>(VLY_TILE_ARGS);
         case 74: return launch_tile<128, 256, 64, 64, 6>(VLY_TILE_ARGS);
         case 76: return launch_tile<192, 192, 96, 48, 6>(VLY_TILE_ARGS);
@@ -1734,19 +1352,13 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 83: return launch_tile<256, 128, 64, 64, 7>(VLY_TILE_ARGS);
         case 84: return launch_tile<128, 256, 64, 64, 7>(VLY_TILE_ARGS);
         case 86: return launch_tile<192, 192, 96, 48, 7>(VLY_TILE_ARGS);
-        case 56: return launch_tile<192, 192, 96, 48, 4>(VLY_TILE_ARGS);
         // 128x192: 40 KB per stage, two 2-stage workgroups per CU (each covers the other's prologue / epilogue)
         case 7: return launch_tile<128, 192, 64, 48, 0>(VLY_TILE_ARGS);
-        case 57: return launch_tile<128, 192, 64, 48, 4>(VLY_TILE_ARGS);
         case 8: return launch_tile<192, 128, 96, 32, 0>(VLY_TILE_ARGS);
         // 16 waves (4 x 4): four waves per SIMD hide LDS / barrier latency without the role split
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 93: return launch_tile<256, 128, 64, 32, 6>(VLY_TILE_ARGS);
         case 94: return launch_tile<128, 256, 32, 64, 6>(VLY_TILE_ARGS);
-        // 224 x 256: M = 2688 (13B prefill, 8 x 336 rows) is 12 x 224 exactly — no padded rows, 720 / 240 tiles instead of
-        // 660 / 220 where the 11th 256-row tile is half empty
-        case 95: return launch_tile<224, 256, 112, 64, 0>(VLY_TILE_ARGS);
-        case 96: return launch_tile<224, 256, 112, 64, 4>(VLY_TILE_ARGS);
         // 4 waves x (128 x 128): a quarter of the 16-wave tile's LDS fragment traffic (PIPE 8 comment)
         case 197:                                           // persistent: one workgroup per CU walks the tiles (gemm_p4_kernel)
         case 198:
@@ -1770,10 +1382,6 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 53: return launch_tile<256, 128, 64, 64, 4>(VLY_TILE_ARGS);
         case 54: return launch_tile<128, 256, 64, 64, 4>(VLY_TILE_ARGS);
         case 55: return launch_tile<192, 256, 96, 64, 4>(VLY_TILE_ARGS);
-        case 31: return launch_tile<256, 256, 128, 64, 3>(VLY_TILE_ARGS);
-        case 33: return launch_tile<256, 128, 64, 64, 3>(VLY_TILE_ARGS);
-        case 34: return launch_tile<128, 256, 64, 64, 3>(VLY_TILE_ARGS);
-        case 35: return launch_tile<192, 256, 96, 64, 3>(VLY_TILE_ARGS);
         default: vly_set_error("vly_gemm_bf16: bad tile_hint %d", tile_hint); return -22;
     }
 #endif

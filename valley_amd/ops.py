@@ -26,7 +26,6 @@ TILE_NAMES = {1: "256, 256, 128, 64", 2: "128, 128, 64, 64", 3: "256, 128, 64, 6
               5: "192, 256, 96, 64", 6: "192, 192, 96, 48", 7: "128, 192, 64, 48",
               8: "192, 128, 96, 32", 9: "256, 256, 64, 64"}
 TILE_SPECIAL = {93: ("256, 128, 64, 32", 6), 94: ("128, 256, 32, 64", 6),       # 16-wave 3-stage variants
-                95: ("224, 256, 112, 64", 0), 96: ("224, 256, 112, 64", 4),     # 224-row tiles (M = 2688 = 12 x 224)
                 97: ("256, 256, 128, 128", 8), 98: ("224, 256, 112, 128", 8),   # 4 waves x (128 | 112 | 96) x 128
                 99: ("192, 256, 96, 128", 8),
                 197: ("p4 256, 256", 8), 198: ("p4 224, 256", 8), 199: ("p4 192, 256", 8)}   # ... persistent (gemm_p4_kernel)
@@ -374,7 +373,7 @@ def _flush_caches(device):
     buf.zero_()
 
 
-CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94, 95, 96, 97, 98, 99, 197, 198, 199)] + \
+CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94, 97, 98, 99, 197, 198, 199)] + \
              [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186)]
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 TUNE_FINALISTS = 4   # after TUNE_TRIALS calls per candidate the best few are re-timed to 3 x TUNE_TRIALS calls each
