@@ -831,11 +831,12 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
-    // VLY_VIT_ATTN=1 launches the round-2 kernel (A/B measurements)
-    static const bool v1 = getenv("VLY_VIT_ATTN") && atoi(getenv("VLY_VIT_ATTN")) == 1;
-    if (v1) hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    // VLY_VIT_ATTN=2 launches vit_attn2_kernel (LDS-DMA staging, packed softmax; measured within 4 % of this one either way:
+    // profiles/r03/r03_vit_attn_v1_v2.jsonl) with VLY_VIT_SKEW x 512 cycles of head start for waves 0-3
+    static const bool v2 = getenv("VLY_VIT_ATTN") && atoi(getenv("VLY_VIT_ATTN")) == 2;
+    if (!v2) hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
     else {
-        static const int skew = getenv("VLY_VIT_SKEW") ? atoi(getenv("VLY_VIT_SKEW")) : 0;       // measurement switch
+        static const int skew = getenv("VLY_VIT_SKEW") ? atoi(getenv("VLY_VIT_SKEW")) : 0;
         hipLaunchKernelGGL(vit_attn2_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, skew);
     }
     return vly_check_launch("vly_vit_attention");

@@ -42,7 +42,6 @@ def _dev(t, device, dtype):
 
 
 VIT_CHUNK = int(os.environ.get("VALLEY_VIT_CHUNK", "256"))
-QKV_SPLIT = os.environ.get("VALLEY_VIT_QKV_SPLIT", "0") == "1"      # measurement switch: row split (ops.row_split) for q|k|v too
 
 
 class HipCLIPVisionTower:
@@ -178,14 +177,12 @@ class HipCLIPVisionTower:
             ops.add_norm(h, ws["delta"], L["ln1_g"], L["ln1_b"], eps, out=ws["x"], delta2=d2)
         else:
             ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=ws["x"])
-        if QKV_SPLIT:
-            ops.gemm_split(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
-        else:
-            ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        ops.gemm(ws["x"], L["w_qkv"], L["b_qkv"], out=ws["qkv"])
         ops.vit_attention(ws["qkv"], F, out=ws["att"])
         # M = F*257 rows: the *_split forms cut a launch at a multiple of 4096 rows so that the main launch is a whole
         # number of workgroup rounds and hand the F-row remainder to the latency-optimised skinny kernel (ops.row_split;
-        # q|k|v gains nothing from it: measured)
+        # q|k|v gains nothing from it: measured in round 2 and again in round 3 with the skinny remainder kernel — ViT 21.73 ->
+        # 22.13 ms per 128 frames with q|k|v split, profiles/r03/r03_vit_qkv_split.jsonl)
         d2 = ws["delta2"] if ops.gemm2_split(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
         ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"], delta2=d2)
         ops.gemm_split(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
