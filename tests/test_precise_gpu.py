@@ -276,3 +276,32 @@ def test_bf16_path_vs_same_dtype_oracle(method):
     if ref is not None:
         assert maxabs(got[v], ref[v]) <= 1.15 * maxabs(same[v], ref[v]) + 2e-3      # measured 3.05e-2 vs 3.12e-2
         assert rel(got[v], ref[v]) <= 1.15 * rel(same[v], ref[v])
+
+
+def test_output_hidden_states_vs_reference_fixture():
+    """``output_hidden_states=True`` (valley_model.py:281-282, 324-330 -> HF LlamaModel's all_hidden_states: the embeddings,
+    every layer's output, the last entry after the final norm) against the reference's own tuple (g10, tools/gen_goldens_r3.py):
+    fp32 mode within 1e-4, the half-precision production path at its storage tolerance; same logits as without the flag."""
+    g = np.load(os.path.join(GOLD, "g10_hidden_states.npz"))
+    T = G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224).cuda()
+    v = mask.astype(bool)[:, ::4]
+    for precision, tol in (("fp32", 1e-4), ("bf16", 6e-2)):          # "bf16" = the production engines in the library's storage type
+        model = build_model("mean", precision)
+        kw = dict(input_ids=torch.from_numpy(ids).cuda(), images=images, attention_mask=torch.from_numpy(mask).cuda())
+        out = model(output_hidden_states=True, **kw)
+        assert len(out.hidden_states) == int(g["n"]) == G.GCFG["L"] + 1
+        errs = []
+        for i, h in enumerate(out.hidden_states):
+            assert tuple(h.shape) == (2, ids.shape[1], G.GCFG["H"])
+            errs.append(maxabs(h.float().cpu().numpy()[:, ::4, ::2][v], g[f"hs{i}"][v]))
+        plain = model(**kw)
+        same = maxabs(out.logits.cpu().numpy(), plain.logits.cpu().numpy())
+        print(f"{precision}: hidden_states max-abs vs the reference's {['%.2e' % e for e in errs]} (|h| up to 4.9), logits with/without the flag differ by {same:.1e}")
+        assert max(errs) < tol
+        assert maxabs(out.logits.cpu().numpy()[:, ::4][v], g["logits"][v]) < (TOL_FP32 if precision == "fp32" else 4.5e-2)
+        assert same < (1e-5 if precision == "fp32" else 4.5e-2)       # the collecting pass flushes the residual per layer: rounding order only
+        assert plain.hidden_states is None
+    with pytest.raises(NotImplementedError):
+        model(output_attentions=True, **kw)

@@ -186,9 +186,12 @@ class HipLlama:
             self._ws[key] = ws
         return ws
 
-    def forward(self, h: torch.Tensor, B: int, S: int, cache: HipKVCache, n_layers: Optional[int] = None) -> torch.Tensor:
+    def forward(self, h: torch.Tensor, B: int, S: int, cache: HipKVCache, n_layers: Optional[int] = None,
+                collect: Optional[list] = None) -> torch.Tensor:
         """h fp32 [B*S, H] (modified in place) -> final-norm hidden bf16 [B*S, H].  Appends S
-        positions to ``cache``; key validity comes from cache.key_valid."""
+        positions to ``cache``; key validity comes from cache.key_valid.  ``collect`` (a list): HF's ``output_hidden_states``
+        (hf:llama/modeling_llama.py LlamaModel.forward) — receives the embeddings, every decoder layer's output (fp32
+        copies of the residual stream) and, last, the final-norm output; costs one residual flush + copy per layer."""
         if not self.loaded:
             raise RuntimeError("Llama engine has no weights")
         past = cache.seq_len
@@ -197,22 +200,25 @@ class HipLlama:
             raise ValueError("cache batch mismatch")
         ops.sk_check_polled(self.device)                   # a stream-K hand-off failure of an earlier call surfaces here
         with runtime.stream_lock():                        # launch sequences on one stream must not interleave
-            out = self._forward_locked(h, B, S, cache, past, n_layers)
+            out = self._forward_locked(h, B, S, cache, past, n_layers, collect)
             if S > 1:
                 ops.sk_poll_async(self.device)
             return out
 
-    def _forward_locked(self, h, B, S, cache, past, n_layers):
+    def _forward_locked(self, h, B, S, cache, past, n_layers, collect=None):
         M = B * S
         ws = self._workspace(M)
         kv = cache.key_valid                                # uint8 [B, ctx_max] or None (row stride = ctx_max)
         nl = self.L if n_layers is None else n_layers
         fused = M > 8            # prefill: residual adds ride on the norm kernels; decode keeps the GEMV epilogue
         d2 = None                  # second split-K partial of the pending sub-layer output (ops.gemm2), if any
+        pending = False            # ws["delta"] (+ d2) holds a sub-layer output that has not been added to h yet
+        if collect is not None:
+            collect.append(h.clone())                       # hidden_states[0]: the (spliced) input embeddings
         for li in range(nl):
             L = self.layers[li]
             W = self.packed[li] if (fused and self.packed) else L      # projection weights as this pass reads them
-            if fused and li > 0:
+            if pending:
                 ops.add_norm(h, ws["delta"], L["ln1"], None, self.eps, out=ws["x"], rms=True, delta2=d2)
             else:
                 ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
@@ -237,12 +243,22 @@ class HipLlama:
             ops.gemm(ws["x"], W["w_gu"], epilogue=ops.EPI_SWIGLU, out=ws["mlp"])
             if fused:
                 d2 = ws["delta2"] if ops.gemm2(ws["mlp"], W["w_down"], ws["delta"], ws["delta2"]) == 2 else None
+                pending = True
             else:
                 ops.gemm(ws["mlp"], L["w_down"], residual=h, out=h)
+            if collect is not None and li + 1 < nl:
+                if pending:                                 # flush: h is a complete hidden state again
+                    ops.add_norm(h, ws["delta"], None, None, self.eps, rms=True, delta2=d2)
+                    pending = False
+                collect.append(h.clone())
         cache.seq_len = past + S
-        if fused and nl > 0:
-            return ops.add_norm(h, ws["delta"], self.norm, None, self.eps, out=ws["x"], rms=True, delta2=d2)
-        return ops.rmsnorm(h, self.norm, self.eps, out=ws["x"])
+        if pending:
+            out = ops.add_norm(h, ws["delta"], self.norm, None, self.eps, out=ws["x"], rms=True, delta2=d2)
+        else:
+            out = ops.rmsnorm(h, self.norm, self.eps, out=ws["x"])
+        if collect is not None:
+            collect.append(out.float())                     # HF: the last entry is taken AFTER the final norm
+        return out
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:
         """x bf16 [M,H] -> fp32 [M,V] (a view of the V-padded GEMM output)."""

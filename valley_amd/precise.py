@@ -247,8 +247,10 @@ class PreciseLlama:
     def new_cache(self, batch: int, ctx_max: Optional[int] = None) -> F32KVCache:
         return F32KVCache(self.L, batch, self.heads, ctx_max or self.max_positions, self.device)
 
-    def forward(self, h: torch.Tensor, B: int, S: int, cache: F32KVCache, n_layers: Optional[int] = None) -> torch.Tensor:
-        """h fp32 [B*S, H] (modified in place) -> final-norm hidden fp32 [B*S, H]; appends S positions to ``cache``."""
+    def forward(self, h: torch.Tensor, B: int, S: int, cache: F32KVCache, n_layers: Optional[int] = None,
+                collect: Optional[list] = None) -> torch.Tensor:
+        """h fp32 [B*S, H] (modified in place) -> final-norm hidden fp32 [B*S, H]; appends S positions to ``cache``;
+        ``collect`` as in HipLlama.forward (HF's output_hidden_states)."""
         if not self.loaded:
             raise RuntimeError("Llama engine has no weights")
         if not isinstance(cache, F32KVCache):
@@ -258,7 +260,10 @@ class PreciseLlama:
         if cache.batch != B:
             raise ValueError("cache batch mismatch")
         with runtime.stream_lock():
-            for li in range(self.L if n_layers is None else n_layers):
+            nl = self.L if n_layers is None else n_layers
+            if collect is not None:
+                collect.append(h.clone())
+            for li in range(nl):
                 L = self.layers[li]
                 qkv = F.gemm(F.norm(h, L["ln1"], None, self.eps), L["w_qkv"])
                 F.rope_kv(qkv, cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
@@ -266,8 +271,13 @@ class PreciseLlama:
                 F.gemm(att, L["w_o"], residual=h, out=h)
                 mid = F.gemm(F.norm(h, L["ln2"], None, self.eps), L["w_gu"], epilogue=ops.EPI_SWIGLU)
                 F.gemm(mid, L["w_down"], residual=h, out=h)
+                if collect is not None and li + 1 < nl:
+                    collect.append(h.clone())
             cache.seq_len = past + S
-            return F.norm(h, self.norm, None, self.eps)
+            out = F.norm(h, self.norm, None, self.eps)
+            if collect is not None:
+                collect.append(out.clone())
+            return out
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:
         return F.gemm(x, self.lm_head)[:, :self.V]
