@@ -352,3 +352,34 @@ def test_c4_shape_tower_chunk_invariance():
     r = float((b - a).norm() / a.norm())
     print("c4 tower, tuned (row-split + skinny remainder) vs whole tiles: rel-L2", r)
     assert r < 5e-3 and ops.sk_error_flag("cuda:0") == 0
+
+
+def test_vit_two_stream_remainder_schedule_is_bit_identical(monkeypatch):
+    """vision_tower.layer_forward_2s (the remainder rows of the row-split GEMMs on a side stream, forked after attention and
+    joined before the next q|k|v GEMM) runs the same kernels on the same rows as the single-stream schedule: once the
+    tuner has decided every shape, 32 frames through 4 ViT-L/14 layers give bit-identical features, repeatedly (a missing
+    dependency between the streams would show as a difference or as run-to-run noise)."""
+    from valley_amd import ops, vision_tower as vt
+    from valley_amd import valley_model as vm
+    monkeypatch.setattr(ops, "GEMM_MODE", "tuned")
+    monkeypatch.setattr(ops, "ROW_SPLIT_MIN", 8192)          # F = 32: M = 8224 = 8192 + 32 remainder rows
+    tower = vm.build_vision_tower(None)
+    tower.init_random(seed=3, layers=4)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    frames = torch.randn((32, 3, 224, 224), generator=g, device="cuda").to(torch.bfloat16)
+    assert ops.row_split(32 * 257) == 8192
+    for it in range(400):                                      # let the online tuner settle on the split shapes
+        monkeypatch.setattr(vt, "TWO_STREAM", bool(it & 1))
+        tower.encode(frames, select_layer=4)
+        torch.cuda.synchronize()
+        if ops.tuning_pending() == 0 and it >= 3:
+            break
+    assert ops.tuning_pending() == 0
+    monkeypatch.setattr(vt, "TWO_STREAM", False)
+    ref = tower.encode(frames, select_layer=4).clone()
+    monkeypatch.setattr(vt, "TWO_STREAM", True)
+    for _ in range(5):
+        got = tower.encode(frames, select_layer=4)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0.1

@@ -455,7 +455,7 @@ def gemm2(a, w, out, out2, bias=None) -> int:
 
 
 ROW_SPLIT = os.environ.get("VALLEY_ROW_SPLIT", "1") == "1"
-ROW_SPLIT_MIN = int(os.environ.get("VALLEY_ROW_SPLIT_MIN", "32768"))      # smallest M that is split (measurements)
+ROW_SPLIT_MIN = int(os.environ.get("VALLEY_ROW_SPLIT_MIN", "8192"))       # smallest M that is split (32 frames: 8224 = 8192 + 32)
 
 
 def row_split(M: int) -> int:
@@ -472,9 +472,13 @@ def row_split(M: int) -> int:
     out-proj 778 -> 897 TFLOP/s, q|k|v unchanged.  On the tile kernels the F-row remainder is one tile row's latency-bound
     K loop (14-17 us at K = 1024, 33 us at K = 4096: all of the gain); on vly_gemm_skinny_bf16 it costs 12 (fc1), 22 (fc2)
     and 9 us (out-proj), which nets a gain for all three — so vision_tower.layer_forward splits fc1, fc2 AND out-proj, and
-    leaves q|k|v (224-row tiles: 147 x 12 tiles, nothing to gain) in one launch."""
+    leaves q|k|v (224-row tiles: 147 x 12 tiles, nothing to gain) in one launch.
+    Round 3: with the persistent kernels the split pays from F = 32 frames on (M = 8224: fc1 81.9 -> 63.7 us, fc2 75.2 -> 65.6,
+    out-proj 29.9 -> 25.0 per layer against 36 us of remainder kernels — which the side-stream schedule of
+    vision_tower.layer_forward_2s takes off the critical path at these sizes: ViT 6.88 -> 6.62 ms at 32 frames, 12.24 -> 11.72 at
+    64; profiles/r03/r03_vit_two_stream.jsonl)."""
     if not ROW_SPLIT or GEMM_MODE != "tuned" or M < ROW_SPLIT_MIN or M % 4096 == 0:
-        return M                 # F = 32 / 64 frames (M = 8224 / 16448): the latency-bound remainder costs more than the round saved
+        return M
     return M // 4096 * 4096
 
 

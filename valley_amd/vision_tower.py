@@ -42,6 +42,11 @@ def _dev(t, device, dtype):
 
 
 VIT_CHUNK = int(os.environ.get("VALLEY_VIT_CHUNK", "256"))
+# Remainder rows of the row-split GEMMs on a side stream (layer_forward_2s): "auto" (default) below 32768 rows, where it
+# measured +2..5 % (profiles/r03/r03_vit_two_stream.jsonl); at 128+ frames it measured equal (the main stream's GEMMs leave
+# no registers for a co-resident kernel and its LayerNorm windows are short against 42 us of remainders), so the headline
+# configuration stays on one stream.  "1" / "0" force it on / off.
+TWO_STREAM = {"1": True, "0": False}.get(os.environ.get("VALLEY_VIT_TWO_STREAM", "auto"), None)
 
 
 class HipCLIPVisionTower:
@@ -150,6 +155,14 @@ class HipCLIPVisionTower:
             self._ws[key] = ws
         return ws
 
+    def _side_stream(self):
+        """One side stream per main stream (layer_forward_2s)."""
+        key = ("side", runtime.stream_key())
+        st = self._ws.get(key)
+        if st is None:
+            st = self._ws[key] = torch.cuda.Stream(device=self.device)
+        return st
+
     def n_layers_for(self, select_layer: int) -> int:
         n = self.config.num_hidden_layers
         idx = select_layer if select_layer >= 0 else n + 1 + select_layer
@@ -191,6 +204,56 @@ class HipCLIPVisionTower:
             ops.add_norm(h, ws["delta"], None, None, eps,                # last residual update of the stack
                          delta2=ws["delta2"] if ws["split"] else None)
 
+    def layer_forward_2s(self, h: torch.Tensor, L: Dict[str, torch.Tensor], F: int, Mm: int, pending: bool, nxt, side):
+        """layer_forward with the F remainder rows of the row-split GEMMs (ops.row_split) on a SIDE stream.
+
+        Rows [Mm, M) are independent of rows [0, Mm) everywhere except inside attention, so between two attention kernels
+        they form their own chain — out-proj remainder -> add+LN -> fc1 remainder -> fc2 remainder -> add+LN of the next
+        layer — which the single-stream schedule serialises behind the main launches (42 us of skinny kernels per layer,
+        0.97 ms of the c3 step: VERDICT r2).  On a second stream the chain runs wherever the main stream leaves room: the
+        persistent GEMMs fill every CU's register file, but the fused add+LayerNorm kernels of the main rows (HBM-bound,
+        few registers, no LDS) do not, and those 2 x 60 us per layer are where the remainder kernels land.  Two
+        cross-stream dependencies per layer: the fork after attention (the side chain reads att[Mm:]) and the join before
+        the q|k|v GEMM (which reads every row of x).  Row ranges of h / x / delta / mlp are disjoint between the streams."""
+        ws = self._workspace(F)                                # (keyed by the MAIN stream: fetched before any stream switch)
+        eps = self.config.layer_norm_eps
+        main = torch.cuda.current_stream()
+        hm, hr = h[:Mm], h[Mm:]
+        x, att, mlp, dl, dl2 = ws["x"], ws["att"], ws["mlp"], ws["delta"], ws["delta2"]
+
+        def rem_gemm2(a, w, bias, n):                          # remainder rows follow the main launch's answer (gemm2_split)
+            if n == 2:
+                ops.gemm_mfma_splitk2(a, w, bias, dl[Mm:], dl2[Mm:], 0)
+            else:
+                ops._gemm_rem(a, w, bias, ops.EPI_NONE, dl[Mm:])
+
+        if pending:
+            split = ws["split"]
+            ops.add_norm(hm, dl[:Mm], L["ln1_g"], L["ln1_b"], eps, out=x[:Mm], delta2=dl2[:Mm] if split else None)
+            with torch.cuda.stream(side):                      # ordered behind the side stream's own fc2 remainder
+                ops.add_norm(hr, dl[Mm:], L["ln1_g"], L["ln1_b"], eps, out=x[Mm:], delta2=dl2[Mm:] if split else None)
+            main.wait_stream(side)                             # join: q|k|v reads all rows of x
+        else:
+            ops.layernorm(h, L["ln1_g"], L["ln1_b"], eps, out=x)
+        ops.gemm(x, L["w_qkv"], L["b_qkv"], out=ws["qkv"])
+        ops.vit_attention(ws["qkv"], F, out=att)
+        side.wait_stream(main)                                 # fork: the side chain reads att[Mm:]
+        n = ops.gemm2(att[:Mm], L["w_o"], dl[:Mm], dl2[:Mm], L["b_o"])
+        ops.add_norm(hm, dl[:Mm], L["ln2_g"], L["ln2_b"], eps, out=x[:Mm], delta2=dl2[:Mm] if n == 2 else None)
+        ops.gemm(x[:Mm], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=mlp[:Mm])
+        n2 = ops.gemm2(mlp[:Mm], L["w_fc2"], dl[:Mm], dl2[:Mm], L["b_fc2"])
+        with torch.cuda.stream(side):
+            rem_gemm2(att[Mm:], L["w_o"], L["b_o"], n)
+            ops.add_norm(hr, dl[Mm:], L["ln2_g"], L["ln2_b"], eps, out=x[Mm:], delta2=dl2[Mm:] if n == 2 else None)
+            ops._gemm_rem(x[Mm:], L["w_fc1"], L["b_fc1"], ops.EPI_QUICK_GELU, mlp[Mm:])
+            rem_gemm2(mlp[Mm:], L["w_fc2"], L["b_fc2"], n2)
+        ws["split"] = n2 == 2
+        if nxt is None:                                        # last residual update of the stack, both row ranges; join
+            ops.add_norm(hm, dl[:Mm], None, None, eps, delta2=dl2[:Mm] if n2 == 2 else None)
+            with torch.cuda.stream(side):
+                ops.add_norm(hr, dl[Mm:], None, None, eps, delta2=dl2[Mm:] if n2 == 2 else None)
+            main.wait_stream(side)
+
     def encode(self, frames: torch.Tensor, select_layer: int = -2, chunk: Optional[int] = None,
                keep_all: bool = False):
         """frames [F,3,224,224] (any float dtype, device) -> fp32 [F,257,1024] = hidden_states[select_layer].
@@ -221,8 +284,15 @@ class HipCLIPVisionTower:
             h = out[f0 * 257:(f0 + F) * 257]
             self.embed(frames[f0:f0 + F], h)
             states = [h.clone()] if keep_all else None
+            Mm = ops.row_split(F * 257)
+            want2 = (F * 257 < 32768) if TWO_STREAM is None else TWO_STREAM
+            two = want2 and Mm < F * 257 and not keep_all and not torch.cuda.is_current_stream_capturing()
+            side = self._side_stream() if two else None
             for li, L in enumerate(self.layers[:nl]):
                 last = li == nl - 1
+                if two:
+                    self.layer_forward_2s(h, L, F, Mm, pending=li > 0, nxt=None if last else True, side=side)
+                    continue
                 # with keep_all every layer flushes its pending MLP output so that h is a complete hidden state
                 self.layer_forward(h, L, F, pending=(li > 0 and not keep_all), nxt=None if (last or keep_all) else True)
                 if keep_all:
