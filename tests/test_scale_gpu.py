@@ -368,13 +368,14 @@ def test_vit_two_stream_remainder_schedule_is_bit_identical(monkeypatch):
     g = torch.Generator(device="cuda").manual_seed(8)
     frames = torch.randn((32, 3, 224, 224), generator=g, device="cuda").to(torch.bfloat16)
     assert ops.row_split(32 * 257) == 8192
-    for it in range(400):                                      # let the online tuner settle on the split shapes
+    before = set(ops._ONLINE)                                  # shapes other tests of this process left undecided do not recur here
+    for it in range(400):                                      # let the online tuner settle on this tower's shapes
         monkeypatch.setattr(vt, "TWO_STREAM", bool(it & 1))
         tower.encode(frames, select_layer=4)
         torch.cuda.synchronize()
-        if ops.tuning_pending() == 0 and it >= 3:
+        if set(ops._ONLINE) <= before and it >= 3:
             break
-    assert ops.tuning_pending() == 0
+    assert set(ops._ONLINE) <= before
     monkeypatch.setattr(vt, "TWO_STREAM", False)
     ref = tower.encode(frames, select_layer=4).clone()
     monkeypatch.setattr(vt, "TWO_STREAM", True)

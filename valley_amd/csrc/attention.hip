@@ -53,6 +53,29 @@ VLY_DEVICE int opaque_i32(int v) {
     return v;
 }
 
+// Output of one query tile: lane (q = l15, g) holds O[q][d = dt*16 + 4g + r] — four 8-byte pieces, one per dt, each a quarter
+// of a 32-byte run of its row.  Stored as they are, a wave instruction writes 16 rows x 32 bytes and every 128-byte line is
+// touched by four instructions: the timing variant without the stores runs 75 instead of 90 us per layer at 128 frames
+// (profiles/r03/r03_vit_attn_timing_variants.jsonl).  A 4 x 4 transpose across the four lanes of a row (the SwiGLU epilogue's
+// v_permlane16/32_swap pattern, once per 32-bit word) leaves lane g with the whole 32-byte run d = 16g .. 16g + 15.
+VLY_DEVICE void store_tile_rows(uint16_t* row_ptr, const f32x4 (&o)[4], float inv, int g) {
+    uint32_t y[2][4];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        uint32_t d[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) d[dt] = pack_h2(o[dt][2 * w] * inv, o[dt][2 * w + 1] * inv);
+        const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+        const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+        const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+        const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+        y[w][0] = q0[0]; y[w][1] = q1[0]; y[w][2] = q0[1]; y[w][3] = q1[1];       // y[w][j] = word w of lane j's piece dt = g
+    }
+    u32x4* dst = (u32x4*)(row_ptr + 16 * g);
+    dst[0] = u32x4{y[0][0], y[1][0], y[0][1], y[1][1]};
+    dst[1] = u32x4{y[0][2], y[1][2], y[0][3], y[1][3]};
+}
+
 // ---------------------------------------------------------------------------------------------
 // ViT attention
 // ---------------------------------------------------------------------------------------------
@@ -77,8 +100,14 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
     const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
 
+#ifndef VLY_VIT_STORE
+#define VLY_VIT_STORE 1    // 1: 32-byte runs per lane after a 4 x 4 lane transpose (store_tile_rows' pattern); 0: four 8-byte pieces (A/B)
+#endif
+#ifndef VLY_VIT_DBG
+#define VLY_VIT_DBG 0      // timing experiments (WRONG results; A/B builds only): 1 = staging only, 2 = compute only, 3 = no output stores
+#endif
     // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7 ------------------------------------
-    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
+    for (int s = tid; s < (VLY_VIT_DBG == 2 ? 0 : VNT * 16 * 8); s += VNW * 64) {
         const int row = s >> 3, c = s & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
@@ -87,7 +116,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     // ---- V^T: [64 d][288 kv]; wave w transposes d = 16(w&3)..+15, lane <-> key pair; the key-pair groups
     //      pg = 0,1,2 are dealt to the wave quads (w>>2) round-robin
     const int dq = wave & 3;
-    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
+    for (int pg = wave >> 2; pg < (VLY_VIT_DBG == 2 ? 0 : 3); pg += VNW / 4) {
         const int p = pg * 64 + lane;
         if (p < VNC * 16) {
             const int kv0 = 2 * p, kv1 = kv0 + 1;
@@ -110,6 +139,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         }
     }
     __syncthreads();
+    if (VLY_VIT_DBG == 1) return;
 
     const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
     // the Q fragments come straight from global memory: the next query tile's are requested before this tile's math
@@ -237,17 +267,791 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             }
             asm volatile("" ::: "memory");
         }
-        if (q < VN) {
+        if (VLY_VIT_DBG == 3) { asm volatile("" ::"v"(o[0][0]), "v"(o[1][0]), "v"(o[2][0]), "v"(o[3][0]), "v"(l)); continue; }
+        {   // (every lane takes part in the lane swaps; rows past token 256 write to the clamped row's twin and are masked)
             const float inv = 1.f / l;
-            uint16_t* op = out + ((size_t)f * VN + q) * 1024 + h * 64 + 4 * g;
+            uint16_t* op = out + ((size_t)f * VN + min(q, VN - 1)) * 1024 + h * 64;
+            if (VLY_VIT_STORE == 0) {
+                if (q < VN) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                u32x2 pk;
-                pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
-                pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
-                *(u32x2*)(op + dt * 16) = pk;
+                    for (int dt = 0; dt < 4; ++dt) {
+                        u32x2 pk;
+                        pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
+                        pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
+                        *(u32x2*)(op + 4 * g + dt * 16) = pk;
+                    }
+                }
+            } else {
+                uint32_t y[2][4];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    uint32_t d[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) d[dt] = pack_h2(o[dt][2 * w] * inv, o[dt][2 * w + 1] * inv);
+                    const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                    const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+                    const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+                    const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+                    y[w][0] = q0[0]; y[w][1] = q1[0]; y[w][2] = q0[1]; y[w][3] = q1[1];
+                }
+                if (q < VN) {
+                    u32x4* dst = (u32x4*)(op + 16 * g);
+                    dst[0] = u32x4{y[0][0], y[1][0], y[0][1], y[1][1]};
+                    dst[1] = u32x4{y[0][2], y[1][2], y[0][3], y[1][3]};
+                }
             }
         }
+    }
+}
+
+// ---- round 3: the 257th query --------------------------------------------------------------------------------------
+// 257 tokens are 16 query tiles + ONE row.  vit_attn_kernel gives that row a whole 16-row tile: 17 tiles on 8 waves = 3 for
+// wave 0 and 2 for the others, so a workgroup lives three tile-times while seven of its eight waves work two (PMC, round 3:
+// mean wave lifetime 15.9 us x 4 rounds of workgroups = 64 of the kernel's 92 us).  Here every wave computes two full query
+// tiles, and the last query is split over the KEYS instead: wave w takes key tiles w and w + 8 (wave 0 also the 17th, which
+// holds key 256 alone) as one 32-key chunk of the second product, keeps a partial (max, sum, 64 outputs) of the online
+// softmax for that query, and wave 0 merges the eight partials through 2 KB of LDS.  The query's 16-row MFMA tile still
+// exists (its other 15 columns repeat token 256 and are discarded) but each wave runs 4-6 + 4-8 MFMAs of it instead of
+// one wave running 70.
+constexpr int VMERGE_F = 68;                     // floats per wave in the merge area: m, l, 2 pad, 64 outputs
+
+__global__ void __launch_bounds__(VNW * 64, 2) vit_attn3_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2 + VNW * VMERGE_F * 4];
+    char* sK = smem;
+    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
+    float* sMg = (float*)(smem + VK_BYTES + 64 * VT_STRIDE * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int hi16 = opaque_i32(16);                                   // see opaque_i32
+    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
+    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
+
+    // ---- staging: as vit_attn_kernel
+    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
+        const int row = s >> 3, c = s & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
+        *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+    const int dq = wave & 3;
+    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
+        const int p = pg * 64 + lane;
+        if (p < VNC * 16) {
+            const int kv0 = 2 * p, kv1 = kv0 + 1;
+            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
+            if (kv0 < VN) {
+                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + dq * 16;
+                a0 = *(const u32x4*)r0;
+                a1 = *(const u32x4*)(r0 + 8);
+            }
+            if (kv1 < VN) {
+                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + dq * 16;
+                b0 = *(const u32x4*)r1;
+                b1 = *(const u32x4*)(r1 + 8);
+            }
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
+                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + kv0) = w;
+            }
+        }
+    }
+    __syncthreads();
+
+    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
+    bf16x8 qn[2];
+    {
+        const int qc0 = wave * 16 + l15;
+        qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
+        qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
+    }
+    // ---- two full query tiles per wave: qt = wave, wave + 8
+    for (int qt = wave; qt < 2 * VNW; qt += VNW) {
+        const int q = qt * 16 + l15;
+        bf16x8 qf[2] = {qn[0], qn[1]};
+        if (qt + VNW < 2 * VNW) {                              // the next tile's Q fragments
+            const int qc1 = (qt + VNW) * 16 + l15;
+            qn[0] = *(const bf16x8*)(base + (size_t)qc1 * VLD + g * 8);
+            qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
+        }
+        f32x4 s[VNT];
+#pragma unroll
+        for (int t = 0; t < VNT; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                acc = mfma16(kf, qf[kk], acc);
+            }
+            s[t] = acc * sc;
+            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;       // keys 257..271 are padding
+        float m = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sm_exp2(s[t][r] - m);
+                s[t][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < VNC; ++c) {
+            u32x4 pk;
+            pk[0] = pack_h2(s[2 * c][0], s[2 * c][1]);
+            pk[1] = pack_h2(s[2 * c][2], s[2 * c][3]);
+            if (2 * c + 1 < VNT) {
+                pk[2] = pack_h2(s[2 * c + 1][0], s[2 * c + 1][1]);
+                pk[3] = pack_h2(s[2 * c + 1][2], s[2 * c + 1][3]);
+            } else {
+                pk[2] = 0u;
+                pk[3] = 0u;
+            }
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 32 * c + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + hi16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
+            }
+            asm volatile("" ::: "memory");
+        }
+        store_tile_rows(out + ((size_t)f * VN + q) * 1024 + h * 64, o, 1.f / l, g);
+    }
+    // ---- the last query (token 256), split over the keys: this wave's key tiles are wave and wave + 8 (+ 16 for wave 0)
+    {
+        // (lane coordinates re-derived behind an opaque copy: otherwise hipcc hoists this section's address arithmetic above
+        // the query-tile loop and the kernel no longer fits the 128 registers that let two workgroups share a CU)
+        const int l15 = opaque_i32(lane) & 15, g = opaque_i32(lane) >> 4;
+        // the last query, replicated over the tile's 16 columns (only column 0 is kept)
+        const bf16x8 qf[2] = {*(const bf16x8*)(base + (size_t)(VN - 1) * VLD + g * 8), *(const bf16x8*)(base + (size_t)(VN - 1) * VLD + 32 + g * 8)};
+        const int nt = wave == 0 ? 3 : 2;                      // wave-uniform
+        f32x4 s[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int t = wave + VNW * j;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (j < nt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                    acc = mfma16(kf, qf[kk], acc);
+                }
+            }
+            s[j] = acc * sc;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (nt < 3 || g != 0 || r != 0) s[2][r] = NEG_BIG;   // the third tile is keys 256..271: only key 256 (g = 0, r = 0) exists
+        }
+        float m = NEG_BIG;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[j][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sm_exp2(s[j][r] - m);
+                s[j][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // chunk 0: k slots 0..3 of a lane group <-> keys of tile `wave`, 4..7 <-> keys of tile `wave + 8`
+        {
+            u32x4 pk;
+            pk[0] = pack_h2(s[0][0], s[0][1]);
+            pk[1] = pack_h2(s[0][2], s[0][3]);
+            pk[2] = pack_h2(s[1][0], s[1][1]);
+            pk[3] = pack_h2(s[1][2], s[1][3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 16 * wave + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + 8 * hi16);            // + 128 keys: tile wave + 8
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
+            }
+        }
+        if (nt == 3) {                                            // wave 0: key tile 16 (key 256; V^T columns 257..287 are zeros)
+            u32x4 pk;
+            pk[0] = pack_h2(s[2][0], s[2][1]);
+            pk[1] = pack_h2(s[2][2], s[2][3]);
+            pk[2] = 0u;
+            pk[3] = 0u;
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 256 + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + hi16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
+            }
+        }
+        // the query is column 0 (l15 == 0) of the tile: its partial (m, l, O[d = dt*16 + 4g + r]) goes to the merge area
+        if (l15 == 0) {
+            float* mg = sMg + wave * VMERGE_F;
+            if (g == 0) { mg[0] = m; mg[1] = l; }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(mg + 4 + dt * 16 + 4 * g) = o[dt];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                                              // merge: lane d owns output d of the query
+        float M = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < VNW; ++w) M = fmaxf(M, sMg[w * VMERGE_F]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < VNW; ++w) {
+            const float a = sm_exp2(sMg[w * VMERGE_F] - M);
+            L = fmaf(sMg[w * VMERGE_F + 1], a, L);
+            O = fmaf(sMg[w * VMERGE_F + 4 + lane], a, O);
+        }
+        out[((size_t)f * VN + (VN - 1)) * 1024 + h * 64 + lane] = f2h(O / L);
+    }
+}
+
+// ---- round 3: two query tiles per wave -----------------------------------------------------------------------------------
+// What the four kernels above have in common — and what bounds all of them at ~90 us per layer whatever their staging looks
+// like — is the LDS READ traffic of the two products: every 16-query tile re-reads the head's whole K (34 x 1 KB fragments)
+// and V^T (72 x 512 B) from LDS, 1.2 MB per head, 9.6 MB per CU and launch (the "compute only" timing variant that runs 47 us
+// is really "no LDS reads": hipcc folds loads of a never-written LDS array).  Here a wave owns TWO query tiles (w and w + 8)
+// and walks the keys in blocks of 64 with an online softmax, so every K and V^T fragment it reads feeds two MFMAs: half the
+// LDS reads per flop, at the price of the rescaling arithmetic (one exp2 and 16 multiplies per tile and block).  Staging and
+// layout as vit_attn_kernel (two 8-wave workgroups per CU); the 257th query is split over the keys as in vit_attn3_kernel.
+__global__ void __launch_bounds__(VNW * 64, 4) vit_attn5_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2 + VNW * VMERGE_F * 4];
+    char* sK = smem;
+    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
+    float* sMg = (float*)(smem + VK_BYTES + 64 * VT_STRIDE * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int hi16 = opaque_i32(16);                                   // see opaque_i32
+    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
+    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
+
+    // ---- staging: as vit_attn_kernel
+    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
+        const int row = s >> 3, c = s & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
+        *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+    const int dq = wave & 3;
+    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
+        const int p = pg * 64 + lane;
+        if (p < VNC * 16) {
+            const int kv0 = 2 * p, kv1 = kv0 + 1;
+            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
+            if (kv0 < VN) {
+                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + dq * 16;
+                a0 = *(const u32x4*)r0;
+                a1 = *(const u32x4*)(r0 + 8);
+            }
+            if (kv1 < VN) {
+                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + dq * 16;
+                b0 = *(const u32x4*)r1;
+                b1 = *(const u32x4*)(r1 + 8);
+            }
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
+                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + kv0) = w;
+            }
+        }
+    }
+    // the Q fragments of both tiles (rows wave*16 + l15 and (wave + 8)*16 + l15: all below 256)
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint16_t* qp = base + (size_t)((wave + VNW * u) * 16 + l15) * VLD + g * 8;
+        qf[u][0] = *(const bf16x8*)qp;
+        qf[u][1] = *(const bf16x8*)(qp + 32);
+    }
+    __syncthreads();
+
+    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
+    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+    f32x4 o[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- key blocks of 64 (blocks 0..3: keys 0..255; block 4: key tile 16 = key 256 and padding)
+#pragma unroll 1
+    for (int kb = 0; kb < 5; ++kb) {
+        const int nt = kb < 4 ? 4 : 1;                      // key tiles in this block (uniform)
+        f32x4 s[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            if (t < nt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + ((kb * 4 + t) * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                    a0 = mfma16(kf, qf[0][kk], a0);
+                    a1 = mfma16(kf, qf[1][kk], a1);
+                }
+            }
+            s[0][t] = a0 * sc;
+            s[1][t] = a1 * sc;
+            if (t & 1) asm volatile("" ::: "memory");       // cap the K fragments in flight (register budget)
+        }
+        if (kb == 4) {                                      // only (tile 16, g == 0, r == 0) is a real key
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t > 0 || g != 0 || r != 0) s[u][t][r] = NEG_BIG;
+        }
+        u32x4 pk[2][2];                                     // [tile][chunk]: the probabilities in the second product's k-slot order
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float rm = NEG_BIG;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rm = fmaxf(rm, s[u][t][r]);
+            rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
+            rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
+            const float mn = fmaxf(m[u], rm);
+            const float alpha = sm_exp2(m[u] - mn);
+            m[u] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = sm_exp2(s[u][t][r] - mn);
+                    s[u][t][r] = p;
+                    ps += p;
+                }
+            l[u] = l[u] * alpha + ps;                       // per-lane partial; the four g-lanes of a query share alpha
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                pk[u][c][0] = pack_h2(s[u][2 * c][0], s[u][2 * c][1]);
+                pk[u][c][1] = pack_h2(s[u][2 * c][2], s[u][2 * c][3]);
+                pk[u][c][2] = pack_h2(s[u][2 * c + 1][0], s[u][2 * c + 1][1]);
+                pk[u][c][3] = pack_h2(s[u][2 * c + 1][2], s[u][2 * c + 1][3]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c == 1 && kb == 4) break;                   // the last block has one 32-key chunk (V^T columns 256..287)
+            const bf16x8 pf0 = __builtin_bit_cast(bf16x8, pk[0][c]), pf1 = __builtin_bit_cast(bf16x8, pk[1][c]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 64 * kb + 32 * c + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + hi16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                o[0][dt] = mfma16(vf, pf0, o[0][dt]);
+                o[1][dt] = mfma16(vf, pf1, o[1][dt]);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float lt = l[u];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        store_tile_rows(out + ((size_t)f * VN + (wave + VNW * u) * 16 + l15) * 1024 + h * 64, o[u], 1.f / lt, g);
+    }
+    // ---- the last query (token 256), split over the keys: this wave's key tiles are wave and wave + 8 (+ 16 for wave 0)
+    {
+        const int l15 = opaque_i32(lane) & 15, g = opaque_i32(lane) >> 4;
+        const bf16x8 ql[2] = {*(const bf16x8*)(base + (size_t)(VN - 1) * VLD + g * 8), *(const bf16x8*)(base + (size_t)(VN - 1) * VLD + 32 + g * 8)};
+        const int nt = wave == 0 ? 3 : 2;                      // wave-uniform
+        f32x4 s[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int t = wave + VNW * j;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (j < nt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                    acc = mfma16(kf, ql[kk], acc);
+                }
+            }
+            s[j] = acc * sc;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (nt < 3 || g != 0 || r != 0) s[2][r] = NEG_BIG;
+        float pm = NEG_BIG;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pm = fmaxf(pm, s[j][r]);
+        pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
+        pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+        float pl = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sm_exp2(s[j][r] - pm);
+                s[j][r] = p;
+                pl += p;
+            }
+        pl += __shfl_xor(pl, 16, 64);
+        pl += __shfl_xor(pl, 32, 64);
+        f32x4 po[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) po[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            u32x4 pk;
+            pk[0] = pack_h2(s[0][0], s[0][1]);
+            pk[1] = pack_h2(s[0][2], s[0][3]);
+            pk[2] = pack_h2(s[1][0], s[1][1]);
+            pk[3] = pack_h2(s[1][2], s[1][3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 16 * wave + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + 8 * hi16);            // + 128 keys: tile wave + 8
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                po[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, po[dt]);
+            }
+        }
+        if (nt == 3) {
+            u32x4 pk;
+            pk[0] = pack_h2(s[2][0], s[2][1]);
+            pk[1] = pack_h2(s[2][2], s[2][3]);
+            pk[2] = 0u;
+            pk[3] = 0u;
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 256 + 4 * g;
+                const u32x2 lo = *(const u32x2*)vp;
+                const u32x2 hi = *(const u32x2*)(vp + hi16);
+                u32x4 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
+                po[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, po[dt]);
+            }
+        }
+        if (l15 == 0) {
+            float* mg = sMg + wave * VMERGE_F;
+            if (g == 0) { mg[0] = pm; mg[1] = pl; }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(mg + 4 + dt * 16 + 4 * g) = po[dt];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float M = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < VNW; ++w) M = fmaxf(M, sMg[w * VMERGE_F]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < VNW; ++w) {
+            const float a = sm_exp2(sMg[w * VMERGE_F] - M);
+            L = fmaf(sMg[w * VMERGE_F + 1], a, L);
+            O = fmaf(sMg[w * VMERGE_F + 4 + lane], a, O);
+        }
+        out[((size_t)f * VN + (VN - 1)) * 1024 + h * 64 + lane] = f2h(O / L);
+    }
+}
+
+// ---- round 3: persistent, double-buffered, everything staged by LDS-DMA -----------------------------------------------
+// Timing variants of vit_attn_kernel (profiles/r03/r03_vit_attn_timing_variants.jsonl): 90 us per layer at 128 frames, 47 of
+// them compute (QK^T, softmax, PV on data already in LDS) — the other half is a workgroup WAITING for its K / V (135 MB per
+// launch, one dependent round trip after another: 4.25 for K, 2 for V, then a register transpose of V) with one other
+// workgroup per CU to cover for it, because a head's K + V^T fill 71 of the 160 KB.  Here ONE 16-wave workgroup per CU walks
+// its heads (block id + k * grid), and while it computes head i out of LDS buffer i & 1 the K and V of head i + 1 land in
+// the other buffer by LDS-DMA — no registers, no VALU, no barrier of their own:
+//   * K as before ([272][128 B], chunk ^= row & 7 on the SOURCE address), V ROW-major ([288][128 B], chunk ^= row & 6) and
+//     read as the second product's A operand with ds_read_b64_tr_b16 (the hardware 4 x 4 transpose; semantics probed in
+//     profiles/r03/r03_tr_read_probe.txt: lanes 4t .. 4t+3 of a 16-lane block supply row t, lane j receives column j).  The
+//     swizzle keeps the 32 lanes of a half wave on 32 distinct 8-byte slots of a 256-byte bank window;
+//   * one barrier per head: vmcnt(0) + barrier says both "my pieces of this head landed" and "I am done with the other
+//     buffer"; the next head's pieces are issued right after the QK^T phase (the only consumer of the Q fragments: hipcc
+//     drains the DMA queue at the next use of an ordinary load, so none may be pending then) and fly under softmax + PV;
+//   * 17 query tiles on 16 waves: wave w owns tile w, and the 257th query is split over the keys (vit_attn3_kernel's scheme:
+//     key tile w per wave, wave 0 also the 17th; partials merged by wave 0 through a double-buffered 4 KB area);
+//   * outputs leave as 32-byte runs per lane (store_tile_rows).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int V4W = 16;
+constexpr int V4_KB = VNT * 16 * 128;              // 34816
+constexpr int V4_VB = VNC * 32 * 128;              // 36864
+constexpr int V4_QL = 1024;                        // one piece: rows 249..256 of Q (the last query is its row 7)
+constexpr int V4_BUF = V4_KB + V4_VB + V4_QL;      // 72704
+constexpr int V4_MG = V4W * VMERGE_F * 4;          // 4352
+
+VLY_DEVICE bf16x8 vt_frag(const char* lo_addr) {   // two transpose reads: keys +0..3 and +16..19 of this lane group's slots
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_addr + 16 * 128));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ void __launch_bounds__(V4W * 64) vit_attn4_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int nheads) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * V4_BUF + 2 * V4_MG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int G = (int)gridDim.x;
+
+    // LDS-DMA pieces in asm (M0 = the wave's 1 KB destination, then buffer_load ... lds — gemm_p4_kernel's form): hipcc orders
+    // every later ds_read behind a builtin global_load_lds with vmcnt(0), because it cannot know that the pieces land in the
+    // OTHER buffer — which would put the whole DMA latency back in front of the second product.  The waits are explicit.
+    const __amdgpu_buffer_rsrc_t rsQ = vly_rsrc(qkv);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto stage = [&](int id, int buf) {              // 34 K pieces + 36 V pieces of 1 KB, dealt to the 16 waves
+        const uint32_t hb = ((uint32_t)(id >> 4) * (uint32_t)(VN * VLD) + (uint32_t)(id & 15) * 64u) * 2u;    // byte offset of (frame, head)
+        for (int pc = wave; pc < VNT * 2 + VNC * 4 + 1; pc += V4W) {
+            const bool isk = pc < VNT * 2, isq = pc == VNT * 2 + VNC * 4;   // wave-uniform
+            const int pv = isk ? pc : pc - VNT * 2;
+            const int sl = pv * 64 + lane, row = isq ? VN - 8 + (lane >> 3) : sl >> 3, cp = sl & 7;
+            const uint32_t vo = hb + ((uint32_t)min(row, VN - 1) * (uint32_t)VLD + (isq ? 0u : isk ? 1024u : 2048u) +
+                                      (uint32_t)((cp ^ (isq ? 0 : row & (isk ? 7 : 6))) << 3)) * 2u;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)buf * V4_BUF + (isk ? 0u : (uint32_t)V4_KB) + (uint32_t)pv * 1024u);
+            asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
+            asm volatile("s_nop 0" ::: "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(rsQ) : "memory");
+        }
+    };
+    // per-lane byte offsets of the V fragments inside a buffer's V image: row 4g + t (t = l15 >> 2), 8-byte half l15 & 1,
+    // 16-byte chunk (2 dt + ((l15 & 3) >> 1)) ^ ((4g + t) & 6); + 4096 c per 32-key chunk, + 2048 for the second read
+    int voff[4];
+    {
+        const int t = l15 >> 2, r = 4 * g + t, key = r & 6;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) voff[dt] = V4_KB + r * 128 + (((2 * dt + ((l15 & 3) >> 1)) ^ key) << 4) + (l15 & 1) * 8;
+    }
+    const float sc = 0.125f * LOG2E;
+    const int id0 = (int)blockIdx.x;
+    if (id0 >= nheads) return;
+    stage(id0, 0);
+    bf16x8 qn[2];                                    // Q fragments of this wave's tile of the CURRENT head (loaded one head ahead)
+    {
+        const uint16_t* base = qkv + (size_t)(id0 >> 4) * VN * VLD + (id0 & 15) * 64;
+        qn[0] = *(const bf16x8*)(base + (size_t)(wave * 16 + l15) * VLD + g * 8);
+        qn[1] = *(const bf16x8*)(base + (size_t)(wave * 16 + l15) * VLD + 32 + g * 8);
+    }
+    int it = 0;
+    for (int id = id0; id < nheads; id += G, ++it) {
+        const int buf = it & 1;
+        const char* sK = smem + buf * V4_BUF;
+        float* sMg = (float*)(smem + 2 * V4_BUF + buf * V4_MG);
+        const int f = id >> 4, h = id & 15;
+        const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
+        // this wave's pieces of this head have landed (and its Q fragments, and its stores are out).  The BUILTIN form
+        // (0x0f70 = vmcnt(0)): hipcc's own wait insertion sees it and does not put a second vmcnt(0) in front of the first
+        // use of the Q fragments — which would sit behind the next head's DMA issue and drain it
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();                             // ... everyone's have, and everyone is done with the other buffer
+        if (it > 0 && wave == 0) {                   // merge the previous head's 257th query (its partials were complete at the barrier)
+            const float* pm = (const float*)(smem + 2 * V4_BUF + (buf ^ 1) * V4_MG);
+            const int pid = id - G;
+            float M = NEG_BIG;
+#pragma unroll
+            for (int w = 0; w < V4W; ++w) M = fmaxf(M, pm[w * VMERGE_F]);
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int w = 0; w < V4W; ++w) {
+                const float a = sm_exp2(pm[w * VMERGE_F] - M);
+                L = fmaf(pm[w * VMERGE_F + 1], a, L);
+                O = fmaf(pm[w * VMERGE_F + 4 + lane], a, O);
+            }
+            out[((size_t)(pid >> 4) * VN + (VN - 1)) * 1024 + (pid & 15) * 64 + lane] = f2h(O / L);
+        }
+        // ---- the next head's K / V / last-query piece: in flight under this WHOLE head (no ordinary load is pending here: the
+        //      Q fragments were waited for above, and the last query comes out of LDS)
+        if (id + G < nheads) stage(id + G, buf ^ 1);
+        // ---- first the 257th query's partial over this wave's keys (key tile `wave`; wave 0 also key tile 16), start to finish:
+        //      nothing of it stays in registers while the full tile runs (the kernel has exactly 128 registers per lane)
+        {
+            const char* sQ = sK + V4_KB + V4_VB + 7 * 128;           // row 7 of the piece = token 256, linear chunks
+            const bf16x8 ql[2] = {*(const bf16x8*)(sQ + g * 16), *(const bf16x8*)(sQ + 64 + g * 16)};
+            f32x4 sl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = j == 0 ? wave : VNT - 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (j == 0 || wave == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                        acc = mfma16(kf, ql[kk], acc);
+                    }
+                }
+                sl[j] = acc * sc;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (wave != 0 || g != 0 || r != 0) sl[1][r] = NEG_BIG;     // tile 16 holds key 256 alone, and only wave 0 looks at it
+            float pm = NEG_BIG;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pm = fmaxf(pm, sl[j][r]);
+            pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
+            pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+            float pl = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = sm_exp2(sl[j][r] - pm);
+                    sl[j][r] = p;
+                    pl += p;
+                }
+            pl += __shfl_xor(pl, 16, 64);
+            pl += __shfl_xor(pl, 32, 64);
+            f32x4 po[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) po[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {   // k slots 0..3 <-> key tile `wave`; slots 4..7 carry zero weights (their V reads stay inside the image)
+                u32x4 pk;
+                pk[0] = pack_h2(sl[0][0], sl[0][1]);
+                pk[1] = pack_h2(sl[0][2], sl[0][3]);
+                pk[2] = 0u;
+                pk[3] = 0u;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) po[dt] = mfma16(vt_frag(sK + voff[dt] + wave * 2048), pf, po[dt]);
+            }
+            if (wave == 0) {                         // key tile 16: rows 256.. (token 256 and its clamped copies, weights 0 past the first)
+                u32x4 pk;
+                pk[0] = pack_h2(sl[1][0], sl[1][1]);
+                pk[1] = pack_h2(sl[1][2], sl[1][3]);
+                pk[2] = 0u;
+                pk[3] = 0u;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) po[dt] = mfma16(vt_frag(sK + voff[dt] + 16 * 2048), pf, po[dt]);
+            }
+            if (l15 == 0) {
+                float* mg = sMg + wave * VMERGE_F;
+                if (g == 0) { mg[0] = pm; mg[1] = pl; }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(mg + 4 + dt * 16 + 4 * g) = po[dt];
+            }
+        }
+        asm volatile("" ::: "memory");
+        // ---- QK^T of this wave's query tile (tile = wave)
+        f32x4 s[VNT];
+        {
+            const bf16x8 qf[2] = {qn[0], qn[1]};
+#pragma unroll
+            for (int t = 0; t < VNT; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
+                    acc = mfma16(kf, qf[kk], acc);
+                }
+                s[t] = acc * sc;
+                if ((t & 1) == 1) asm volatile("" ::: "memory");     // at most two key tiles of K fragments in flight (register budget)
+            }
+        }
+        // ---- softmax of the full tile; the probabilities are packed to the storage type as they are produced (34 instead of
+        //      68 registers live through the second product)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;       // keys 257..271 are padding
+        float m = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < VNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        uint32_t pb[VNT][2];
+#pragma unroll
+        for (int t = 0; t < VNT; ++t) {
+            const float p0 = sm_exp2(s[t][0] - m), p1 = sm_exp2(s[t][1] - m), p2 = sm_exp2(s[t][2] - m), p3 = sm_exp2(s[t][3] - m);
+            l += (p0 + p1) + (p2 + p3);
+            pb[t][0] = pack_h2(p0, p1);
+            pb[t][1] = pack_h2(p2, p3);
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        // ---- O^T += V^T P^T, V fragments by transpose reads
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < VNC; ++c) {
+            u32x4 pk;
+            pk[0] = pb[2 * c][0];
+            pk[1] = pb[2 * c][1];
+            pk[2] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][0] : 0u;
+            pk[3] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][1] : 0u;
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(vt_frag(sK + voff[dt] + c * 4096), pf, o[dt]);
+            asm volatile("" ::: "memory");
+            if (c == 4 && id + G < nheads) {         // this wave's Q fragments of the next head, into registers the probabilities have left
+                const int nid = id + G;
+                const uint16_t* nb = qkv + (size_t)(nid >> 4) * VN * VLD + (nid & 15) * 64;
+                qn[0] = *(const bf16x8*)(nb + (size_t)(wave * 16 + l15) * VLD + g * 8);
+                qn[1] = *(const bf16x8*)(nb + (size_t)(wave * 16 + l15) * VLD + 32 + g * 8);
+            }
+        }
+        store_tile_rows(out + ((size_t)f * VN + wave * 16 + l15) * 1024 + h * 64, o, 1.f / l, g);
+    }
+    __syncthreads();
+    if (wave == 0) {                                 // the last head's 257th query
+        const int lastit = it - 1, pid = id0 + lastit * G;
+        const float* pm = (const float*)(smem + 2 * V4_BUF + (lastit & 1) * V4_MG);
+        float M = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < V4W; ++w) M = fmaxf(M, pm[w * VMERGE_F]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < V4W; ++w) {
+            const float a = sm_exp2(pm[w * VMERGE_F] - M);
+            L = fmaf(pm[w * VMERGE_F + 1], a, L);
+            O = fmaf(pm[w * VMERGE_F + 4 + lane], a, O);
+        }
+        out[((size_t)(pid >> 4) * VN + (VN - 1)) * 1024 + (pid & 15) * 64 + lane] = f2h(O / L);
     }
 }
 
@@ -847,8 +1651,20 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
     // VLY_VIT_ATTN=2 launches vit_attn2_kernel (LDS-DMA staging, packed softmax; measured within 4 % of this one either way:
     // profiles/r03/r03_vit_attn_v1_v2.jsonl) with VLY_VIT_SKEW x 512 cycles of head start for waves 0-3
-    static const bool v2 = getenv("VLY_VIT_ATTN") && atoi(getenv("VLY_VIT_ATTN")) == 2;
-    if (!v2) hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 1;
+    if (ver == 5) hipLaunchKernelGGL(vit_attn5_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    else if (ver == 4) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        const int nheads = F * 16;
+        hipLaunchKernelGGL(vit_attn4_kernel, dim3(nheads < cus ? nheads : cus), dim3(V4W * 64), 0, (hipStream_t)stream,
+                           (const uint16_t*)qkv, (uint16_t*)out, nheads);
+    } else if (ver == 3) hipLaunchKernelGGL(vit_attn3_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+    else if (ver != 2) hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
     else {
         static const int skew = getenv("VLY_VIT_SKEW") ? atoi(getenv("VLY_VIT_SKEW")) : 0;
         hipLaunchKernelGGL(vit_attn2_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, skew);
