@@ -97,14 +97,18 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     [[maybe_unused]] const int hi16 = opaque_i32(16);          // see opaque_i32
-    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
-    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
+    const int h = blockIdx.x & 15;
+#ifndef VLY_VIT_DBG
+#define VLY_VIT_DBG 0      // timing experiments (WRONG results; A/B builds only): 1 = staging only, 2 = compute only (hipcc also folds
+                           // the LDS reads of the never-written array), 3 = no output stores, 4 = every workgroup reads frame
+                           // blockIdx & 3's q|k|v (L2-resident inputs), 5 = as 4 and writes there too (no HBM traffic at all),
+                           // 6 = softmax without the exp2, 7 = no softmax arithmetic at all
+#endif
+    const int f = VLY_VIT_DBG == 5 ? (blockIdx.x >> 4) & 3 : blockIdx.x >> 4;
+    const uint16_t* base = qkv + (size_t)(VLY_VIT_DBG >= 4 ? f & 3 : f) * VN * VLD + h * 64;
 
 #ifndef VLY_VIT_STORE
 #define VLY_VIT_STORE 1    // 1: 32-byte runs per lane after a 4 x 4 lane transpose (store_tile_rows' pattern); 0: four 8-byte pieces (A/B)
-#endif
-#ifndef VLY_VIT_DBG
-#define VLY_VIT_DBG 0      // timing experiments (WRONG results; A/B builds only): 1 = staging only, 2 = compute only, 3 = no output stores
 #endif
     // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7 ------------------------------------
     for (int s = tid; s < (VLY_VIT_DBG == 2 ? 0 : VNT * 16 * 8); s += VNW * 64) {
@@ -221,23 +225,25 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
 
         float m = NEG_BIG;
+        float l = 0.f;
+        if (VLY_VIT_DBG != 7) {                                   // 7: no softmax arithmetic at all (scores go straight to the packs)
 #pragma unroll
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
 #pragma unroll
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = sm_exp2(s[t][r] - m);
+                const float p = VLY_VIT_DBG == 6 ? s[t][r] - m : sm_exp2(s[t][r] - m);     // 6: no transcendentals
                 s[t][r] = p;
                 l += p;
             }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        } else l = 1.f;
 
 #endif
         f32x4 o[4];
