@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 3   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype */
+#define VLY_ABI_VERSION 4   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16 */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -259,6 +259,15 @@ int vly_decode_attention_rows(const void *qkv_bf16, void *kcache_bf16, void *vca
 int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                   int epilogue, int out_dtype, void *stream);
+
+/* The same GEMV with the RMSNorm that feeds it folded in:  C = epi(rmsnorm(H; gamma, eps) · W^T + bias) + residual,
+ *   H the fp32 residual stream [M, K] (row stride ldh), M <= 2, 2048 <= K <= 6144.  Replaces the pairs
+ *   input_layernorm -> q|k|v, post_attention_layernorm -> gate|up and norm -> lm_head of a decode step
+ *   (HF LlamaDecoderLayer.forward / LlamaModel.norm + lm_head behind serve/model_worker.py:380-387): two launches and two
+ *   kernel boundaries per layer less.  Bit-identical to vly_rmsnorm followed by vly_gemv_bf16. */
+int vly_gemv_rmsnorm_bf16(const float *H, const float *gamma, float eps, const void *W, const float *bias,
+                          const float *residual, void *C, int M, int N, int K, int ldh, int ldw, int ldc, int ldr,
+                          int epilogue, int out_dtype, void *stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) over n contiguous elements, n % 8 == 0: the `.to(dtype)`
  *   between an fp32 tensor and a GEMM input (only used on the `max`-pooling path, where the

@@ -130,6 +130,32 @@ def test_gemv(M):
     assert relerr(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 15360, 5120), (2, 1000, 4096), (1, 32008, 5120), (1, 4098, 2048), (2, 64, 6144), (1, 6, 4096)])
+def test_gemv_rmsnorm_is_bit_identical_to_the_pair(M, N, K):
+    """vly_gemv_rmsnorm_bf16 == vly_rmsnorm then vly_gemv_bf16, bit for bit (all three epilogue / out forms the decode step
+    uses, plus bias + residual), and both agree with the fp32 formula."""
+    from valley_amd import ops
+    d = dev()
+    h = (rnd((M, K), 31, 1.5) + 0.1).to(d)
+    g = (rnd((K,), 32, 0.1) + 1.0).to(d)
+    w = rnd((N, K), 33, 0.03, dtype=torch.bfloat16).to(d)
+    bias = rnd((N,), 34, 0.5).to(d)
+    res = rnd((M, N), 35).to(d)
+    x = ops.rmsnorm(h, g, 1e-6)
+    for kw in (dict(), dict(out_dtype=torch.float32), dict(bias=bias, residual=res, out_dtype=torch.float32)) + \
+            ((dict(epilogue=ops.EPI_SWIGLU),) if N % 2 == 0 else ()):
+        pair = ops.gemv(x, w, **kw)
+        fused = ops.gemv_rmsnorm(h, g, 1e-6, w, **kw)
+        assert torch.equal(pair, fused), kw
+    hf = h.float().cpu()
+    xr = (g.cpu() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6))).to(torch.bfloat16).float()
+    ref = xr @ w.float().cpu().t()
+    assert relerr(ops.gemv_rmsnorm(h, g, 1e-6, w, out_dtype=torch.float32), ref) < 3e-3
+    assert not ops.gemv_rmsnorm_ok(3, K) and not ops.gemv_rmsnorm_ok(1, 1024)
+    with pytest.raises(Exception):
+        ops.gemv_rmsnorm(h[:, :1024].contiguous(), g[:1024].contiguous(), 1e-6, w[:, :1024].contiguous())
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("D", [1024, 4096, 5120, 256])
 def test_norms(D):

@@ -23,11 +23,20 @@ for spec in sys.argv[1].split(";"):
         ops.gemv(a, w, residual=res, epilogue=epi, out=out, out_dtype=out.dtype)
     torch.cuda.synchronize()
     reps = 5
+    # one hipGraph of reps x copies launches: short kernels (N = 5120, K = 5120 runs ~8 us) would otherwise time the
+    # ~10 us Python launch path, not the kernel
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(reps):
+            for w in ws:
+                ops.gemv(a, w, residual=res, epilogue=epi, out=out, out_dtype=out.dtype)
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        for w in ws:
-            ops.gemv(a, w, residual=res, epilogue=epi, out=out, out_dtype=out.dtype)
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * ncopy)

@@ -18,95 +18,140 @@ VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {
     return s;
 }
 
-// KS = 1: every wave owns two weight rows (short rows).  KS = 4 (K >= 2048, i.e. every decode projection): the
-// workgroup owns two rows and its four waves split K, partial sums meet in LDS — four times the waves, hence
+// KS = 1: every wave owns NR weight rows (short rows).  KS = 4 (K >= 2048, i.e. every decode projection): the
+// workgroup owns NR rows and its four waves split K, partial sums meet in LDS — four times the waves, hence
 // four times the loads in flight: o/down 4.0-4.5 -> 4.9-5.5 TB/s, q|k|v 5.9 -> 6.4, gate/up 6.5 -> 6.8, lm_head 6.9.
-template <int MR, int EPI, int OUT, int KS>
+// NR = 2 or 4 rows per workgroup, chosen per shape by launch_mr for the BALANCE of the launch: a CU holds eight
+// 4-wave workgroups of the NR = 2 kernel (<= 64 registers) — with N = 5120 (o / down of the 13B decoder) that is 2560
+// workgroups on 2048 slots, a second round at a quarter of the chip (the 5.2 TB/s of those two GEMVs next to the 6.8
+// of gate/up); NR = 4 makes it 1280 workgroups = exactly five per CU, all resident, every CU streaming to the end.
+template <int MR, int EPI, int OUT, int KS, int NR>
 __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                    const float* __restrict__ bias, const float* __restrict__ R,
                                                    void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
-    __shared__ float red[KS == 1 ? 1 : KS * 2 * MR];
+    __shared__ float red[KS == 1 ? 1 : KS * NR * MR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = (KS == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * 2;
+    const int n0 = (KS == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * NR;
     if (n0 >= N) return;
-    const uint16_t* w0 = W + (size_t)n0 * ldw;
-    const uint16_t* w1 = W + (size_t)min(n0 + 1, N - 1) * ldw;
-    float acc0[MR], acc1[MR];
+    const uint16_t* w[NR];
 #pragma unroll
-    for (int m = 0; m < MR; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+    for (int r = 0; r < NR; ++r) w[r] = W + (size_t)min(n0 + r, N - 1) * ldw;
+    float acc[NR][MR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
     const int nch = K >> 3;
-#pragma unroll 4
+#pragma clang loop unroll_count(8 / NR)
     for (int c = (KS == 1 ? lane : wave * 64 + lane); c < nch; c += 64 * KS) {
-        const u32x4 x0 = __builtin_nontemporal_load((const u32x4*)(w0 + 8 * c));
-        const u32x4 x1 = __builtin_nontemporal_load((const u32x4*)(w1 + 8 * c));
+        u32x4 x[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = __builtin_nontemporal_load((const u32x4*)(w[r] + 8 * c));
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const u32x4 a = *(const u32x4*)(A + (size_t)min(m, M - 1) * lda + 8 * c);
-            acc0[m] += dot8(x0, a);
-            acc1[m] += dot8(x1, a);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r][m] += dot8(x[r], a);
         }
     }
 #pragma unroll
-    for (int m = 0; m < MR; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[r][m] = wave_sum(acc[r][m]);
     if constexpr (KS > 1) {
         if (lane == 0) {
 #pragma unroll
-            for (int m = 0; m < MR; ++m) { red[(wave * MR + m) * 2] = acc0[m]; red[(wave * MR + m) * 2 + 1] = acc1[m]; }
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) red[(wave * MR + m) * NR + r] = acc[r][m];
         }
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {                       // fixed order: wave 0 + 1 + 2 + ...
-            float s0 = red[m * 2], s1 = red[m * 2 + 1];
+        for (int m = 0; m < MR; ++m)                         // fixed order: wave 0 + 1 + 2 + ...
 #pragma unroll
-            for (int w = 1; w < KS; ++w) { s0 += red[(w * MR + m) * 2]; s1 += red[(w * MR + m) * 2 + 1]; }
-            acc0[m] = s0;
-            acc1[m] = s1;
-        }
+            for (int r = 0; r < NR; ++r) {
+                float s = red[m * NR + r];
+#pragma unroll
+                for (int wv = 1; wv < KS; ++wv) s += red[(wv * MR + m) * NR + r];
+                acc[r][m] = s;
+            }
     }
     if (lane != 0) return;
-    const bool has1 = n0 + 1 < N;
-    const float b0 = bias ? bias[n0] : 0.f, b1 = (bias && has1) ? bias[n0 + 1] : 0.f;
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        if (m >= M) break;
-        float v0 = acc0[m] + b0, v1 = acc1[m] + b1;
-        if constexpr (EPI == VLY_EPI_QUICK_GELU) {
-            v0 = x_sigmoid(v0, 1.702f);
-            v1 = x_sigmoid(v1, 1.702f);
-        }
-        if constexpr (EPI == VLY_EPI_SWIGLU) {
-            const float o = x_sigmoid(v0, 1.f) * v1;
-            const size_t off = (size_t)m * ldc + (n0 >> 1);
-            if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f2h(o);
-            else ((float*)Cv)[off] = o;
-        } else {
-            if (R) {
-                v0 += R[(size_t)m * ldr + n0];
-                if (has1) v1 += R[(size_t)m * ldr + n0 + 1];
+    for (int rp = 0; rp < NR; rp += 2) {                     // row pairs: (gate, up) under SwiGLU
+        const int n = n0 + rp;
+        if (n >= N) break;
+        const bool has1 = n + 1 < N;
+        const float b0 = bias ? bias[n] : 0.f, b1 = (bias && has1) ? bias[n + 1] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= M) break;
+            float v0 = acc[rp][m] + b0, v1 = acc[rp + 1][m] + b1;
+            if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+                v0 = x_sigmoid(v0, 1.702f);
+                v1 = x_sigmoid(v1, 1.702f);
             }
-            const size_t off = (size_t)m * ldc + n0;
-            if constexpr (OUT == VLY_OUT_BF16) {
-                ((uint16_t*)Cv)[off] = f2h(v0);
-                if (has1) ((uint16_t*)Cv)[off + 1] = f2h(v1);
+            if constexpr (EPI == VLY_EPI_SWIGLU) {
+                const float o = x_sigmoid(v0, 1.f) * v1;
+                const size_t off = (size_t)m * ldc + (n >> 1);
+                if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f2h(o);
+                else ((float*)Cv)[off] = o;
             } else {
-                ((float*)Cv)[off] = v0;
-                if (has1) ((float*)Cv)[off + 1] = v1;
+                if (R) {
+                    v0 += R[(size_t)m * ldr + n];
+                    if (has1) v1 += R[(size_t)m * ldr + n + 1];
+                }
+                const size_t off = (size_t)m * ldc + n;
+                if constexpr (OUT == VLY_OUT_BF16) {
+                    ((uint16_t*)Cv)[off] = f2h(v0);
+                    if (has1) ((uint16_t*)Cv)[off + 1] = f2h(v1);
+                } else {
+                    ((float*)Cv)[off] = v0;
+                    if (has1) ((float*)Cv)[off + 1] = v1;
+                }
             }
         }
     }
 }
 
+int cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
+// fraction of the resident slots a launch of `wgs` equal workgroups keeps busy (whole rounds of `slots`)
+float balance(int wgs, int slots) { return (float)wgs / (float)(((wgs + slots - 1) / slots) * slots); }
+
 template <int MR>
 int launch_mr(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
               int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
     const bool split = K >= 2048;                            // long rows: the workgroup's four waves split K
-    dim3 grid(split ? (N + 1) / 2 : (N + 7) / 8), block(256);
+    // rows per workgroup (see gemv_kernel): the NR = 2 kernel is resident eight to a CU, NR = 4 five to a CU (<= 96 registers);
+    // four rows only where they fill the rounds better (VLY_GEMV_ROWS=2|4 pins it for A/B runs)
+    static const int pin = [] { const char* e = getenv("VLY_GEMV_ROWS"); return e ? atoi(e) : 0; }();
+    bool four = false;
+    if (split && MR <= 2 && N >= 8) {
+        const int cus = cu_count();
+        four = pin ? pin == 4 : balance((N + 3) / 4, cus * 5) > balance((N + 1) / 2, cus * 8) + 0.02f;
+    }
+    dim3 grid(split ? (four ? (N + 3) / 4 : (N + 1) / 2) : (N + 7) / 8), block(256);
 #define VLY_GEMV(E, O)                                                                                            \
     do {                                                                                                          \
-        if (split) hipLaunchKernelGGL((gemv_kernel<MR, E, O, 4>), grid, block, 0, st, (const uint16_t*)A,         \
+        if constexpr (MR <= 2) {                                                                                  \
+            if (four) {                                                                                           \
+                hipLaunchKernelGGL((gemv_kernel<MR, E, O, 4, 4>), grid, block, 0, st, (const uint16_t*)A,         \
+                                   (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr);                  \
+                break;                                                                                            \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (split) hipLaunchKernelGGL((gemv_kernel<MR, E, O, 4, 2>), grid, block, 0, st, (const uint16_t*)A,      \
                                       (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr);               \
-        else hipLaunchKernelGGL((gemv_kernel<MR, E, O, 1>), grid, block, 0, st, (const uint16_t*)A,               \
+        else hipLaunchKernelGGL((gemv_kernel<MR, E, O, 1, 2>), grid, block, 0, st, (const uint16_t*)A,            \
                                 (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, ldc, ldr);                     \
     } while (0)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMV(VLY_EPI_NONE, VLY_OUT_BF16);
@@ -119,6 +164,200 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
     }
 #undef VLY_GEMV
     return vly_check_launch("vly_gemv_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm folded into the GEMV that consumes it (decode: input_layernorm -> q|k|v, post_attention_layernorm -> gate|up,
+// norm -> lm_head): C = epi(rmsnorm(H; gamma, eps) · W^T + bias) + residual, H the fp32 residual stream.
+// A batch-1 decode layer is short weight-streaming kernels back to back; a norm launch between two of them costs its body
+// plus a kernel boundary (MI355X_MICROARCH "boundary" / "launches-baseline") and moves 30 KB.  Here the norm is computed once
+// per CU — norm_row_kernel's arithmetic operation for operation, so x and everything downstream are BIT-IDENTICAL to
+// vly_rmsnorm + vly_gemv_bf16 — into LDS, and the GEMV loop reads x from LDS instead of re-fetching it through the vector
+// cache beside the weight stream.  Measured (13B decode, 256 tokens, same box, interleaved): 201.5 -> 207.0 tokens/s; three
+// structures of the prologue (five 256-thread workgroups per CU each normalising for itself, with and without a second
+// pair in flight, and this one) all land within 0.3 % of each other — profiles/r03/r03_decode_fuse_norm.txt.
+// ---------------------------------------------------------------------------------------------
+template <int CH>
+struct PairRegs {
+    u32x4 x0[CH], x1[CH];
+};
+
+template <int MR, int EPI, int OUT, int CH>
+__global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict__ H, const float* __restrict__ gamma, float eps,
+                                                         const uint16_t* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K,
+                                                         int ldh, int ldw, int ldc, int ldr) {
+    // ONE 16-wave workgroup per CU = four 256-thread GROUPS, each of which is a gemv_kernel<.., 4, 2> workgroup (same chunk
+    // order per thread, same wave sums, same fixed-order sum over its four waves) walking its own row pairs; the norm is
+    // computed ONCE per CU, by group 0 with norm_row_kernel's arithmetic, into LDS (256 x 40 KB of H and gamma leave L2 per
+    // launch instead of 1280 x 40 KB).
+    extern __shared__ __attribute__((aligned(16))) char gn_dyn[];
+    uint16_t* xs = (uint16_t*)gn_dyn;                                   // [MR][K]
+    __shared__ float red[2][4][4 * 2 * MR];
+    __shared__ float nred[4];
+    const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8, lane = tid & 63, wave = tid >> 6;
+    const int nvec = K >> 2, nch = K >> 3;
+    // A row pair is CH 16-byte chunks per thread and row (CH = ceil(K / 2048)), all issued at once.  Two pairs are in
+    // flight per group: pair i + 1's loads leave before pair i is reduced, and the FIRST pair's loads leave before the norm
+    // prologue, so the weight stream starts with the kernel.
+    auto load_pair = [&](PairRegs<CH>& p, int n0) {
+        // UNCONDITIONAL, branch-free loads: behind exec-masked branches hipcc loses count of what is in flight and waits
+        // vmcnt(0) — for the prefetched pair too.  A ragged last chunk, and the pair past the end a group "prefetches"
+        // in its last trip, read W[0..7] (one cache line for the whole group) and are never accumulated.
+        const bool live = n0 < N;
+        const uint16_t* w0 = W + (live ? (size_t)n0 * ldw : 0);
+        const uint16_t* w1 = W + (live ? (size_t)min(n0 + 1, N - 1) * ldw : 0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + 256 * i;
+            const int off = (live && c < nch) ? 8 * c : 0;
+            p.x0[i] = __builtin_nontemporal_load((const u32x4*)(w0 + off));
+            p.x1[i] = __builtin_nontemporal_load((const u32x4*)(w1 + off));
+        }
+    };
+    auto reduce_pair = [&](const PairRegs<CH>& p, int n0, float* rd) {      // (every group, every trip: the barrier is the workgroup's)
+        float acc0[MR], acc1[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {                       // chunk order per thread as gemv_kernel<.., 4, 2>: tid, tid + 256, ...
+            const int c = tid + 256 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const u32x4 a = *(const u32x4*)(xs + (size_t)m * K + 8 * c);
+                    acc0[m] += dot8(p.x0[i], a);
+                    acc1[m] += dot8(p.x1[i], a);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m) { rd[(wave * MR + m) * 2] = acc0[m]; rd[(wave * MR + m) * 2 + 1] = acc1[m]; }
+        }
+        __syncthreads();                                     // (one barrier per pair: the two halves of red alternate)
+        if (tid != 0 || n0 >= N) return;
+        const bool has1 = n0 + 1 < N;
+        const float b0 = bias ? bias[n0] : 0.f, b1 = (bias && has1) ? bias[n0 + 1] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= M) break;
+            float s0 = rd[m * 2], s1 = rd[m * 2 + 1];        // fixed order: wave 0 + 1 + 2 + 3 (gemv_kernel's)
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) { s0 += rd[(wv * MR + m) * 2]; s1 += rd[(wv * MR + m) * 2 + 1]; }
+            float v0 = s0 + b0, v1 = s1 + b1;
+            if constexpr (EPI == VLY_EPI_SWIGLU) {
+                const float o = x_sigmoid(v0, 1.f) * v1;
+                const size_t off = (size_t)m * ldc + (n0 >> 1);
+                if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f2h(o);
+                else ((float*)Cv)[off] = o;
+            } else {
+                if (R) {
+                    v0 += R[(size_t)m * ldr + n0];
+                    if (has1) v1 += R[(size_t)m * ldr + n0 + 1];
+                }
+                const size_t off = (size_t)m * ldc + n0;
+                if constexpr (OUT == VLY_OUT_BF16) {
+                    ((uint16_t*)Cv)[off] = f2h(v0);
+                    if (has1) ((uint16_t*)Cv)[off + 1] = f2h(v1);
+                } else {
+                    ((float*)Cv)[off] = v0;
+                    if (has1) ((float*)Cv)[off + 1] = v1;
+                }
+            }
+        }
+    };
+    PairRegs<CH> pa, pb;
+    const int first = ((int)blockIdx.x * 4 + grp) * 2, stride = gridDim.x * 4 * 2;
+    if (grp == 0) {
+        // issue order: row 0 of H and gamma FIRST, then the weights — vmcnt retires in order, so the norm below waits for its
+        // own operands only and runs under the weights' HBM latency
+        float4 v[2 * CH], gm[2 * CH];                                    // K <= 2048 CH: 2 CH float4 per thread cover a row
+        auto load_h = [&](int m) {
+            const float4* hr = (const float4*)(H + (size_t)min(m, M - 1) * ldh);
+#pragma unroll
+            for (int i = 0; i < 2 * CH; ++i) {
+                const int c = tid + 256 * i;
+                const float4 t = hr[min(c, nvec - 1)];
+                v[i] = (c < nvec) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        load_h(0);
+#pragma unroll
+        for (int i = 0; i < 2 * CH; ++i) gm[i] = ((const float4*)gamma)[min(tid + 256 * i, nvec - 1)];
+        load_pair(pa, first);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m > 0) load_h(m);
+            float s = 0.f;                                               // norm_row_kernel's arithmetic, operation for operation
+#pragma unroll
+            for (int i = 0; i < 2 * CH; ++i) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            s = wave_sum(s);
+            if (lane == 0) nred[wave] = s;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // group 0's four waves only meet here: see below
+            s = nred[0] + nred[1] + nred[2] + nred[3];
+            const float rstd = rsqrtf(s / (float)K + eps);
+#pragma unroll
+            for (int i = 0; i < 2 * CH; ++i) {
+                const int c = tid + 256 * i;
+                if (c >= nvec) continue;
+                float4 o;
+                o.x = gm[i].x * (v[i].x * rstd); o.y = gm[i].y * (v[i].y * rstd);
+                o.z = gm[i].z * (v[i].z * rstd); o.w = gm[i].w * (v[i].w * rstd);
+                u32x2 pk;
+                pk[0] = pack_h2(o.x, o.y);
+                pk[1] = pack_h2(o.z, o.w);
+                *(u32x2*)(xs + (size_t)m * K + 4 * c) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
+        load_pair(pa, first);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {                                   // the other groups arrive at the same 2 MR barriers
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+    }
+    // trips are counted for the workgroup (group 0 owns the lowest pair index, so its count is the largest): every group
+    // passes every barrier, pairs past N are loaded from W[0..7] and dropped
+#pragma unroll 1
+    for (int n0 = first, nb = (int)blockIdx.x * 8; nb < N; n0 += 2 * stride, nb += 2 * stride) {
+        const int n1 = n0 + stride;
+        load_pair(pb, n1);
+        reduce_pair(pa, n0, red[0][grp]);
+        if (nb + stride >= N) break;
+        load_pair(pa, n1 + stride);
+        reduce_pair(pb, n1, red[1][grp]);
+    }
+}
+
+template <int MR>
+int launch_norm_mr(const float* H, const float* gamma, float eps, const void* W, const float* bias, const float* R, void* C, int M,
+                   int N, int K, int ldh, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
+    const size_t lds = (size_t)MR * K * 2;
+    const int pairs = (N + 1) / 2, groups = (pairs + 3) / 4;
+    dim3 grid(groups < cu_count() ? groups : cu_count()), block(1024);       // one 16-wave workgroup per CU
+#define VLY_GEMVN_CH(E, O, CH)                                                                                     \
+    hipLaunchKernelGGL((gemv_norm_kernel<MR, E, O, CH>), grid, block, lds, st, H, gamma, eps, (const uint16_t*)W, bias, R, C, M, \
+                       N, K, ldh, ldw, ldc, ldr)
+#define VLY_GEMVN(E, O)                                                                                           \
+    do {                                                                                                          \
+        if (K <= 4096) VLY_GEMVN_CH(E, O, 2);                                                                     \
+        else VLY_GEMVN_CH(E, O, 3);                                                                               \
+    } while (0)
+    if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMVN(VLY_EPI_NONE, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMVN(VLY_EPI_NONE, VLY_OUT_F32);
+    else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMVN(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    else {
+        vly_set_error("vly_gemv_rmsnorm_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
+        return -22;
+    }
+#undef VLY_GEMVN_CH
+#undef VLY_GEMVN
+    return vly_check_launch("vly_gemv_rmsnorm_bf16");
 }
 
 }  // namespace
@@ -135,4 +374,18 @@ extern "C" int vly_gemv_bf16(const void* A, const void* W, const float* bias, co
     if (M == 2) return launch_mr<2>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
     if (M <= 4) return launch_mr<4>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
     return launch_mr<8>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+}
+
+extern "C" int vly_gemv_rmsnorm_bf16(const float* H, const float* gamma, float eps, const void* W, const float* bias,
+                                     const float* residual, void* C, int M, int N, int K, int ldh, int ldw, int ldc, int ldr,
+                                     int epilogue, int out_dtype, void* stream) {
+    if (M <= 0 || M > 2 || N <= 0 || K < 2048 || K > 6144 || K % 8 || ldh % 4 || ldw % 8 || ldw <= 0 || ((uintptr_t)H & 15) ||
+        ((uintptr_t)gamma & 15) || ((uintptr_t)W & 15) || (epilogue == VLY_EPI_SWIGLU && (N % 2 || residual))) {
+        vly_set_error("vly_gemv_rmsnorm_bf16: unsupported shape/alignment M=%d N=%d K=%d ldh=%d ldw=%d (M <= 2, 2048 <= K <= 6144)", M, N, K,
+                      ldh, ldw);
+        return -22;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 1) return launch_norm_mr<1>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st);
+    return launch_norm_mr<2>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st);
 }

@@ -1,16 +1,17 @@
 """hipGraph-captured autoregressive decode step (BASELINE.json configs[4]; the loop of
 valley/serve/model_worker.py:380-394 and of HF ``generate`` behind valley_model.py:432).
 
-One decode step = embedding gather of the current token -> L x [RMSNorm, q|k|v GEMV, RoPE + KV append,
-decode attention, o GEMV(+res), RMSNorm, gate/up GEMV with SwiGLU, down GEMV(+res)] -> RMSNorm ->
-lm_head GEMV -> argmax -> position += 1.  Every kernel is HBM-bound weight/KV streaming, ~8 launches
-per layer: launched eagerly from Python the step would be host-bound (>300 launches x ~15 us), so the
+One decode step = embedding gather of the current token -> L x [RMSNorm + q|k|v GEMV, RoPE + KV append +
+decode attention, o GEMV(+res), RMSNorm + gate/up GEMV with SwiGLU, down GEMV(+res)] -> RMSNorm +
+lm_head GEMV -> argmax -> position += 1.  Every kernel is HBM-bound weight/KV streaming, 5 launches
+per layer (the norms ride inside the GEMV that consumes them at batch <= 2; 7 otherwise): launched eagerly from Python the step would be host-bound (>300 launches x ~15 us), so the
 step is captured ONCE into a hipGraph and replayed.  Static shapes are what capture needs: the KV
 cache is pre-allocated to ctx_max, and the only thing that changes between replays — the position —
 lives on the device (``pos``) and is read by vly_rope_kv / vly_llama_attention through their
 ``past_len_dev`` argument."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -18,6 +19,9 @@ import torch
 from . import ops
 from .runtime import HALF
 from .llama import HipKVCache, HipLlama
+
+
+FUSE_NORM = os.environ.get("VALLEY_DECODE_FUSE_NORM", "1") != "0"
 
 
 class DecodeSession:
@@ -46,22 +50,34 @@ class DecodeSession:
     def _enqueue_step(self):
         ll, c = self.ll, self.cache
         B = self.B
+        # the three norm -> projection seams as one launch each where the fused kernel takes the shape (bit-identical either way;
+        # VALLEY_DECODE_FUSE_NORM=0 keeps the pairs, for A/B runs)
+        fused = FUSE_NORM and ops.gemv_rmsnorm_ok(B, ll.H)
         ops.embed_splice(self.tok, ll.embed, None, out=self.h)
         for li in range(ll.L):
             L = ll.layers[li]
-            ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
-            ops.gemv(self.x, L["w_qkv"], out=self.qkv)
+            if fused:
+                ops.gemv_rmsnorm(self.h, L["ln1"], ll.eps, L["w_qkv"], out=self.qkv)      # input_layernorm inside the q|k|v GEMV
+            else:
+                ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
+                ops.gemv(self.x, L["w_qkv"], out=self.qkv)
             if self.per_row:
                 ops.decode_attention_rows(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, self.pos, out=self.att)
             else:
                 ops.decode_attention(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, out=self.att,
                                      past_dev=self.pos)          # RoPE + KV append + attention in one launch
             ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
-            ops.rmsnorm(self.h, L["ln2"], ll.eps, out=self.x)
-            ops.gemv(self.x, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)
+            if fused:
+                ops.gemv_rmsnorm(self.h, L["ln2"], ll.eps, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)
+            else:
+                ops.rmsnorm(self.h, L["ln2"], ll.eps, out=self.x)
+                ops.gemv(self.x, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)
             ops.gemv(self.mlp, L["w_down"], residual=self.h, out=self.h)
-        ops.rmsnorm(self.h, ll.norm, ll.eps, out=self.x)
-        ops.gemv(self.x, ll.lm_head, out=self.logits)
+        if fused:
+            ops.gemv_rmsnorm(self.h, ll.norm, ll.eps, ll.lm_head, out=self.logits)
+        else:
+            ops.rmsnorm(self.h, ll.norm, ll.eps, out=self.x)
+            ops.gemv(self.x, ll.lm_head, out=self.logits)
         # greedy next token straight into the input slot of the next step (the V-padding columns of the
         # lm_head buffer are excluded through the row stride)
         ops.argmax(self.logits[:, :ll.V], out=self.tok)

@@ -312,6 +312,38 @@ def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
 
+def gemv_rmsnorm(h, gamma, eps, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=None):
+    """vly_gemv_rmsnorm_bf16: gemv(rmsnorm(h, gamma, eps), w, ...) in one launch (M <= 2 rows, 2048 <= K <= 6144) — bit-identical
+    to the pair; the decode step's norm -> projection seams."""
+    _chk(h, torch.float32, "h", contiguous=False)
+    _chk(gamma, torch.float32, "gamma")
+    wt, ldw = _w_args(w, False)
+    assert h.dim() == 2 and len(w.shape) == 2 and h.stride(1) == 1 and h.shape[1] == w.shape[1] == gamma.numel(), (h.shape, w.shape)
+    M, K = h.shape
+    N = w.shape[0]
+    No = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, No), dtype=out_dtype, device=h.device)
+    else:
+        assert tuple(out.shape) == (M, No) and out.stride(1) == 1, (out.shape, (M, No))
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    if residual is not None:
+        _chk(residual, torch.float32, "residual", contiguous=False)
+        assert tuple(residual.shape) == (M, N) and residual.stride(1) == 1
+    od = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    rc = _lib.load().vly_gemv_rmsnorm_bf16(h.data_ptr(), gamma.data_ptr(), eps, wt.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                           M, N, K, h.stride(0), ldw, out.stride(0), residual.stride(0) if residual is not None else 0,
+                                           epilogue, od, _stream())
+    _lib.check(rc, "vly_gemv_rmsnorm_bf16")
+    return out
+
+
+def gemv_rmsnorm_ok(M: int, K: int) -> bool:
+    """Shapes vly_gemv_rmsnorm_bf16 takes (the caller keeps rmsnorm + gemv otherwise)."""
+    return M <= 2 and 2048 <= K <= 6144 and K % 8 == 0
+
+
 # "tuned"  (default): per (M,N,K,epilogue,out dtype) pick the fastest of {whole-tile, stream-K} x {tile shapes}
 #                      x {loop variants} ONLINE: while a shape is undecided every call runs the next candidate
 #                      on the real operands in its real place in the step (producer output warm in cache,
