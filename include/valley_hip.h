@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 4   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16 */
+#define VLY_ABI_VERSION 4   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
+                               vly_decode_attention_split, vly_gemv_attnmerge_bf16 */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -253,6 +254,19 @@ int vly_decode_attention_rows(const void *qkv_bf16, void *kcache_bf16, void *vca
                               const float *sin_table, const uint8_t *key_valid, int key_valid_stride, void *out_bf16,
                               int B, int heads, const int32_t *past_len_rows, int ctx_max, void *stream);
 
+/* The same step split over the keys (flash-decoding): every head is VLY_DECODE_SPLITS workgroups, each over a 64-aligned
+ *   quarter of the keys, so a batch-1 step keeps 4 x heads CUs busy instead of `heads`.  Writes, per (row, head, split),
+ *   132 fp32 = {running max (log2 domain), sum of exponentials, 0, 0, unnormalised P·V[128]} to `partials`
+ *   ([B][heads][VLY_DECODE_SPLITS][132], 16-byte aligned); vly_gemv_attnmerge_bf16 — the o projection — merges them.
+ *   past_len_dev_stride: 0 = one device position for the batch (as vly_decode_attention), 1 = one per row
+ *   (as vly_decode_attention_rows).  Same RoPE / append arithmetic as vly_decode_attention; the softmax sums are
+ *   associated per split, so outputs agree with it to fp32 rounding, not bit for bit. */
+#define VLY_DECODE_SPLITS 4
+int vly_decode_attention_split(const void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
+                               const float *sin_table, const uint8_t *key_valid, int key_valid_stride, float *partials,
+                               int B, int heads, int past_len, const int32_t *past_len_dev, int past_len_dev_stride,
+                               int ctx_max, void *stream);
+
 /* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
  *   serve/model_worker.py:380-387 (one-token forward). */
@@ -268,6 +282,12 @@ int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *
 int vly_gemv_rmsnorm_bf16(const float *H, const float *gamma, float eps, const void *W, const float *bias,
                           const float *residual, void *C, int M, int N, int K, int ldh, int ldw, int ldc, int ldr,
                           int epilogue, int out_dtype, void *stream);
+
+/* The o projection of a decode step with the merge of vly_decode_attention_split's partials folded in:
+ *   C = (merge(partials) as bf16 [M, heads*128]) · W^T + bias + residual, M <= 2 rows, 2048 <= K = heads*128 <= 6144.
+ *   (HF LlamaAttention.forward: attn_output -> o_proj, behind serve/model_worker.py:380-387.) */
+int vly_gemv_attnmerge_bf16(const float *partials, const void *W, const float *bias, const float *residual, void *C,
+                            int M, int N, int heads, int ldw, int ldc, int ldr, int out_dtype, void *stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) over n contiguous elements, n % 8 == 0: the `.to(dtype)`
  *   between an fp32 tensor and a GEMM input (only used on the `max`-pooling path, where the

@@ -345,6 +345,61 @@ def test_decode_attention_fused_equals_rope_then_attention(B, past, heads, pad, 
     assert torch.equal(got3, got) and torch.equal(k3, k2)
 
 
+@pytest.mark.parametrize("B,past,pad,ctx_max,per_row", [(1, 0, 0, 64, False), (1, 5, 0, 600, False), (1, 336, 0, 600, False),
+                                                        (2, 463, 7, 600, False), (1, 1100, 0, 1200, False), (2, 255, 0, 300, True),
+                                                        (2, 700, 300, 1024, True), (1, 64, 0, 128, False)])
+def test_decode_attention_split_and_merge(B, past, pad, ctx_max, per_row):
+    """vly_decode_attention_split + vly_gemv_attnmerge_bf16 vs vly_decode_attention(_rows) + vly_gemv_bf16: the appended cache rows
+    are bit-identical; the projected output agrees to the rounding of the attention output (one bf16 ulp of a few elements,
+    through a K = 2048 dot product).  Covers empty splits (short contexts), two passes per split (kv_len > 1024), masks,
+    per-row positions, the position on a split boundary (past = 64)."""
+    from valley_amd import ops
+    d = dev()
+    heads, N = 16, 264                       # K = 2048: the narrowest width the fused GEMVs take
+    Hq = heads * 128
+    cos, sin = _rope_tables(ctx_max)
+    cos, sin = cos.to(d), sin.to(d)
+    pasts = [past, max(past - 130, 0)][:B] if per_row else [past] * B
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    for b in range(B):
+        if pasts[b]:
+            kc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 30 + b, dtype=torch.bfloat16)
+            vc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 40 + b, dtype=torch.bfloat16)
+    qkv = rnd((B, 3 * Hq), 32, dtype=torch.bfloat16).to(d)
+    w = rnd((N, Hq), 33, 0.05, dtype=torch.bfloat16).to(d)
+    res = rnd((B, N), 34).to(d)
+    valid = None
+    if pad or per_row:
+        valid = torch.ones((B, ctx_max), dtype=torch.uint8)
+        valid[0, :pad] = 0
+        valid = valid.to(d)
+    pos = torch.tensor(pasts if per_row else [past], dtype=torch.int32, device=d)
+    k1, v1 = kc.to(d), vc.to(d)
+    if per_row:
+        att = ops.decode_attention_rows(qkv, k1, v1, cos, sin, valid, B, heads, pos)
+    else:
+        att = ops.decode_attention(qkv, k1, v1, cos, sin, valid, B, heads, 0, past_dev=pos)
+    want = ops.gemv(att, w, residual=res, out_dtype=torch.float32)
+    k2, v2 = kc.to(d), vc.to(d)
+    parts = ops.decode_partials(B, heads, d)
+    ops.decode_attention_split(qkv, k2, v2, cos, sin, valid, B, heads, 0, parts, past_dev=pos, per_row=per_row)
+    got = ops.gemv_attnmerge(parts, w, residual=res, out_dtype=torch.float32)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert relerr(got - res, want - res) < 4e-3 and maxabs(got, want) < 2e-2, (relerr(got - res, want - res), maxabs(got, want))
+    # the merged attention output itself, through an identity-like projection: rows of W = unit vectors
+    eye = torch.zeros((256, Hq), dtype=torch.bfloat16)
+    eye[torch.arange(256), torch.arange(256) * 8] = 1.0
+    m_att = ops.gemv_attnmerge(parts, eye.to(d), out_dtype=torch.float32)
+    assert maxabs(m_att, att[:, ::8][:, :256].float()) <= 2e-2
+    if not per_row:                          # host-side position, bf16 output
+        k3, v3 = kc.to(d), vc.to(d)
+        parts3 = ops.decode_partials(B, heads, d)
+        ops.decode_attention_split(qkv, k3, v3, cos, sin, valid[:, :past + 1].contiguous() if valid is not None else None, B, heads, past, parts3)
+        assert torch.equal(parts3, parts) and torch.equal(k3, k2)
+        assert relerr(ops.gemv_attnmerge(parts, w), want - res) < 8e-3
+
+
 @pytest.mark.parametrize("tile", [0, 2, 7, 8, 84, 86, 9])
 @pytest.mark.parametrize("M,N,K", [(1312, 1024, 1024), (300, 264, 192), (77, 512, 128)])
 def test_gemm_splitk2_and_add2_rmsnorm(M, N, K, tile):

@@ -1651,6 +1651,146 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
     }
 }
 
+// ---- decode attention split over the keys (flash-decoding) ----------------------------------------------------------------
+// decode_fused_kernel gives a head to ONE workgroup: at batch 1 that is `heads` (40) of 256 CUs, each pulling its head's
+// 2 x kv_len x 256 B of K and V through one CU's memory pipe (~10 us per layer at kv_len ~ 450 for 9 MB).  Here a head is
+// VLY_DECODE_SPLITS workgroups of 256 threads, each over a 64-aligned quarter of the keys; every workgroup rotates q itself,
+// the one whose range holds the new position also rotates / appends k and v.  It leaves (m, l, o[128]) — running max, sum of
+// exponentials, unnormalised P·V, all fp32 — in `partials` [B][heads][SPLITS][132]; vly_gemv_attnmerge_bf16 (the o projection)
+// merges them in its prologue, in split order.  Deterministic; differs from decode_fused_kernel in summation order only.
+__global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ kc,
+                                                           uint16_t* __restrict__ vc, const float* __restrict__ cos_t,
+                                                           const float* __restrict__ sin_t, const uint8_t* __restrict__ key_valid,
+                                                           float* __restrict__ partials, int heads, int past,
+                                                           const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max,
+                                                           int past_row_stride) {
+    __shared__ float sc[256];
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ __attribute__((aligned(16))) float knew[128];
+    __shared__ __attribute__((aligned(16))) float vnew[128];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float acc_s[16][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int Hq = heads * 128;
+    if (past_dev) past = min(past_dev[(size_t)b * past_row_stride], ctx_max - 1);
+    const int pos = past, kv_len = past + 1;
+    const int chunk = (((kv_len + VLY_DECODE_SPLITS - 1) / VLY_DECODE_SPLITS) + 63) & ~63;
+    const int lo = sp * chunk, hi = min(lo + chunk, kv_len);
+    const bool owner = pos >= lo && pos < hi;                 // (exactly one split: pos = kv_len - 1)
+    const uint16_t* qp = qkv + (size_t)b * 3 * Hq + h * 128;
+    uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
+    uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
+    float* part = partials + (((size_t)b * heads + h) * VLY_DECODE_SPLITS + sp) * 132;
+    if (lo >= hi) {                                           // an empty range (short contexts): the neutral element of the merge
+        if (tid < 132) part[tid] = tid == 0 ? NEG_BIG : 0.f;
+        return;
+    }
+    // ---- RoPE on q (every split), on k + append, v append (the owner): decode_fused_kernel's arithmetic
+    if (tid < 64) {
+        const float cs = cos_t[(size_t)pos * 64 + tid], sn = sin_t[(size_t)pos * 64 + tid];
+        const float q0 = h2f(qp[tid]), q1 = h2f(qp[tid + 64]);
+        const float scale = 0.08838834764831845f * LOG2E;
+        qs[tid] = h2f(f2h(rope_rot(q0, q1, cs, sn, -1.f))) * scale;
+        qs[tid + 64] = h2f(f2h(rope_rot(q1, q0, cs, sn, 1.f))) * scale;
+        if (owner) {
+            const float k0 = h2f(qp[Hq + tid]), k1 = h2f(qp[Hq + tid + 64]);
+            const uint16_t r0 = f2h(rope_rot(k0, k1, cs, sn, -1.f)), r1 = f2h(rope_rot(k1, k0, cs, sn, 1.f));
+            knew[tid] = h2f(r0);
+            knew[tid + 64] = h2f(r1);
+            kbase[(size_t)pos * 128 + tid] = r0;
+            kbase[(size_t)pos * 128 + tid + 64] = r1;
+        }
+    } else if (tid < 192 && owner) {
+        const int d = tid - 64;
+        const uint16_t v = qp[2 * Hq + d];
+        vnew[d] = h2f(v);
+        vbase[(size_t)pos * 128 + d] = v;
+    }
+    __syncthreads();
+
+    const int kg = tid >> 4, dc = tid & 15;                      // V role: key group (16), d chunk (8 dims)
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+#pragma unroll 1
+    for (int c0 = lo; c0 < hi; c0 += 256) {
+        u32x4 vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = c0 + kg + 16 * u;
+            vv[u] = (j < hi && j < pos) ? *(const u32x4*)(vbase + (size_t)j * 128 + 8 * dc) : u32x4{0u, 0u, 0u, 0u};
+        }
+        const int jk = c0 + tid;
+        float s = NEG_BIG;
+        if (jk < hi && (!kvld || kvld[jk])) {
+            float a = 0.f;
+            if (jk < pos) {
+                const u32x4* kr = (const u32x4*)(kbase + (size_t)jk * 128);
+                u32x4 kk[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) kk[c] = kr[c];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const f32x4 q0 = *(const f32x4*)(qs + 8 * c), q1 = *(const f32x4*)(qs + 8 * c + 4);
+                    a = fmaf(h_lo(kk[c][0]), q0[0], a); a = fmaf(h_hi(kk[c][0]), q0[1], a);
+                    a = fmaf(h_lo(kk[c][1]), q0[2], a); a = fmaf(h_hi(kk[c][1]), q0[3], a);
+                    a = fmaf(h_lo(kk[c][2]), q1[0], a); a = fmaf(h_hi(kk[c][2]), q1[1], a);
+                    a = fmaf(h_lo(kk[c][3]), q1[2], a); a = fmaf(h_hi(kk[c][3]), q1[3], a);
+                }
+            } else {                                             // the new token's key: still in LDS
+#pragma unroll 8
+                for (int d = 0; d < 128; ++d) a = fmaf(knew[d], qs[d], a);
+            }
+            s = a;
+        }
+        float mc = wave_max(s);
+        if (lane == 0) red[wave] = mc;
+        __syncthreads();
+        mc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float m_new = fmaxf(m_run, mc);
+        const float alpha = sm_exp2(m_run - m_new);
+        const float p = s > 0.5f * NEG_BIG ? sm_exp2(s - m_new) : 0.f;   // masked keys never count, even in an all-masked chunk
+        sc[tid] = p;
+        float lc = wave_sum(p);
+        if (lane == 0) red[4 + wave] = lc;
+        __syncthreads();
+        lc = red[4] + red[5] + red[6] + red[7];
+        l_run = l_run * alpha + lc;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int jl = kg + 16 * u;
+            const float pj = sc[jl];
+            if (c0 + jl == pos) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(pj, vnew[8 * dc + i], o[i]);
+            } else {
+                o[0] = fmaf(pj, h_lo(vv[u][0]), o[0]); o[1] = fmaf(pj, h_hi(vv[u][0]), o[1]);
+                o[2] = fmaf(pj, h_lo(vv[u][1]), o[2]); o[3] = fmaf(pj, h_hi(vv[u][1]), o[3]);
+                o[4] = fmaf(pj, h_lo(vv[u][2]), o[4]); o[5] = fmaf(pj, h_hi(vv[u][2]), o[5]);
+                o[6] = fmaf(pj, h_lo(vv[u][3]), o[6]); o[7] = fmaf(pj, h_hi(vv[u][3]), o[7]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc_s[kg][8 * dc + i] = o[i];
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += acc_s[k2][tid];
+        part[4 + tid] = t;
+    } else if (tid < 132) {
+        part[tid - 128] = tid == 128 ? m_run : tid == 129 ? l_run : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
@@ -1732,4 +1872,24 @@ extern "C" int vly_decode_attention_rows(const void* qkv, void* kcache, void* vc
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, (uint16_t*)out, heads, 0,
                        past_len_rows, key_valid_stride, ctx_max, 1);
     return vly_check_launch("vly_decode_attention_rows");
+}
+
+extern "C" int vly_decode_attention_split(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
+                                          const uint8_t* key_valid, int key_valid_stride, float* partials, int B, int heads,
+                                          int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
+                                          void* stream) {
+    if (B <= 0 || heads <= 0 || past_len < 0 || past_len + 1 > ctx_max || B > 65535 || heads > 65535 || ((uintptr_t)qkv & 15) ||
+        ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) || !partials || ((uintptr_t)partials & 15) || !cos_table || !sin_table ||
+        past_len_dev_stride < 0 || past_len_dev_stride > 1 || (past_len_dev_stride == 1 && !past_len_dev)) {
+        vly_set_error("vly_decode_attention_split: bad args B=%d heads=%d past=%d ctx_max=%d", B, heads, past_len, ctx_max);
+        return -22;
+    }
+    if (key_valid && key_valid_stride < (past_len_dev ? ctx_max : past_len + 1)) {
+        vly_set_error("vly_decode_attention_split: key_valid_stride %d too short", key_valid_stride);
+        return -22;
+    }
+    hipLaunchKernelGGL(decode_split_kernel, dim3(heads, B, VLY_DECODE_SPLITS), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, partials, heads, past_len, past_len_dev,
+                       key_valid_stride, ctx_max, past_len_dev_stride);
+    return vly_check_launch("vly_decode_attention_split");
 }

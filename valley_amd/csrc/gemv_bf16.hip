@@ -137,7 +137,9 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
     bool four = false;
     if (split && MR <= 2 && N >= 8) {
         const int cus = cu_count();
-        four = pin ? pin == 4 : balance((N + 3) / 4, cus * 5) > balance((N + 1) / 2, cus * 8) + 0.02f;
+        // (measured, profiles/r03/r03_gemv_rows_per_wg.jsonl: 5120 x 13824 25.3 -> 23.9 us; 5120 x 5120 10.8 -> 10.9: short rows
+        // gain nothing, so K >= 8192 as well)
+        four = pin ? pin == 4 : K >= 8192 && balance((N + 3) / 4, cus * 5) > balance((N + 1) / 2, cus * 8) + 0.02f;
     }
     dim3 grid(split ? (four ? (N + 3) / 4 : (N + 1) / 2) : (N + 7) / 8), block(256);
 #define VLY_GEMV(E, O)                                                                                            \
@@ -182,7 +184,7 @@ struct PairRegs {
     u32x4 x0[CH], x1[CH];
 };
 
-template <int MR, int EPI, int OUT, int CH>
+template <int MR, int EPI, int OUT, int CH, int PRO>
 __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict__ H, const float* __restrict__ gamma, float eps,
                                                          const uint16_t* __restrict__ W, const float* __restrict__ bias,
                                                          const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K,
@@ -271,7 +273,52 @@ __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict
     };
     PairRegs<CH> pa, pb;
     const int first = ((int)blockIdx.x * 4 + grp) * 2, stride = gridDim.x * 4 * 2;
-    if (grp == 0) {
+    if constexpr (PRO == 1) {
+        // x = the merge of vly_decode_attention_split's partials (H = partials, ldh = heads): all 1024 threads, one or two
+        // 4-wide units each — unit u is dims 4 (u & 31) .. + 3 of head u >> 5 — loads first, then the weights
+        const int heads = ldh, gt = threadIdx.x;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const float* pb_ = H + (size_t)min(m, M - 1) * heads * (VLY_DECODE_SPLITS * 132);
+            float ms[2][VLY_DECODE_SPLITS], ls[2][VLY_DECODE_SPLITS];
+            float4 os[2][VLY_DECODE_SPLITS];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int u = min(gt + 1024 * i, nvec - 1);
+                const float* hb = pb_ + (size_t)(u >> 5) * (VLY_DECODE_SPLITS * 132);
+#pragma unroll
+                for (int sp = 0; sp < VLY_DECODE_SPLITS; ++sp) {
+                    ms[i][sp] = hb[sp * 132];
+                    ls[i][sp] = hb[sp * 132 + 1];
+                    os[i][sp] = *(const float4*)(hb + sp * 132 + 4 + 4 * (u & 31));
+                }
+            }
+            if (m == 0) load_pair(pa, first);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int u = gt + 1024 * i;
+                float mx = ms[i][0];
+#pragma unroll
+                for (int sp = 1; sp < VLY_DECODE_SPLITS; ++sp) mx = fmaxf(mx, ms[i][sp]);
+                float L = 0.f;
+                float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sp = 0; sp < VLY_DECODE_SPLITS; ++sp) {            // split order: deterministic
+                    const float w = exp2f(ms[i][sp] - mx);
+                    L = fmaf(ls[i][sp], w, L);
+                    O.x = fmaf(os[i][sp].x, w, O.x); O.y = fmaf(os[i][sp].y, w, O.y);
+                    O.z = fmaf(os[i][sp].z, w, O.z); O.w = fmaf(os[i][sp].w, w, O.w);
+                }
+                if (u < nvec) {
+                    u32x2 pk;
+                    pk[0] = pack_h2(O.x / L, O.y / L);
+                    pk[1] = pack_h2(O.z / L, O.w / L);
+                    *(u32x2*)(xs + (size_t)m * K + 4 * u) = pk;
+                }
+            }
+        }
+        __syncthreads();
+    } else if (grp == 0) {
         // issue order: row 0 of H and gamma FIRST, then the weights — vmcnt retires in order, so the norm below waits for its
         // own operands only and runs under the weights' HBM latency
         float4 v[2 * CH], gm[2 * CH];                                    // K <= 2048 CH: 2 CH float4 per thread cover a row
@@ -334,15 +381,15 @@ __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict
     }
 }
 
-template <int MR>
+template <int MR, int PRO>
 int launch_norm_mr(const float* H, const float* gamma, float eps, const void* W, const float* bias, const float* R, void* C, int M,
-                   int N, int K, int ldh, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st) {
+                   int N, int K, int ldh, int ldw, int ldc, int ldr, int epi, int out, hipStream_t st, const char* name) {
     const size_t lds = (size_t)MR * K * 2;
     const int pairs = (N + 1) / 2, groups = (pairs + 3) / 4;
     dim3 grid(groups < cu_count() ? groups : cu_count()), block(1024);       // one 16-wave workgroup per CU
 #define VLY_GEMVN_CH(E, O, CH)                                                                                     \
-    hipLaunchKernelGGL((gemv_norm_kernel<MR, E, O, CH>), grid, block, lds, st, H, gamma, eps, (const uint16_t*)W, bias, R, C, M, \
-                       N, K, ldh, ldw, ldc, ldr)
+    hipLaunchKernelGGL((gemv_norm_kernel<MR, E, O, CH, PRO>), grid, block, lds, st, H, gamma, eps, (const uint16_t*)W, bias, R, C, \
+                       M, N, K, ldh, ldw, ldc, ldr)
 #define VLY_GEMVN(E, O)                                                                                           \
     do {                                                                                                          \
         if (K <= 4096) VLY_GEMVN_CH(E, O, 2);                                                                     \
@@ -350,14 +397,15 @@ int launch_norm_mr(const float* H, const float* gamma, float eps, const void* W,
     } while (0)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMVN(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMVN(VLY_EPI_NONE, VLY_OUT_F32);
-    else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMVN(VLY_EPI_SWIGLU, VLY_OUT_BF16);
-    else {
-        vly_set_error("vly_gemv_rmsnorm_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
+    else if (PRO == 0 && epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) {
+        if constexpr (PRO == 0) VLY_GEMVN(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    } else {
+        vly_set_error("%s: unsupported epilogue/out_dtype combination (%d,%d)", name, epi, out);
         return -22;
     }
 #undef VLY_GEMVN_CH
 #undef VLY_GEMVN
-    return vly_check_launch("vly_gemv_rmsnorm_bf16");
+    return vly_check_launch(name);
 }
 
 }  // namespace
@@ -386,6 +434,20 @@ extern "C" int vly_gemv_rmsnorm_bf16(const float* H, const float* gamma, float e
         return -22;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (M == 1) return launch_norm_mr<1>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st);
-    return launch_norm_mr<2>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st);
+    if (M == 1) return launch_norm_mr<1, 0>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st, "vly_gemv_rmsnorm_bf16");
+    return launch_norm_mr<2, 0>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st, "vly_gemv_rmsnorm_bf16");
+}
+
+extern "C" int vly_gemv_attnmerge_bf16(const float* partials, const void* W, const float* bias, const float* residual, void* C, int M,
+                                       int N, int heads, int ldw, int ldc, int ldr, int out_dtype, void* stream) {
+    const int K = heads * 128;
+    if (M <= 0 || M > 2 || N <= 0 || heads <= 0 || K < 2048 || K > 6144 || ldw % 8 || ldw < K || ((uintptr_t)partials & 15) ||
+        ((uintptr_t)W & 15)) {
+        vly_set_error("vly_gemv_attnmerge_bf16: unsupported shape/alignment M=%d N=%d heads=%d ldw=%d (M <= 2, 2048 <= heads*128 <= 6144)", M,
+                      N, heads, ldw);
+        return -22;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 1) return launch_norm_mr<1, 1>(partials, nullptr, 0.f, W, bias, residual, C, M, N, K, heads, ldw, ldc, ldr, VLY_EPI_NONE, out_dtype, st, "vly_gemv_attnmerge_bf16");
+    return launch_norm_mr<2, 1>(partials, nullptr, 0.f, W, bias, residual, C, M, N, K, heads, ldw, ldc, ldr, VLY_EPI_NONE, out_dtype, st, "vly_gemv_attnmerge_bf16");
 }

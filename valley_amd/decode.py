@@ -2,7 +2,7 @@
 valley/serve/model_worker.py:380-394 and of HF ``generate`` behind valley_model.py:432).
 
 One decode step = embedding gather of the current token -> L x [RMSNorm + q|k|v GEMV, RoPE + KV append +
-decode attention, o GEMV(+res), RMSNorm + gate/up GEMV with SwiGLU, down GEMV(+res)] -> RMSNorm +
+decode attention (every head split over four workgroups at batch <= 2), (merge +) o GEMV(+res), RMSNorm + gate/up GEMV with SwiGLU, down GEMV(+res)] -> RMSNorm +
 lm_head GEMV -> argmax -> position += 1.  Every kernel is HBM-bound weight/KV streaming, 5 launches
 per layer (the norms ride inside the GEMV that consumes them at batch <= 2; 7 otherwise): launched eagerly from Python the step would be host-bound (>300 launches x ~15 us), so the
 step is captured ONCE into a hipGraph and replayed.  Static shapes are what capture needs: the KV
@@ -22,6 +22,7 @@ from .llama import HipKVCache, HipLlama
 
 
 FUSE_NORM = os.environ.get("VALLEY_DECODE_FUSE_NORM", "1") != "0"
+SPLIT_ATTN = os.environ.get("VALLEY_DECODE_SPLIT_ATTN", "1") != "0"       # flash-decoding split + merge inside the o GEMV (B <= 2)
 
 
 class DecodeSession:
@@ -41,6 +42,7 @@ class DecodeSession:
         self.x = torch.empty((B, llama.H), dtype=bf, device=d)
         self.qkv = torch.empty((B, 3 * llama.H), dtype=bf, device=d)
         self.att = torch.empty((B, llama.H), dtype=bf, device=d)
+        self.partials = ops.decode_partials(B, llama.heads, d)
         self.mlp = torch.empty((B, llama.I), dtype=bf, device=d)
         self.logits = torch.empty((B, llama.Vpad), dtype=torch.float32, device=d)
         self.use_graph = use_graph
@@ -53,6 +55,7 @@ class DecodeSession:
         # the three norm -> projection seams as one launch each where the fused kernel takes the shape (bit-identical either way;
         # VALLEY_DECODE_FUSE_NORM=0 keeps the pairs, for A/B runs)
         fused = FUSE_NORM and ops.gemv_rmsnorm_ok(B, ll.H)
+        split = SPLIT_ATTN and ops.gemv_rmsnorm_ok(B, ll.H) and ll.heads * 128 == ll.H
         ops.embed_splice(self.tok, ll.embed, None, out=self.h)
         for li in range(ll.L):
             L = ll.layers[li]
@@ -61,12 +64,17 @@ class DecodeSession:
             else:
                 ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
                 ops.gemv(self.x, L["w_qkv"], out=self.qkv)
-            if self.per_row:
+            if split:                                            # every head over four workgroups; the o GEMV merges
+                ops.decode_attention_split(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, self.partials,
+                                           past_dev=self.pos, per_row=self.per_row)
+                ops.gemv_attnmerge(self.partials, L["w_o"], residual=self.h, out=self.h)
+            elif self.per_row:
                 ops.decode_attention_rows(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, self.pos, out=self.att)
             else:
                 ops.decode_attention(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, out=self.att,
                                      past_dev=self.pos)          # RoPE + KV append + attention in one launch
-            ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
+            if not split:
+                ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
             if fused:
                 ops.gemv_rmsnorm(self.h, L["ln2"], ll.eps, L["w_gu"], epilogue=ops.EPI_SWIGLU, out=self.mlp)
             else:

@@ -904,6 +904,67 @@ def decode_attention_rows(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch
     return out
 
 
+DECODE_SPLITS = 4          # VLY_DECODE_SPLITS
+
+
+def decode_partials(B: int, heads: int, device) -> torch.Tensor:
+    """Workspace of decode_attention_split / gemv_attnmerge: fp32 [B, heads, DECODE_SPLITS, 132]."""
+    return torch.empty((B, heads, DECODE_SPLITS, 132), dtype=torch.float32, device=device)
+
+
+def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                           key_valid: Optional[torch.Tensor], B: int, heads: int, past_len: int, partials: torch.Tensor,
+                           past_dev: Optional[torch.Tensor] = None, per_row: bool = False) -> torch.Tensor:
+    """vly_decode_attention_split: decode_attention (or decode_attention_rows with ``per_row``) with every head split over
+    DECODE_SPLITS workgroups; leaves the per-split (max, sum, P·V) in ``partials`` for gemv_attnmerge."""
+    _chk(qkv, HALF, "qkv")
+    _chk(cos, torch.float32, "cos")
+    _chk(sin, torch.float32, "sin")
+    _chk(partials, torch.float32, "partials")
+    assert tuple(partials.shape) == (B, heads, DECODE_SPLITS, 132)
+    ctx_max = kcache.shape[2]
+    if per_row or past_dev is not None:
+        if cos.shape[0] < ctx_max or sin.shape[0] < ctx_max or cos.shape[-1] != 64 or sin.shape[-1] != 64:
+            raise ValueError(f"RoPE tables {tuple(cos.shape)} / {tuple(sin.shape)} do not cover ctx_max = {ctx_max} positions x 64")
+    if per_row:
+        _chk(past_dev, torch.int32, "past_dev")
+        assert past_dev.numel() == B
+    kv_stride = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        assert key_valid.shape[0] == B and key_valid.shape[1] >= (ctx_max if past_dev is not None else past_len + 1)
+        kv_stride = key_valid.stride(0)
+    rc = _lib.load().vly_decode_attention_split(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                _ptr(key_valid), kv_stride, partials.data_ptr(), B, heads, past_len, _ptr(past_dev),
+                                                1 if per_row else 0, ctx_max, _stream())
+    _lib.check(rc, "vly_decode_attention_split")
+    return partials
+
+
+def gemv_attnmerge(partials: torch.Tensor, w, bias=None, residual=None, out_dtype=HALF, out=None):
+    """vly_gemv_attnmerge_bf16: the o projection over the merge of decode_attention_split's partials (M = B <= 2 rows)."""
+    _chk(partials, torch.float32, "partials")
+    B, heads = partials.shape[0], partials.shape[1]
+    assert tuple(partials.shape) == (B, heads, DECODE_SPLITS, 132)
+    wt, ldw = _w_args(w, False)
+    N, K = w.shape
+    assert K == heads * 128, (w.shape, heads)
+    if out is None:
+        out = torch.empty((B, N), dtype=out_dtype, device=partials.device)
+    else:
+        assert tuple(out.shape) == (B, N) and out.stride(1) == 1
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    if residual is not None:
+        _chk(residual, torch.float32, "residual", contiguous=False)
+        assert tuple(residual.shape) == (B, N) and residual.stride(1) == 1
+    od = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    rc = _lib.load().vly_gemv_attnmerge_bf16(partials.data_ptr(), wt.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), B, N, heads,
+                                             ldw, out.stride(0), residual.stride(0) if residual is not None else 0, od, _stream())
+    _lib.check(rc, "vly_gemv_attnmerge_bf16")
+    return out
+
+
 def argmax(x: torch.Tensor, out=None) -> torch.Tensor:
     """x fp32 [M,N] (row stride may exceed N) -> int32 [M]."""
     _chk(x, torch.float32, "x", contiguous=False)
