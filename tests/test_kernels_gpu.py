@@ -218,6 +218,23 @@ def test_vit_attention():
     assert relerr(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("F", [3, 40])
+def test_vit_attention_persistent_variant(F):
+    """VLY_VIT_ATTN=4 (vit_attn4_kernel: one 16-wave workgroup per CU, K / V by LDS-DMA, V through ds_read_b64_tr_b16) against
+    the fp32 formula — the switch is read once per process, so the variant runs in a child (tools/vit_attn_time.py).  40 frames =
+    640 heads on 256 CUs: every workgroup walks 2-3 heads through both LDS buffers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VLY_VIT_ATTN="4")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "vit_attn_time.py"), str(F)], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-500:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["kernel"] == "4" and line["rel_l2_vs_fp32"] < 4e-3 and line["max_abs"] < 4e-2, line
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_pool_tokens(mode):
     from valley_amd import ops

@@ -310,516 +310,29 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     }
 }
 
-// ---- round 3: the 257th query --------------------------------------------------------------------------------------
-// 257 tokens are 16 query tiles + ONE row.  vit_attn_kernel gives that row a whole 16-row tile: 17 tiles on 8 waves = 3 for
-// wave 0 and 2 for the others, so a workgroup lives three tile-times while seven of its eight waves work two (PMC, round 3:
-// mean wave lifetime 15.9 us x 4 rounds of workgroups = 64 of the kernel's 92 us).  Here every wave computes two full query
-// tiles, and the last query is split over the KEYS instead: wave w takes key tiles w and w + 8 (wave 0 also the 17th, which
-// holds key 256 alone) as one 32-key chunk of the second product, keeps a partial (max, sum, 64 outputs) of the online
-// softmax for that query, and wave 0 merges the eight partials through 2 KB of LDS.  The query's 16-row MFMA tile still
-// exists (its other 15 columns repeat token 256 and are discarded) but each wave runs 4-6 + 4-8 MFMAs of it instead of
-// one wave running 70.
-constexpr int VMERGE_F = 68;                     // floats per wave in the merge area: m, l, 2 pad, 64 outputs
-
-__global__ void __launch_bounds__(VNW * 64, 2) vit_attn3_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2 + VNW * VMERGE_F * 4];
-    char* sK = smem;
-    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
-    float* sMg = (float*)(smem + VK_BYTES + 64 * VT_STRIDE * 2);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int hi16 = opaque_i32(16);                                   // see opaque_i32
-    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
-    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
-
-    // ---- staging: as vit_attn_kernel
-    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
-        const int row = s >> 3, c = s & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
-        *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = v;
-    }
-    const int dq = wave & 3;
-    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
-        const int p = pg * 64 + lane;
-        if (p < VNC * 16) {
-            const int kv0 = 2 * p, kv1 = kv0 + 1;
-            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
-            if (kv0 < VN) {
-                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + dq * 16;
-                a0 = *(const u32x4*)r0;
-                a1 = *(const u32x4*)(r0 + 8);
-            }
-            if (kv1 < VN) {
-                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + dq * 16;
-                b0 = *(const u32x4*)r1;
-                b1 = *(const u32x4*)(r1 + 8);
-            }
-#pragma unroll
-            for (int dd = 0; dd < 16; ++dd) {
-                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
-                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + kv0) = w;
-            }
-        }
-    }
-    __syncthreads();
-
-    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
-    bf16x8 qn[2];
-    {
-        const int qc0 = wave * 16 + l15;
-        qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
-        qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
-    }
-    // ---- two full query tiles per wave: qt = wave, wave + 8
-    for (int qt = wave; qt < 2 * VNW; qt += VNW) {
-        const int q = qt * 16 + l15;
-        bf16x8 qf[2] = {qn[0], qn[1]};
-        if (qt + VNW < 2 * VNW) {                              // the next tile's Q fragments
-            const int qc1 = (qt + VNW) * 16 + l15;
-            qn[0] = *(const bf16x8*)(base + (size_t)qc1 * VLD + g * 8);
-            qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
-        }
-        f32x4 s[VNT];
-#pragma unroll
-        for (int t = 0; t < VNT; ++t) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                acc = mfma16(kf, qf[kk], acc);
-            }
-            s[t] = acc * sc;
-            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;       // keys 257..271 are padding
-        float m = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = sm_exp2(s[t][r] - m);
-                s[t][r] = p;
-                l += p;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < VNC; ++c) {
-            u32x4 pk;
-            pk[0] = pack_h2(s[2 * c][0], s[2 * c][1]);
-            pk[1] = pack_h2(s[2 * c][2], s[2 * c][3]);
-            if (2 * c + 1 < VNT) {
-                pk[2] = pack_h2(s[2 * c + 1][0], s[2 * c + 1][1]);
-                pk[3] = pack_h2(s[2 * c + 1][2], s[2 * c + 1][3]);
-            } else {
-                pk[2] = 0u;
-                pk[3] = 0u;
-            }
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 32 * c + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + hi16);
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
-            }
-            asm volatile("" ::: "memory");
-        }
-        store_tile_rows(out + ((size_t)f * VN + q) * 1024 + h * 64, o, 1.f / l, g);
-    }
-    // ---- the last query (token 256), split over the keys: this wave's key tiles are wave and wave + 8 (+ 16 for wave 0)
-    {
-        // (lane coordinates re-derived behind an opaque copy: otherwise hipcc hoists this section's address arithmetic above
-        // the query-tile loop and the kernel no longer fits the 128 registers that let two workgroups share a CU)
-        const int l15 = opaque_i32(lane) & 15, g = opaque_i32(lane) >> 4;
-        // the last query, replicated over the tile's 16 columns (only column 0 is kept)
-        const bf16x8 qf[2] = {*(const bf16x8*)(base + (size_t)(VN - 1) * VLD + g * 8), *(const bf16x8*)(base + (size_t)(VN - 1) * VLD + 32 + g * 8)};
-        const int nt = wave == 0 ? 3 : 2;                      // wave-uniform
-        f32x4 s[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int t = wave + VNW * j;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (j < nt) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                    acc = mfma16(kf, qf[kk], acc);
-                }
-            }
-            s[j] = acc * sc;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (nt < 3 || g != 0 || r != 0) s[2][r] = NEG_BIG;   // the third tile is keys 256..271: only key 256 (g = 0, r = 0) exists
-        }
-        float m = NEG_BIG;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[j][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = sm_exp2(s[j][r] - m);
-                s[j][r] = p;
-                l += p;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // chunk 0: k slots 0..3 of a lane group <-> keys of tile `wave`, 4..7 <-> keys of tile `wave + 8`
-        {
-            u32x4 pk;
-            pk[0] = pack_h2(s[0][0], s[0][1]);
-            pk[1] = pack_h2(s[0][2], s[0][3]);
-            pk[2] = pack_h2(s[1][0], s[1][1]);
-            pk[3] = pack_h2(s[1][2], s[1][3]);
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 16 * wave + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + 8 * hi16);            // + 128 keys: tile wave + 8
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
-            }
-        }
-        if (nt == 3) {                                            // wave 0: key tile 16 (key 256; V^T columns 257..287 are zeros)
-            u32x4 pk;
-            pk[0] = pack_h2(s[2][0], s[2][1]);
-            pk[1] = pack_h2(s[2][2], s[2][3]);
-            pk[2] = 0u;
-            pk[3] = 0u;
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 256 + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + hi16);
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
-            }
-        }
-        // the query is column 0 (l15 == 0) of the tile: its partial (m, l, O[d = dt*16 + 4g + r]) goes to the merge area
-        if (l15 == 0) {
-            float* mg = sMg + wave * VMERGE_F;
-            if (g == 0) { mg[0] = m; mg[1] = l; }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(mg + 4 + dt * 16 + 4 * g) = o[dt];
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {                                              // merge: lane d owns output d of the query
-        float M = NEG_BIG;
-#pragma unroll
-        for (int w = 0; w < VNW; ++w) M = fmaxf(M, sMg[w * VMERGE_F]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int w = 0; w < VNW; ++w) {
-            const float a = sm_exp2(sMg[w * VMERGE_F] - M);
-            L = fmaf(sMg[w * VMERGE_F + 1], a, L);
-            O = fmaf(sMg[w * VMERGE_F + 4 + lane], a, O);
-        }
-        out[((size_t)f * VN + (VN - 1)) * 1024 + h * 64 + lane] = f2h(O / L);
-    }
-}
-
-// ---- round 3: two query tiles per wave -----------------------------------------------------------------------------------
-// What the four kernels above have in common — and what bounds all of them at ~90 us per layer whatever their staging looks
-// like — is the LDS READ traffic of the two products: every 16-query tile re-reads the head's whole K (34 x 1 KB fragments)
-// and V^T (72 x 512 B) from LDS, 1.2 MB per head, 9.6 MB per CU and launch (the "compute only" timing variant that runs 47 us
-// is really "no LDS reads": hipcc folds loads of a never-written LDS array).  Here a wave owns TWO query tiles (w and w + 8)
-// and walks the keys in blocks of 64 with an online softmax, so every K and V^T fragment it reads feeds two MFMAs: half the
-// LDS reads per flop, at the price of the rescaling arithmetic (one exp2 and 16 multiplies per tile and block).  Staging and
-// layout as vit_attn_kernel (two 8-wave workgroups per CU); the 257th query is split over the keys as in vit_attn3_kernel.
-__global__ void __launch_bounds__(VNW * 64, 4) vit_attn5_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2 + VNW * VMERGE_F * 4];
-    char* sK = smem;
-    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
-    float* sMg = (float*)(smem + VK_BYTES + 64 * VT_STRIDE * 2);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int hi16 = opaque_i32(16);                                   // see opaque_i32
-    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
-    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
-
-    // ---- staging: as vit_attn_kernel
-    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
-        const int row = s >> 3, c = s & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
-        *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = v;
-    }
-    const int dq = wave & 3;
-    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
-        const int p = pg * 64 + lane;
-        if (p < VNC * 16) {
-            const int kv0 = 2 * p, kv1 = kv0 + 1;
-            u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0;
-            if (kv0 < VN) {
-                const uint16_t* r0 = base + (size_t)kv0 * VLD + 2048 + dq * 16;
-                a0 = *(const u32x4*)r0;
-                a1 = *(const u32x4*)(r0 + 8);
-            }
-            if (kv1 < VN) {
-                const uint16_t* r1 = base + (size_t)kv1 * VLD + 2048 + dq * 16;
-                b0 = *(const u32x4*)r1;
-                b1 = *(const u32x4*)(r1 + 8);
-            }
-#pragma unroll
-            for (int dd = 0; dd < 16; ++dd) {
-                const uint32_t w = sel16(a0, a1, dd) | (sel16(b0, b1, dd) << 16);
-                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + kv0) = w;
-            }
-        }
-    }
-    // the Q fragments of both tiles (rows wave*16 + l15 and (wave + 8)*16 + l15: all below 256)
-    bf16x8 qf[2][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const uint16_t* qp = base + (size_t)((wave + VNW * u) * 16 + l15) * VLD + g * 8;
-        qf[u][0] = *(const bf16x8*)qp;
-        qf[u][1] = *(const bf16x8*)(qp + 32);
-    }
-    __syncthreads();
-
-    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
-    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
-    f32x4 o[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- key blocks of 64 (blocks 0..3: keys 0..255; block 4: key tile 16 = key 256 and padding)
-#pragma unroll 1
-    for (int kb = 0; kb < 5; ++kb) {
-        const int nt = kb < 4 ? 4 : 1;                      // key tiles in this block (uniform)
-        f32x4 s[2][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-            if (t < nt) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + ((kb * 4 + t) * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                    a0 = mfma16(kf, qf[0][kk], a0);
-                    a1 = mfma16(kf, qf[1][kk], a1);
-                }
-            }
-            s[0][t] = a0 * sc;
-            s[1][t] = a1 * sc;
-            if (t & 1) asm volatile("" ::: "memory");       // cap the K fragments in flight (register budget)
-        }
-        if (kb == 4) {                                      // only (tile 16, g == 0, r == 0) is a real key
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t > 0 || g != 0 || r != 0) s[u][t][r] = NEG_BIG;
-        }
-        u32x4 pk[2][2];                                     // [tile][chunk]: the probabilities in the second product's k-slot order
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float rm = NEG_BIG;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rm = fmaxf(rm, s[u][t][r]);
-            rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
-            rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
-            const float mn = fmaxf(m[u], rm);
-            const float alpha = sm_exp2(m[u] - mn);
-            m[u] = mn;
-            float ps = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = sm_exp2(s[u][t][r] - mn);
-                    s[u][t][r] = p;
-                    ps += p;
-                }
-            l[u] = l[u] * alpha + ps;                       // per-lane partial; the four g-lanes of a query share alpha
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                pk[u][c][0] = pack_h2(s[u][2 * c][0], s[u][2 * c][1]);
-                pk[u][c][1] = pack_h2(s[u][2 * c][2], s[u][2 * c][3]);
-                pk[u][c][2] = pack_h2(s[u][2 * c + 1][0], s[u][2 * c + 1][1]);
-                pk[u][c][3] = pack_h2(s[u][2 * c + 1][2], s[u][2 * c + 1][3]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (c == 1 && kb == 4) break;                   // the last block has one 32-key chunk (V^T columns 256..287)
-            const bf16x8 pf0 = __builtin_bit_cast(bf16x8, pk[0][c]), pf1 = __builtin_bit_cast(bf16x8, pk[1][c]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 64 * kb + 32 * c + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + hi16);
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-                o[0][dt] = mfma16(vf, pf0, o[0][dt]);
-                o[1][dt] = mfma16(vf, pf1, o[1][dt]);
-            }
-            asm volatile("" ::: "memory");
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        float lt = l[u];
-        lt += __shfl_xor(lt, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
-        store_tile_rows(out + ((size_t)f * VN + (wave + VNW * u) * 16 + l15) * 1024 + h * 64, o[u], 1.f / lt, g);
-    }
-    // ---- the last query (token 256), split over the keys: this wave's key tiles are wave and wave + 8 (+ 16 for wave 0)
-    {
-        const int l15 = opaque_i32(lane) & 15, g = opaque_i32(lane) >> 4;
-        const bf16x8 ql[2] = {*(const bf16x8*)(base + (size_t)(VN - 1) * VLD + g * 8), *(const bf16x8*)(base + (size_t)(VN - 1) * VLD + 32 + g * 8)};
-        const int nt = wave == 0 ? 3 : 2;                      // wave-uniform
-        f32x4 s[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int t = wave + VNW * j;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (j < nt) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                    acc = mfma16(kf, ql[kk], acc);
-                }
-            }
-            s[j] = acc * sc;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (nt < 3 || g != 0 || r != 0) s[2][r] = NEG_BIG;
-        float pm = NEG_BIG;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pm = fmaxf(pm, s[j][r]);
-        pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
-        pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-        float pl = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = sm_exp2(s[j][r] - pm);
-                s[j][r] = p;
-                pl += p;
-            }
-        pl += __shfl_xor(pl, 16, 64);
-        pl += __shfl_xor(pl, 32, 64);
-        f32x4 po[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) po[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            u32x4 pk;
-            pk[0] = pack_h2(s[0][0], s[0][1]);
-            pk[1] = pack_h2(s[0][2], s[0][3]);
-            pk[2] = pack_h2(s[1][0], s[1][1]);
-            pk[3] = pack_h2(s[1][2], s[1][3]);
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 16 * wave + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + 8 * hi16);            // + 128 keys: tile wave + 8
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                po[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, po[dt]);
-            }
-        }
-        if (nt == 3) {
-            u32x4 pk;
-            pk[0] = pack_h2(s[2][0], s[2][1]);
-            pk[1] = pack_h2(s[2][2], s[2][3]);
-            pk[2] = 0u;
-            pk[3] = 0u;
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 256 + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + hi16);
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                po[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, po[dt]);
-            }
-        }
-        if (l15 == 0) {
-            float* mg = sMg + wave * VMERGE_F;
-            if (g == 0) { mg[0] = pm; mg[1] = pl; }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(mg + 4 + dt * 16 + 4 * g) = po[dt];
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float M = NEG_BIG;
-#pragma unroll
-        for (int w = 0; w < VNW; ++w) M = fmaxf(M, sMg[w * VMERGE_F]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int w = 0; w < VNW; ++w) {
-            const float a = sm_exp2(sMg[w * VMERGE_F] - M);
-            L = fmaf(sMg[w * VMERGE_F + 1], a, L);
-            O = fmaf(sMg[w * VMERGE_F + 4 + lane], a, O);
-        }
-        out[((size_t)f * VN + (VN - 1)) * 1024 + h * 64 + lane] = f2h(O / L);
-    }
-}
-
-// ---- round 3: persistent, double-buffered, everything staged by LDS-DMA -----------------------------------------------
-// Timing variants of vit_attn_kernel (profiles/r03/r03_vit_attn_timing_variants.jsonl): 90 us per layer at 128 frames, 47 of
-// them compute (QK^T, softmax, PV on data already in LDS) — the other half is a workgroup WAITING for its K / V (135 MB per
-// launch, one dependent round trip after another: 4.25 for K, 2 for V, then a register transpose of V) with one other
-// workgroup per CU to cover for it, because a head's K + V^T fill 71 of the 160 KB.  Here ONE 16-wave workgroup per CU walks
-// its heads (block id + k * grid), and while it computes head i out of LDS buffer i & 1 the K and V of head i + 1 land in
-// the other buffer by LDS-DMA — no registers, no VALU, no barrier of their own:
-//   * K as before ([272][128 B], chunk ^= row & 7 on the SOURCE address), V ROW-major ([288][128 B], chunk ^= row & 6) and
-//     read as the second product's A operand with ds_read_b64_tr_b16 (the hardware 4 x 4 transpose; semantics probed in
-//     profiles/r03/r03_tr_read_probe.txt: lanes 4t .. 4t+3 of a 16-lane block supply row t, lane j receives column j).  The
-//     swizzle keeps the 32 lanes of a half wave on 32 distinct 8-byte slots of a 256-byte bank window;
+// ---- round 3: persistent, double-buffered, everything staged by LDS-DMA (VLY_VIT_ATTN=4; NOT the default) ----------------
+// The design round 2's review asked for.  ONE 16-wave workgroup per CU walks its heads (block id + k * grid), and while it
+// computes head i out of LDS buffer i & 1 the K and V of head i + 1 land in the other buffer by LDS-DMA — no registers, no
+// VALU, no barrier of their own:
+//   * K as in vit_attn_kernel ([272][128 B], chunk ^= row & 7 on the SOURCE address), V ROW-major ([288][128 B], chunk ^=
+//     row & 6) and read as the second product's A operand with ds_read_b64_tr_b16 (the hardware 4 x 4 transpose; semantics
+//     probed in profiles/r03/r03_tr_read_probe.txt: lanes 4t .. 4t+3 of a 16-lane block supply row t, lane j receives column
+//     j).  The swizzle keeps the 32 lanes of a half wave on 32 distinct 8-byte slots of a 256-byte bank window;
 //   * one barrier per head: vmcnt(0) + barrier says both "my pieces of this head landed" and "I am done with the other
-//     buffer"; the next head's pieces are issued right after the QK^T phase (the only consumer of the Q fragments: hipcc
-//     drains the DMA queue at the next use of an ordinary load, so none may be pending then) and fly under softmax + PV;
-//   * 17 query tiles on 16 waves: wave w owns tile w, and the 257th query is split over the keys (vit_attn3_kernel's scheme:
-//     key tile w per wave, wave 0 also the 17th; partials merged by wave 0 through a double-buffered 4 KB area);
+//     buffer"; the next head's pieces are issued right after it (asm buffer_load ... lds: behind the builtin hipcc drains the
+//     DMA queue before every ds_read) and fly under the whole head;
+//   * 17 query tiles on 16 waves: wave w owns tile w, and the 257th query is split over the KEYS (key tile w per wave, wave 0
+//     also the 17th, which holds key 256 alone; partial (max, sum, 64 outputs) per wave, merged by wave 0 through a
+//     double-buffered 4 KB area) instead of costing one wave a whole 16-row tile;
 //   * outputs leave as 32-byte runs per lane (store_tile_rows).
+// Measured (profiles/r03/r03_vit_attn_v4.jsonl, same box, medians): 89.7 vs vit_attn_kernel's 91.4 us at 128 frames, 176.1 vs
+// 179.8 at 256, 26.9 vs 27.0 at 32 — staging that costs nothing buys 2 %.  The timing variants of vit_attn_kernel
+// (r03_vit_attn_timing_variants{,2}.jsonl) say why: 87 us = 52 with no softmax arithmetic at all, 79 without the exp2, 64
+// with every byte served from L2, 76 without the output stores — nothing in this kernel overlaps with anything else well
+// enough for one removed cost to show in full, and none of them is dominant.  Three more structures measured the same or
+// worse and live in the history only (commit daf98f1): LDS-DMA K staging + packed softmax (v2, +-4 %), the split last query
+// alone (v3, 90.2 vs 90.6), two query tiles per wave with an online softmax to halve the LDS reads (v5, 99.9 vs 89.9).
+constexpr int VMERGE_F = 68;                     // floats per wave in the merge area: m, l, 2 pad, 64 outputs
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 constexpr int V4W = 16;
 constexpr int V4_KB = VNT * 16 * 128;              // 34816
@@ -1061,169 +574,6 @@ __global__ void __launch_bounds__(V4W * 64) vit_attn4_kernel(const uint16_t* __r
     }
 }
 
-// ---- round 3: the same kernel with its staging and softmax rebuilt -------------------------------------------------
-// What the round-2 kernel spent its 96 us per layer (F = 128) on, from its ISA (tools/isa_blocks.py): the K staging loop
-// issued ONE global load per iteration and waited for it — 4.25 dependent HBM round trips per workgroup before the first
-// MFMA, the V staging another two —, and a query tile cost 310 VALU + 66 transcendental instructions for its 70 MFMAs
-// (scale, max, subtract, exponential, sum, convert: one instruction per score each).  Here
-//   * K goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, the chunk swizzle on the SOURCE address): 34 pieces of
-//     1 KB, 4-5 per wave, no registers, all in flight at once; padded key rows re-read token 256 (their scores are
-//     overwritten with -1e30, their probabilities are exact zeros);
-//   * all of a lane's V loads (and the first Q fragments) are issued before the first wait;
-//   * the softmax works on register PAIRS: exp2(s * c - m * c) as one v_pk_fma_f32 per two scores (the scale is folded
-//     into the exponent), row sums by v_pk_add_f32, the maximum by v_max3_f32.
-typedef __attribute__((ext_vector_type(2))) float vf2;
-VLY_DEVICE float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // hipcc fuses to v_max3_f32
-
-__global__ void __launch_bounds__(VNW * 64, 2) vit_attn2_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int skew) {
-    __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2];
-    char* sK = smem;
-    uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    [[maybe_unused]] const int hi16 = opaque_i32(16);          // see opaque_i32
-    const int f = blockIdx.x >> 4, h = blockIdx.x & 15;
-    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
-
-    // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7; piece pc = rows 8 pc .. 8 pc + 7
-    for (int pc = wave; pc < VNT * 2; pc += VNW) {
-        const int sl = pc * 64 + lane, row = sl >> 3, cp = sl & 7;
-        glds16(base + (size_t)min(row, VN - 1) * VLD + 1024 + ((cp ^ (row & 7)) << 3), sK + pc * 1024);
-    }
-    // ---- V: every load of this lane first (wave w: d = 16 (w & 3) .. +15; key pairs pg = w >> 2, + 2)
-    const int dq = wave & 3;
-    u32x4 va[2][4];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int pg = (wave >> 2) + 2 * it, p = pg * 64 + lane;
-        if (pg < 3 && p < VNC * 16) {                                   // pg is wave-uniform
-            const uint16_t* r0 = base + (size_t)min(2 * p, VN - 1) * VLD + 2048 + dq * 16;
-            const uint16_t* r1 = base + (size_t)min(2 * p + 1, VN - 1) * VLD + 2048 + dq * 16;
-            va[it][0] = *(const u32x4*)r0;
-            va[it][1] = *(const u32x4*)(r0 + 8);
-            va[it][2] = *(const u32x4*)r1;
-            va[it][3] = *(const u32x4*)(r1 + 8);
-        }
-    }
-    bf16x8 qn[2];
-    {
-        const int qc0 = min(wave * 16 + l15, VN - 1);
-        qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
-        qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
-    }
-    // V^T: [64 d][288 kv]: the lane's two keys side by side in one 32-bit word per d (keys past 256 hold token 256: finite)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int pg = (wave >> 2) + 2 * it, p = pg * 64 + lane;
-        if (pg < 3 && p < VNC * 16) {
-#pragma unroll
-            for (int dd = 0; dd < 16; ++dd) {
-                const uint32_t w = sel16(va[it][0], va[it][1], dd) | (sel16(va[it][2], va[it][3], dd) << 16);
-                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + 2 * p) = w;
-            }
-        }
-    }
-    __syncthreads();                                                     // (carries the vmcnt(0) of the LDS-DMA pieces)
-    // Phase skew: every wave runs QK^T (matrix pipe + LDS) -> softmax (VALU, 60 % of a query tile's cycles) -> PV (matrix
-    // pipe + LDS).  Released together by the barrier, the waves of a SIMD stay in the SAME phase — each phase bound by one
-    // pipe while the others idle (the kernel's time was the SUM of its MFMA, VALU and LDS times).  The second half of the
-    // workgroup (waves 4-7: the SIMD partners of waves 0-3) therefore starts `skew` x 512 cycles late.
-    if (wave >= VNW / 2)
-        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(8);
-
-    const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
-    for (int qt = wave; qt < VNT; qt += VNW) {
-        const int q = qt * 16 + l15;
-        bf16x8 qf[2] = {qn[0], qn[1]};
-        if (qt + VNW < VNT) {
-            const int qc1 = min((qt + VNW) * 16 + l15, VN - 1);
-            qn[0] = *(const bf16x8*)(base + (size_t)qc1 * VLD + g * 8);
-            qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
-        }
-        f32x4 s[VNT];                                       // raw scores K . q (the scale rides in the exponent)
-#pragma unroll
-        for (int t = 0; t < VNT; ++t) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                acc = mfma16(kf, qf[kk], acc);
-            }
-            s[t] = acc;
-            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
-        }
-        // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
-
-        float m = max3f(s[0][0], s[0][1], max3f(s[0][2], s[0][3], NEG_BIG));
-#pragma unroll
-        for (int t = 1; t < VNT; ++t) m = max3f(max3f(m, s[t][0], s[t][1]), s[t][2], s[t][3]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const vf2 sc2 = {sc, sc}, nm2 = {-m * sc, -m * sc};
-        uint32_t pb[VNT][2];                                // the probabilities as bf16 pairs, in the second MFMA's k-slot order
-        vf2 l2 = {0.f, 0.f};
-        // step by step over ALL pairs (a packed op feeding a transcendental, or back, costs a wait state that independent
-        // work fills: pair-at-a-time order had 112 s_nop per query tile)
-        vf2 e[VNT][2];
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) e[t][hh] = __builtin_elementwise_fma(vf2{s[t][2 * hh], s[t][2 * hh + 1]}, sc2, nm2);
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) e[t][hh] = vf2{sm_exp2(e[t][hh][0]), sm_exp2(e[t][hh][1])};
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                l2 += e[t][hh];
-                pb[t][hh] = pack_h2(e[t][hh][0], e[t][hh][1]);
-            }
-        float l = l2[0] + l2[1];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < VNC; ++c) {
-            u32x4 pk;
-            pk[0] = pb[2 * c][0];
-            pk[1] = pb[2 * c][1];
-            pk[2] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][0] : 0u;
-            pk[3] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][1] : 0u;
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * VT_STRIDE + 32 * c + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + hi16);
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
-            }
-            asm volatile("" ::: "memory");
-        }
-        if (q < VN) {
-            const float inv = __builtin_amdgcn_rcpf(l);
-            uint16_t* op = out + ((size_t)f * VN + q) * 1024 + h * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                u32x2 pk;
-                pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
-                pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
-                *(u32x2*)(op + dt * 16) = pk;
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
@@ -1795,11 +1145,9 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
-    // VLY_VIT_ATTN=2 launches vit_attn2_kernel (LDS-DMA staging, packed softmax; measured within 4 % of this one either way:
-    // profiles/r03/r03_vit_attn_v1_v2.jsonl) with VLY_VIT_SKEW x 512 cycles of head start for waves 0-3
+    // VLY_VIT_ATTN=4 launches vit_attn4_kernel (persistent, LDS-DMA staged; measured 2 % faster at >= 128 frames, equal at 32)
     static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 1;
-    if (ver == 5) hipLaunchKernelGGL(vit_attn5_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
-    else if (ver == 4) {
+    if (ver == 4) {
         static const int cus = [] {
             int dev = 0, n = 0;
             (void)hipGetDevice(&dev);
@@ -1809,12 +1157,7 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
         const int nheads = F * 16;
         hipLaunchKernelGGL(vit_attn4_kernel, dim3(nheads < cus ? nheads : cus), dim3(V4W * 64), 0, (hipStream_t)stream,
                            (const uint16_t*)qkv, (uint16_t*)out, nheads);
-    } else if (ver == 3) hipLaunchKernelGGL(vit_attn3_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
-    else if (ver != 2) hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
-    else {
-        static const int skew = getenv("VLY_VIT_SKEW") ? atoi(getenv("VLY_VIT_SKEW")) : 0;
-        hipLaunchKernelGGL(vit_attn2_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, skew);
-    }
+    } else hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
     return vly_check_launch("vly_vit_attention");
 }
 
