@@ -604,6 +604,42 @@ def test_gemm_packed_weights_bit_identical(tile):
     assert torch.equal(ops.gemv(a[:4], pw), ops.gemv(a[:4], w))
 
 
+@pytest.mark.parametrize("M,N,K,epi,tile", [
+    (2688, 27648, 5120, 2, 298),      # 13B gate|up on 224-row tiles: 5 whole rounds + 16 tiles, eight slices each
+    (2688, 15360, 5120, 0, 298),      # 13B q|k|v: 2 rounds + 208 tiles (no split pays: S = 1)
+    (2688, 5120, 13824, 0, 298),      # 13B down: 240 tiles on 256 CUs, 216 K tiles per tile
+    (1312, 22016, 4096, 2, 299),      # 7B gate|up: 2 rounds + 90 tiles in two slices — the shape it is shipped for
+    (1312, 4096, 11008, 0, 299),      # 7B down: 112 tiles, two slices each: every tile is shared
+    (2048, 8192, 512, 0, 298),        # ragged 224-row tiling of an exact problem
+    (771, 1000, 256, 1, 299),         # 20 tiles of 4 K tiles: ragged M and N, quick_gelu + bias
+    (513, 520, 128, 0, 299),          # 2 K tiles per tile: one slice at most
+    (1000, 3000, 640, 0, 299), (900, 2040, 1024, 0, 298)])
+def test_gemm_p4_streamk(M, N, K, epi, tile):
+    """The persistent 4-wave kernel with its remainder round split along K (vly_gemm_bf16_streamk, tile hints 298 / 299) against
+    the same kernel without the split (198 / 199): identical where no tile is shared, fp32 summation order apart where one
+    is; fp32 outputs with bias + residual, the packed weight copy (bit-identical), and no hand-off failure."""
+    from valley_amd import ops
+    d = dev()
+    a = rnd((M, K), 91, dtype=torch.bfloat16).to(d)
+    w = rnd((N, K), 92, 0.03, dtype=torch.bfloat16).to(d)
+    bias = rnd((N,), 93, 0.5).to(d) if epi != ops.EPI_SWIGLU else None
+    want = ops.gemm_mfma(a, w, bias, epilogue=epi, tile_hint=tile - 100)
+    got = ops.gemm_streamk(a, w, bias, epilogue=epi, tile_hint=tile)
+    assert relerr(got, want) < 2e-3, relerr(got, want)
+    assert (got != want).float().mean() < 0.02                    # a bf16 ulp here and there, in pool tiles only
+    assert torch.equal(ops.gemm_streamk(a, ops.PackedWeight(w), bias, epilogue=epi, tile_hint=tile), got)
+    if epi == ops.EPI_NONE:
+        res = rnd((M, N), 94).to(d)
+        want32 = ops.gemm_mfma(a, w, bias, res, out_dtype=torch.float32, tile_hint=tile - 100)
+        got32 = ops.gemm_streamk(a, w, bias, res, out_dtype=torch.float32, tile_hint=tile)
+        assert maxabs(got32, want32) < 1e-4 * math.sqrt(K) + 1e-4, maxabs(got32, want32)
+        if M * N * K < 1 << 31:
+            ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu() + res.cpu()
+            assert maxabs(got32, ref) < 2e-4 * math.sqrt(K) + 1e-3
+    torch.cuda.synchronize()
+    assert ops.sk_error_flag(d) == 0
+
+
 def test_gemm_packed_rejects_half_tile_loops():
     from valley_amd import ops
     from valley_amd.lib import ValleyHipError

@@ -866,11 +866,31 @@ VLY_DEVICE void acc_read_pairs(const f32x4& a, f32x2& even, f32x2& odd) {
 // vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads return in order,
 // so an older load (the K tile this barrier publishes) cannot be outstanding unless the N1 younger ones are — whatever the
 // stores issued in between do; they only make the wait conservative.
-template <int BM, int BN, int EPI, int OUT>
+// SK = true (tile hints 298 / 299 of vly_gemm_bf16_streamk, round 3): the same kernel with the REMAINDER ROUND split along K.
+// The tiles past the last whole round of G workgroups (G = CUs) would cost a whole round for a fraction of the chip; instead
+// each of them is cut into S equal K slices (S chosen by the host so that S x remainder fills whole rounds: 164 tiles x 3 =
+// 492 units = 1.92 rounds of a third of a tile), the (slice, tile) units run FIRST, slice-major, one per workgroup and round,
+// then every workgroup walks its whole tiles as before.  Slices are UNIFORM on purpose: all workgroups of a round walk the
+// same K range in step, so tiles of one row / column still share their A / W panel in the XCD's L2 (contiguous stream-K
+// ranges — every workgroup at its own k — measured 1.1-1.8x SLOWER than no split at all: profiles/r03/r03_p4_streamk.jsonl).
+// Slices 0 .. S-2 are CONTRIBUTORS: fp32 accumulators to the unit's slab, agent-scope release, flag.  The last slice OWNS the
+// tile: it waits for the S - 1 flags (their units ran in the same or an earlier round: no deadlock while the grid is
+// resident, spins are bounded) and its epilogue adds the slabs to every accumulator block it reads — the accumulators
+// themselves are only ever written by MFMAs (anything else and hipcc moves them out of the AGPRs).
+// Hand-off protocol as gemm_sk_kernel's (gemm_streamk.hip); the K loop, staging and epilogues are this kernel's.
+struct P4Cursor {                                          // position in a workgroup's iteration stream
+    int tile, k, kend, u, r;                               // u: the pool unit being walked (or >= units: whole tiles, r = next round)
+};
+constexpr int P4_SK_MAX_WAYS = 8;                          // most slices per tile
+constexpr unsigned P4_SK_SPIN_LIMIT = 1u << 24;
+constexpr int P4_SK_ERR_FLAG = 4000;                       // index of the error word in the flag area (gemm_streamk.hip's)
+
+template <int BM, int BN, int EPI, int OUT, bool SK>
 __global__ void __launch_bounds__(256)
 gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
                const float* __restrict__ R, void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
-               int tiles_m, int tiles_n, int gm, RopeArgs rp) {
+               int tiles_m, int tiles_n, int gm, RopeArgs rp, float* __restrict__ slabs, unsigned* __restrict__ flags,
+               unsigned epoch, int sk_S) {
     constexpr int WM = BM / 2, WN = BN / 2, NT = 256;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -901,9 +921,32 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         n0 = (rr / gh) * BN;
     };
     const __amdgpu_buffer_rsrc_t rsA = vly_rsrc(A), rsW = vly_rsrc(W);
-    // (Tried in round 3 and removed: starting the four workgroup phases (id / 8) % 4 of an XCD 2 / 4 / 8 us apart, so that
-    // only a quarter of the XCD is in its store burst or VALU-only epilogue at a time — every shape but one lost 0.5-23 %,
-    // profiles/r03/r03_ab_stagger.jsonl: the idle head costs more than the lockstep does.)
+    // ---- split-K schedule of the remainder round (SK): unit u = slice * rem8 + p is slice u / rem8 of pool tile full * G + p
+    // (p < rem; rem8 = rem rounded up to 8, so that unit u, run by workgroup u % G, sits on tile p's XCD p & 7)
+    [[maybe_unused]] const int sk_full = ntiles / G, sk_rem = ntiles - sk_full * G, sk_rem8 = (sk_rem + 7) & ~7;
+    [[maybe_unused]] const int sk_units = sk_S * sk_rem8, sk_nks = (nk + sk_S - 1) / sk_S;      // K tiles per slice (host: every slice non-empty)
+    [[maybe_unused]] auto cur_unit = [&](P4Cursor& c) {                  // c.u -> the next live unit at or after it, or the whole tiles
+        while (c.u < sk_units && c.u % sk_rem8 >= sk_rem) c.u += G;
+        if (c.u < sk_units) {
+            const int sl = c.u / sk_rem8;
+            c.tile = sk_full * G + (c.u - sl * sk_rem8);
+            c.k = sl * sk_nks;
+            c.kend = min(nk, c.k + sk_nks);
+            return true;
+        }
+        if (c.r < sk_full) {
+            c.tile = c.r * G + (int)blockIdx.x; ++c.r; c.k = 0; c.kend = nk;
+            return true;
+        }
+        return false;
+    };
+    [[maybe_unused]] auto cur_next_seg = [&](P4Cursor& c) {              // false: the stream is used up (the cursor stays where it is)
+        P4Cursor n = c;
+        if (n.u < sk_units) n.u += G;
+        if (!cur_unit(n)) return false;
+        c = n;
+        return true;
+    };
     // ---- load cursor
     uint32_t voA[PA], voW[PW];
     auto set_offsets = [&](int m0, int n0) {
@@ -919,6 +962,14 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         }
     };
     int lt = (int)blockIdx.x, lk = 0;                                // tile / K tile the load cursor points at
+    [[maybe_unused]] P4Cursor sc;                                    // (SK: the same cursor as a segment walker)
+    if constexpr (SK) {
+        sc.u = (int)blockIdx.x;
+        sc.r = 0;
+        if (!cur_unit(sc)) return;                                   // (uniform: the whole workgroup; nothing to do)
+        lt = sc.tile;
+        lk = sc.k;
+    }
     // A piece = M0 (its LDS destination) + one buffer_load ... lds.  Written as two asm statements so that the M0 write
     // can sit in an EARLIER MFMA gap than the load (a 16x16x32 MFMA hides ~3 other issue slots; the builtin form puts
     // s_add m0 + s_nop + buffer_load into one gap).  Nothing else in this kernel touches M0 between the two.
@@ -937,16 +988,25 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         piece_ld(q);
     };
     auto advance_load = [&]() {                                      // past the last tile: stay on its last K tile
-        if (lk + 1 < nk) { ++lk; return; }
-        if (lt + G >= ntiles) return;
-        lt += G;
-        lk = 0;
+        if constexpr (SK) {
+            if (sc.k + 1 < sc.kend) { lk = ++sc.k; return; }
+            if (!cur_next_seg(sc)) return;
+            lt = sc.tile;
+            lk = sc.k;
+        } else {
+            if (lk + 1 < nk) { ++lk; return; }
+            if (lt + G >= ntiles) return;
+            lt += G;
+            lk = 0;
+        }
         int m0, n0;
         tile_origin(lt, m0, n0);
         set_offsets(m0, n0);
     };
     int cm0, cn0;                                                    // compute cursor
-    int ct = (int)blockIdx.x;
+    int ct = lt;
+    [[maybe_unused]] P4Cursor cc;
+    if constexpr (SK) cc = sc;
     tile_origin(ct, cm0, cn0);
     set_offsets(cm0, cn0);
 
@@ -1029,18 +1089,92 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             advance_load();
             buf ^= 1;
         };
+        [[maybe_unused]] int nfol = 0;                                   // SK owner: its epilogue adds the slabs of workgroups (x, j + 1 .. j + nfol)
+        [[maybe_unused]] bool contributor = false;
         {
-            int kt = 0;
-            do ktile(); while (++kt < nk);
+            int kt = SK ? cc.k : 0;
+            const int kend = SK ? cc.kend : nk;
+            do ktile(); while (++kt < kend);
         }
+        if constexpr (SK) {
+            const bool pool = cc.u < sk_units;
+            contributor = pool && cc.kend < nk;                      // slices 0 .. S-2
+            const bool chained = pool && cc.k > 0;                   // slices 1 .. S-1 take over the running sum of slice - 1
+            if (chained) {
+                // Consume side of Guideline 16 R1: one lane polls the one flag relaxed, one agent acquire, barrier, plain loads.
+                // The slices of a tile form a CHAIN — slice s publishes (its accumulators + the slab of slice s - 1) — so that
+                // the owner's epilogue adds ONE slab whatever S is: it has 32 registers to spare for that, not 32 (S - 1).
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(flags + (cc.u - sk_rem8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > P4_SK_SPIN_LIMIT) {            // never hang the GPU: flag the failure
+                            __hip_atomic_store(flags + P4_SK_ERR_FLAG, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                nfol = 1;
+            }
+            if (contributor) {
+                // publish the partial sums (lane-linear float4 image, fully coalesced); no epilogue.
+                // (The lane offset goes through an asm statement per fragment row: left to itself hipcc computes the 64 block
+                // addresses of a lane ONCE, outside the persistent loop, and spills 200 registers to hold them.)
+                // Publish side of R1: WRITE-THROUGH (sc1) 16-byte stores — a release fence would write back the XCD's whole
+                // L2 —, every wave drains its stores, barrier, one lane stores the flag.
+                const __amdgpu_buffer_rsrc_t rsS =
+                    __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)cc.u * (BM * BN), 0, (uint32_t)(BM * BN * 4), 0x00020000);
+                const float* prev = slabs + (size_t)(cc.u - sk_rem8) * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint32_t lo = (uint32_t)((i * NI * NT + tid) * 16);
+                    asm volatile("" : "+v"(lo));
+                    f32x4 pv[NI];
+                    if (chained) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) pv[j] = *(const f32x4*)((const char*)prev + lo + j * (NT * 16));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc_read(acc[i][j]) + pv[j]), rsS, lo + j * (NT * 16), 0, 16);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(flags + cc.u, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nfol = 0;
+            }
+        }
+        // SK owners (nfol = 1): the chain's running sum for the blocks of the current fragment row sits in sk_ld[]; the epilogue
+        // re-issues a block's load for row i + 1 as soon as it has consumed it (sk_next), so the reads of one row fly under
+        // the arithmetic of the row before.  (First version: one dependent load per block at its point of use = 128 exposed
+        // round trips per tile, +93 us on the 13B gate|up; second: two followers x a whole row ahead = 96 registers, spilled.)
+        [[maybe_unused]] f32x4 sk_ld[NI];
+        [[maybe_unused]] auto sk_next = [&](int i, int j0, int n) {  // loads of blocks j0 .. j0 + n - 1 of fragment row i
+            if (nfol == 0 || i >= MI) return;
+            uint32_t lo = (uint32_t)((i * NI * NT + tid) * 16);      // (opaque: see the contributor's stores)
+            asm volatile("" : "+v"(lo));
+            const char* sl = (const char*)(slabs + (size_t)(cc.u - sk_rem8) * (BM * BN)) + lo;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (j >= j0 && j < j0 + n) sk_ld[j] = *(const f32x4*)(sl + j * (NT * 16));
+        };
+        [[maybe_unused]] auto slab_term = [&](int, int j) { return nfol ? sk_ld[j] : f32x4{0.f, 0.f, 0.f, 0.f}; };
+        if constexpr (SK) sk_next(0, 0, NI);
         // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
         // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
-        {
+        if (!(SK && contributor)) {
         if constexpr (OUT == VLY_OUT_BF16 && EPI == VLY_EPI_QKV_ROPE) {
             // RoPE + KV append on registers: a wave's 128 columns are ONE head (cn0 + wn0 is a multiple of 128),
             // the rotation partner of column c < 64 is c + 64 = block j + 4 of the SAME lane.  Same arithmetic
             // on the same bf16-rounded projections as rope_kv_kernel -> identical bits (tests compare them).
             static_assert(NI == 8, "one head per wave");
+            static_assert(!SK, "the fused RoPE epilogue has no stream-K form");
             const int nb = cn0 + wn0, Hq = rp.heads * 128, sect = nb / Hq, head = (nb - sect * Hq) >> 7;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -1114,7 +1248,14 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         // through every step of x_sigmoid2(gate, 1) * up together (see the quick_gelu branch)
                         f32x2 gt[4], up[4], e[4];
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc_read_pairs(acc[i][4 * jq + jj], gt[jj], up[jj]);
+                        for (int jj = 0; jj < 4; ++jj) {
+                            if constexpr (SK) {
+                                const f32x4 v = acc_read(acc[i][4 * jq + jj]) + slab_term(i, 4 * jq + jj);
+                                gt[jj] = f32x2{v[0], v[2]};
+                                up[jj] = f32x2{v[1], v[3]};
+                            } else acc_read_pairs(acc[i][4 * jq + jj], gt[jj], up[jj]);
+                        }
+                        if constexpr (SK) sk_next(i + 1, 4 * jq, 4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) e[q] = gt[q] * -1.4426950408889634f;
 #pragma unroll
@@ -1143,7 +1284,12 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         // the four register pairs of two blocks go through every step TOGETHER: between a packed op and the
                         // transcendental that consumes it (and back) the hardware wants a wait state, which independent
                         // work fills (one chain at a time cost 487 s_nop per tile)
-                        const f32x4 v0 = acc_read(acc[i][2 * jp]) + bv[2 * jp], v1 = acc_read(acc[i][2 * jp + 1]) + bv[2 * jp + 1];
+                        f32x4 v0 = acc_read(acc[i][2 * jp]) + bv[2 * jp], v1 = acc_read(acc[i][2 * jp + 1]) + bv[2 * jp + 1];
+                        if constexpr (SK) {
+                            v0 += slab_term(i, 2 * jp);
+                            v1 += slab_term(i, 2 * jp + 1);
+                            sk_next(i + 1, 2 * jp, 2);
+                        }
                         f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
                         if constexpr (EPI == VLY_EPI_QUICK_GELU) {
                             constexpr float c = -1.4426950408889634f * 1.702f;           // x_sigmoid2's arithmetic, step by step
@@ -1190,6 +1336,12 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 __builtin_amdgcn_sched_barrier(0);
+                [[maybe_unused]] f32x4 skc[NI];                      // (SK owners: this row's slab terms; the next row's loads leave now)
+                if constexpr (SK) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) skc[j] = slab_term(i, j);
+                    sk_next(i + 1, 0, NI);
+                }
                 const int m = cm0 + wm0 + i * 16 + l15;
                 if (m < M) {
                     float* crow = (float*)Cv + (size_t)m * ldc + ncol;
@@ -1197,18 +1349,31 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         const float* rrow = R + (size_t)m * ldr + ncol;
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
-                            if (ncol + j * 16 < N) *(f32x4*)(crow + j * 16) = acc_read(acc[i][j]) + bv[j] + *(const f32x4*)(rrow + j * 16);
+                            if (ncol + j * 16 < N) {
+                                f32x4 v = acc_read(acc[i][j]) + bv[j] + *(const f32x4*)(rrow + j * 16);
+                                if constexpr (SK) v += skc[j];
+                                *(f32x4*)(crow + j * 16) = v;
+                            }
                     } else {
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
-                            if (ncol + j * 16 < N) *(f32x4*)(crow + j * 16) = acc_read(acc[i][j]) + bv[j];
+                            if (ncol + j * 16 < N) {
+                                f32x4 v = acc_read(acc[i][j]) + bv[j];
+                                if constexpr (SK) v += skc[j];
+                                *(f32x4*)(crow + j * 16) = v;
+                            }
                     }
                 }
             }
         }
         }
-        if (ct + G >= ntiles) break;
-        ct += G;
+        if constexpr (SK) {
+            if (!cur_next_seg(cc)) break;
+            ct = cc.tile;
+        } else {
+            if (ct + G >= ntiles) break;
+            ct += G;
+        }
         tile_origin(ct, cm0, cn0);
         {   // K step 0 of the next tile's first K tile: it landed before the last barrier B (same buffer rotation)
             auto r0 = rd_step0(smem + buf * STAGE);
@@ -1219,9 +1384,16 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-template <int BM, int BN>
+struct P4SkArgs {                                          // split-K remainder form (vly_gemm_bf16_streamk, tile hints 298 / 299)
+    float* slabs;
+    unsigned* flags;
+    unsigned epoch;
+    int slab_cap;                                          // slabs the workspace holds
+};
+
+template <int BM, int BN, bool SK = false>
 int launch_p4(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw,
-              int ldc, int ldr, int epi, int out, hipStream_t st, const RopeArgs* rope = nullptr) {
+              int ldc, int ldr, int epi, int out, hipStream_t st, const RopeArgs* rope = nullptr, const P4SkArgs* sk = nullptr) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, 1);
     // bf16 outputs leave as 16-byte buffer stores clipped by the descriptor: aligned rows, whole 8-column chunks, < 2 GB
@@ -1237,17 +1409,34 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
         return n > 0 ? n / 8 * 8 : 256;                                // a multiple of the XCD count (tile -> XCD mapping)
     }();
     const int tiles = tm * tn;
-    dim3 grid(tiles < cus ? tiles : cus), block(256);
+    // SK: slices per remainder tile — the S that packs S x rem8 units into the fewest rounds per slice (1 = no split), within
+    // the slab capacity, at least two K tiles per slice, +6 % of a tile per extra slice for the hand-off chain and the shallower
+    // loop (measured: 7B gate|up on 192-row tiles 206 / 216 / 242 us at S = 2 / 4 / 8, profiles/r03/r03_p4_splitk_slices.jsonl)
+    int sk_S = 1;
+    if constexpr (SK) {
+        const int rem = tiles % cus, rem8 = (rem + 7) & ~7, nk = K / BK;
+        float best = 1e30f;
+        for (int S = 1; S <= P4_SK_MAX_WAYS && rem > 0; ++S) {
+            if (S > 1 && ((S - 1) * rem8 > sk->slab_cap || nk / S < 2 || (S - 1) * ((nk + S - 1) / S) >= nk)) continue;
+            const float cost = (float)((S * rem8 + cus - 1) / cus) / (float)S + 0.06f * (float)(S - 1);
+            if (cost < best - 1e-6f) { best = cost; sk_S = S; }
+        }
+        static const int pin = [] { const char* e = getenv("VLY_P4_SK_S"); return e ? atoi(e) : 0; }();      // (A/B runs)
+        if (pin > 0 && rem > 0 && (pin == 1 || ((pin - 1) * rem8 <= sk->slab_cap && nk / pin >= 2))) sk_S = pin;
+    }
+    dim3 grid(SK || tiles >= cus ? cus : tiles), block(256);           // SK: every CU takes its share of the units
 #define VLY_P4_LAUNCH(E, O)                                                                                                  \
-    hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
-                       K, lda, ldw, ldc, ldr, tm, tn, gm, rope ? *rope : RopeArgs{})
+    hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O, SK>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, \
+                       N, K, lda, ldw, ldc, ldr, tm, tn, gm, rope ? *rope : RopeArgs{}, sk ? sk->slabs : nullptr,                 \
+                       sk ? sk->flags : nullptr, sk ? sk->epoch : 0u, sk_S)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_SWIGLU, VLY_OUT_BF16);
     else if (epi == VLY_EPI_RELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_RELU, VLY_OUT_BF16);
-    else if (epi == VLY_EPI_QKV_ROPE && out == VLY_OUT_BF16 && rope) VLY_P4_LAUNCH(VLY_EPI_QKV_ROPE, VLY_OUT_BF16);
-    else {
+    else if (!SK && epi == VLY_EPI_QKV_ROPE && out == VLY_OUT_BF16 && rope) {
+        if constexpr (!SK) VLY_P4_LAUNCH(VLY_EPI_QKV_ROPE, VLY_OUT_BF16);
+    } else {
         vly_set_error("vly_gemm_bf16: unsupported epilogue/out_dtype combination (%d,%d) for the persistent tiles", epi, out);
         return -22;
     }
@@ -1319,6 +1508,37 @@ static int pick_tile(int M, int N) {
     const double c2x1 = cost(256, 128, 1, 0.88);
     if (c256 <= c128 && c256 <= c2x1) return 1;
     return c2x1 <= c128 ? 3 : 2;
+}
+
+// The split-K-remainder form of the persistent kernel, for vly_gemm_bf16_streamk (gemm_streamk.hip): tile 298 / 299 = 224 / 192
+// rows x 256 columns.  Returns 1 when the shape cannot take the persistent kernel's vector stores (the caller reports it).
+__attribute__((visibility("hidden"))) int valley_p4_streamk(int tile, const void* A, const void* W, const float* bias, const float* R,
+                                                            void* C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epi,
+                                                            int out, void* ws, size_t ws_bytes, unsigned epoch, hipStream_t st) {
+    constexpr size_t FLAG_BYTES = 16384;                               // gemm_streamk.hip's workspace layout: flags, then slabs
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = cus > 0 ? cus / 8 * 8 : 256;
+    const int bm = tile == 298 ? 224 : 192;
+    if (!ws || ws_bytes < FLAG_BYTES + (size_t)bm * 256 * 4) {
+        vly_set_error("vly_gemm_bf16_streamk: workspace too small (%zu bytes)", ws_bytes);
+        return -22;
+    }
+    int cap = (int)((ws_bytes - FLAG_BYTES) / ((size_t)bm * 256 * 4));  // one slab per contributor unit; their flags share the 4000 words
+    if (cap > P4_SK_ERR_FLAG - 8) cap = P4_SK_ERR_FLAG - 8;
+    if (K < 128 || K % BK) { vly_set_error("vly_gemm_bf16_streamk: the persistent tiles need K >= 128"); return -22; }
+    const P4SkArgs sk{(float*)((char*)ws + FLAG_BYTES), (unsigned*)ws, epoch, cap};
+    int rc;
+    // (256-row tiles have no split-K form: with 256 accumulators per lane the owner's epilogue has no 32 registers for the
+    // chain's slab terms — hipcc spills 66-164 — and the kernel measured 3-8 % slower than the plain one on every shape)
+    if (tile == 298) rc = launch_p4<224, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
+    else rc = launch_p4<192, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
+    if (rc == 1) {
+        vly_set_error("vly_gemm_bf16_streamk: tile %d needs 16-byte aligned rows of whole 8-column chunks and no residual for bf16 outputs", tile);
+        return -22;
+    }
+    return rc;
 }
 
 extern "C" int vly_gemm_tile_for(int M, int N) { return pick_tile(M, N); }

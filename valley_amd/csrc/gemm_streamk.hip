@@ -38,6 +38,9 @@
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
+int valley_p4_streamk(int tile, const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda,
+                      int ldw, int ldc, int ldr, int epi, int out, void* ws, size_t ws_bytes, unsigned epoch, hipStream_t st);   // gemm_bf16.hip
+
 namespace {
 
 constexpr int BK = 64;
@@ -396,8 +399,10 @@ int pick_sk_tile(int M, int N, int K) {
 
 extern "C" size_t vly_gemm_streamk_workspace_bytes(void) {
     // worst case over the configurations: G x BM x BN fp32 slabs + flags
+    // (2 x: the persistent kernel's split-K remainder, hints 298 / 299, keeps one slab per contributor UNIT — up to S - 1 per
+    // remainder tile; with less it settles for fewer slices)
     const size_t g1 = (size_t)num_cus();
-    const size_t a = g1 * 256 * 256 * 4, b = 2 * g1 * 128 * 128 * 4;
+    const size_t a = 2 * g1 * 256 * 256 * 4, b = 2 * g1 * 128 * 128 * 4;
     return FLAG_BYTES + (a > b ? a : b);
 }
 
@@ -408,18 +413,22 @@ extern "C" int vly_gemm_bf16_streamk(const void* A, const void* W, const float* 
                                      int out_dtype, int tile_hint, void* workspace, size_t workspace_bytes,
                                      unsigned epoch, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16_streamk: empty problem"); return -22; }
-    if (K % BK || lda % 8 || ldw % 8 || ldw <= 0 /* row-major weights only: no VLY_LDW_PACKED64 */ || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
+    const bool p4 = tile_hint == 298 || tile_hint == 299;   // the persistent 4-wave kernel with a stream-K pool (gemm_bf16.hip)
+    if (K % BK || lda % 8 || ldw % 8 || (ldw <= 0 && !(p4 && ldw == VLY_LDW_PACKED64)) /* row-major weights, or the block layout for 298 / 299 */ || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
         ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || ((uintptr_t)workspace & 15) ||
         (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15)) || epoch == 0) {
         vly_set_error("vly_gemm_bf16_streamk: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",
                       M, N, K, lda, ldw, ldc, ldr);
         return -22;
     }
-    if ((size_t)M * lda >= (1ull << 32) || (size_t)N * ldw >= (1ull << 32)) {
+    if ((size_t)M * lda >= (1ull << 32) || (size_t)N * (ldw > 0 ? ldw : K) >= (1ull << 32)) {
         vly_set_error("vly_gemm_bf16_streamk: operand exceeds 2^32 elements");
         return -22;
     }
     if (epilogue == VLY_EPI_SWIGLU && residual) { vly_set_error("vly_gemm_bf16_streamk: SWIGLU takes no residual"); return -22; }
+    if (p4)
+        return valley_p4_streamk(tile_hint, A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, workspace,
+                                 workspace_bytes, epoch, (hipStream_t)stream);
     const SkArgs a{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype,
                    workspace, workspace_bytes, epoch, (hipStream_t)stream};
     const int t = tile_hint ? tile_hint : pick_sk_tile(M, N, K);
