@@ -118,11 +118,11 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     if rec is not None:
         e1.record()
         if sk and tile in (298, 299):
-            name = f"gemm_p4_kernel<{TILE_SPECIAL[tile - 100][0][3:]}, {epilogue}, {od}, sk>"
+            name = f"gemm_p4_kernel<{TILE_SPECIAL[tile - 100][0][3:]}, {epilogue}, {od}, true>"     # (the names rocprofv3 prints)
         elif sk:
             name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}, {sk_loop}>"
         elif tile in (197, 198, 199) and K >= 128 and (od == OUT_F32 or (residual is None and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0)):
-            name = f"gemm_p4_kernel<{TILE_SPECIAL[tile][0][3:]}, {epilogue}, {od}>"
+            name = f"gemm_p4_kernel<{TILE_SPECIAL[tile][0][3:]}, {epilogue}, {od}, false>"
         elif tile in TILE_SPECIAL:
             name = f"gemm_kernel<{TILE_SPECIAL[tile - 100 if tile in (197, 198, 199) else tile][0]}, {epilogue}, {od}, {TILE_SPECIAL[tile][1]}>"
         else:
@@ -275,7 +275,7 @@ def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
         t = tile_hint or L.vly_gemm_tile_for(M, N)
         nm = TILE_SPECIAL[t][0] if t in TILE_SPECIAL else TILE_NAMES[t % 10]
         loop = TILE_SPECIAL[t][1] if t in TILE_SPECIAL else ({0: 0, 1: 1, 3: 3, 5: 4, 7: 6, 8: 7})[t // 10]
-        name = f"gemm_p4_kernel<{nm[3:]}, 4, 0>" if t in (197, 198, 199) else f"gemm_kernel<{nm}, 4, 0, {loop}>"
+        name = f"gemm_p4_kernel<{nm[3:]}, 4, 0, false>" if t in (197, 198, 199) else f"gemm_kernel<{nm}, 4, 0, {loop}>"
         rec.append((name, 2.0 * M * N * K, e0, e1, (M, N, K, EPI_QKV_ROPE)))
     _lib.check(rc, "vly_gemm_bf16_qkv_rope")
     return qkv
