@@ -218,6 +218,19 @@ def test_vit_attention():
     assert relerr(out, ref) < 6e-3
 
 
+def test_llama_attention_register_staged_kernel_still_passes():
+    """VLY_LLAMA_ATTN=1 keeps the round-2 kernel (llama_attn_kernel: tiles through registers, one workgroup per CU) — the fallback
+    for caches of 4 GB and more; the switch is read once per process, so the attention tests re-run under it in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "attention and not register_staged and not persistent_variant"],
+                       env=dict(os.environ, VLY_LLAMA_ATTN="1"), capture_output=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-1500:]
+
+
 @pytest.mark.parametrize("F", [3, 40])
 def test_vit_attention_persistent_variant(F):
     """VLY_VIT_ATTN=4 (vit_attn4_kernel: one 16-wave workgroup per CU, K / V by LDS-DMA, V through ds_read_b64_tr_b16) against

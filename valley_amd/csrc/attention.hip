@@ -768,6 +768,174 @@ __global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __
 // to LDS; phase 2: block max / sum; phase 3: 16 threads share a V row (8 d each), 16 keys per pass,
 // fp32 partial sums reduced through LDS.
 // ---------------------------------------------------------------------------------------------
+// ---- round 3: the same attention with K / V tiles by LDS-DMA, V through ds_read_b64_tr_b16, two workgroups per CU ---------
+// llama_attn_kernel holds 160-222 registers (one 8-wave workgroup per CU; PMC: half of all wave cycles parked) and pays two
+// barriers per 64-key tile because its tiles pass through registers (K) and a register transpose (V).  Here a tile is 16 + 16
+// one-KB LDS-DMA pieces (asm buffer_load ... lds, M0 = destination: no registers, no VALU), K swizzled on the SOURCE address
+// (chunk ^= row & 15, the layout the S^T fragment reads expect), V ROW-major with its 32-byte chunk pairs XORed by row & 7 and
+// read as the second product's A operand by the hardware transpose read (vit_attn4_kernel's scheme at 256-byte rows: the 8
+// rows of a half wave land in 8 distinct 32-byte slots of the 256-byte bank window).  Two buffers: tile t + 1 flies under
+// tile t, ONE barrier per tile.  No staging registers -> <= 128 per lane -> two workgroups per CU: one workgroup's start-up
+// (Q fragments, first tile) hides under the other's tiles.  Same arithmetic, same order as llama_attn_kernel: bit-identical.
+VLY_DEVICE bf16x8 vt_frag256(const char* lo_addr) {          // two transpose reads: keys +0..3 and +16..19 of this lane group's rows
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_addr + 16 * 256));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+constexpr int L2_TILE = 64 * 256;           // one K or V tile: 64 keys x 128 d x 2 B
+constexpr int L2_BUF = 2 * L2_TILE;
+
+__global__ void __launch_bounds__(LNW * 64, 4) llama_attn2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
+                                                                 const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
+                                                                 uint16_t* __restrict__ out, int S, int heads, int past,
+                                                                 const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
+    static_assert(LNW == 8, "16 + 16 pieces on 8 waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * L2_BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y, qb = (int)gridDim.z - 1 - (int)blockIdx.z;      // longest block first
+    const int Hq = heads * 128;
+    if (past_dev) past = min(*past_dev, ctx_max - S);
+    const int kv_len = past + S;
+
+    const int q = qb * (LNW * 16) + wave * 16 + l15;      // query row inside this call
+    const int qc = min(q, S - 1);
+    const int qpos = past + q;                            // absolute position: keys <= qpos are visible
+    const int q_last = min(qb * (LNW * 16) + LNW * 16 - 1, S - 1);
+    const int wave_qpos_max = past + min(qb * (LNW * 16) + wave * 16 + 15, S - 1);   // tiles beyond it are fully masked for this wave
+    const int kv_end = min(past + q_last + 1, kv_len);
+    const int ntiles = (kv_end + 63) >> 6;
+
+    // ---- staging: wave w issues K pieces 2w, 2w + 1 and V pieces 2w, 2w + 1 of a tile (piece p = rows 4p .. 4p + 3)
+    const __amdgpu_buffer_rsrc_t rsK = vly_rsrc(kc), rsV = vly_rsrc(vc), rsM = vly_rsrc(key_valid);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t hb = (uint32_t)((b * heads + h) * ctx_max) * 256u;                        // byte offset of this head's rows
+    uint32_t okraw = 1u;
+    bool okin = false;
+    auto stage = [&](int kt, int buf) {
+        const int kv0 = kt * 64;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pc = 2 * wave + pp, row = 4 * pc + (lane >> 4), cp = lane & 15;
+            const uint32_t rb = hb + (uint32_t)min(kv0 + row, kv_len - 1) * 256u;          // (rows past kv_len re-read the last key: masked)
+            const uint32_t voK = rb + (uint32_t)((cp ^ (row & 15)) << 4);
+            const uint32_t voV = rb + (uint32_t)((cp ^ ((row & 7) << 1)) << 4);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)buf * L2_BUF + (uint32_t)pc * 1024u);
+            asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
+            asm volatile("s_nop 0" ::: "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voK), "s"(rsK) : "memory");
+            asm volatile("s_mov_b32 m0, %0" ::"s"(dst + (uint32_t)L2_TILE) : "memory");
+            asm volatile("s_nop 0" ::: "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voV), "s"(rsV) : "memory");
+        }
+        const int kvl = kv0 + lane;                                    // (a buffer load: no 64-bit per-lane pointer to keep alive)
+        okin = kvl < kv_len;                                           // (the loaded byte is only looked at at the ballot: no wait for it here)
+        if (key_valid) okraw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsM, (uint32_t)(b * kv_stride + min(kvl, kv_len - 1)), 0, 0);
+    };
+    // per-lane byte offset of the V fragment of d tile dt inside a V tile image: row 4g + t (t = l15 >> 2), 8-byte half l15 & 1,
+    // chunk (2 dt + ((l15 & 3) >> 1)) ^ ((row & 7) << 1); + 8192 c per 32-key chunk (+ 4096 = 16 rows for the second read)
+    // = ((dt ^ (row & 7)) << 5) | (((l15 & 3) >> 1) << 4): one base + one XOR term per lane; both go through opaque_i32 at
+    // the top of every tile, or hipcc precomputes the eight per-dt offsets outside the loop and spills to hold them
+    const int vr = 4 * g + (l15 >> 2);
+    const int vbase0 = L2_TILE + vr * 256 + (l15 & 1) * 8 + (((l15 & 3) >> 1) << 4), vx0 = (vr & 7) << 5;
+
+    if (ntiles > 0) stage(0, 0);
+    const uint16_t* qp = qkv + ((size_t)b * S + qc) * 3 * Hq + h * 128;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 32 + g * 8);
+
+    const float sc = 0.08838834764831845f * LOG2E;        // 128^-0.5 * log2(e)
+    float m = NEG_BIG, l = 0.f;
+    f32x4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int kv0 = kt * 64, buf = kt & 1;
+        const char* sK = smem + buf * L2_BUF;
+        // this wave's pieces of tile kt (and its Q fragments, and the key-validity byte) have landed — the BUILTIN wait, so
+        // that hipcc does not add its own vmcnt(0) behind the next tile's DMA issue —, then everyone's, and everyone is done
+        // with the other buffer
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        const unsigned long long vmask = __ballot(okin && (okraw & 0xffu) != 0u);
+        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1);      // in flight while this tile is multiplied
+        if (kv0 > wave_qpos_max) continue;                // every key of this tile is in this wave's future (wave-uniform)
+        const int vbase = opaque_i32(vbase0), vx = opaque_i32(vx0);
+
+        // ---- S^T tile ---------------------------------------------------------------------------
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 256 + (((kk * 4 + g) ^ l15) << 4));
+                acc = mfma16(kf, qf[kk], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kl = t * 16 + 4 * g + r;
+                const bool vis = ((vmask >> kl) & 1ull) && (kv0 + kl <= qpos);
+                s[t][r] = vis ? acc[r] * sc : NEG_BIG;
+            }
+        }
+        // ---- online softmax ------------------------------------------------------------------------
+        float rm = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rm = fmaxf(rm, s[t][r]);
+        rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
+        rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
+        const float mn = fmaxf(m, rm);
+        const float alpha = sm_exp2(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sm_exp2(s[t][r] - mn);
+                s[t][r] = p;
+                ps += p;
+            }
+        l = l * alpha + ps;                                // per-lane partial; the 4 g-lanes share alpha
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+        // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 pk;
+            pk[0] = pack_h2(s[2 * c][0], s[2 * c][1]);
+            pk[1] = pack_h2(s[2 * c][2], s[2 * c][3]);
+            pk[2] = pack_h2(s[2 * c + 1][0], s[2 * c + 1][1]);
+            pk[3] = pack_h2(s[2 * c + 1][2], s[2 * c + 1][3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+                o[dt] = mfma16(vt_frag256(sK + vbase + ((dt << 5) ^ vx) + c * 8192), pf, o[dt]);
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q < S) {
+        const float inv = 1.f / l;
+        uint16_t* op = out + ((size_t)b * S + q) * Hq + h * 128 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            u32x2 pk;
+            pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
+            pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
+            *(u32x2*)(op + dt * 16) = pk;
+        }
+    }
+}
+
 constexpr int DEC_MAX_CTX = 8192;
 
 __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
@@ -1178,6 +1346,15 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
                            (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out, heads, past_len,
                            past_len_dev, key_valid_stride, ctx_max);
         return vly_check_launch("vly_llama_attention(decode)");
+    }
+    // llama_attn2_kernel (LDS-DMA tiles, two workgroups per CU: 59.3 -> 45.0 us per 13B layer at B = 8, S = 336; 77 -> 53 at S = 1024,
+    // profiles/r03/r03_llama_attn2.txt); its 32-bit row offsets need a cache < 4 GB.  VLY_LLAMA_ATTN=1 keeps llama_attn_kernel.
+    static const int ver = getenv("VLY_LLAMA_ATTN") ? atoi(getenv("VLY_LLAMA_ATTN")) : 2;
+    if (ver == 2 && (size_t)B * heads * ctx_max * 256 < ((size_t)1 << 32)) {
+        hipLaunchKernelGGL(llama_attn2_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,
+                           (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
+                           S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
+        return vly_check_launch("vly_llama_attention");
     }
     hipLaunchKernelGGL(llama_attn_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
