@@ -98,20 +98,14 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     const int l15 = lane & 15, g = lane >> 4;
     [[maybe_unused]] const int hi16 = opaque_i32(16);          // see opaque_i32
     const int h = blockIdx.x & 15;
-#ifndef VLY_VIT_DBG
-#define VLY_VIT_DBG 0      // timing experiments (WRONG results; A/B builds only): 1 = staging only, 2 = compute only (hipcc also folds
-                           // the LDS reads of the never-written array), 3 = no output stores, 4 = every workgroup reads frame
-                           // blockIdx & 3's q|k|v (L2-resident inputs), 5 = as 4 and writes there too (no HBM traffic at all),
-                           // 6 = softmax without the exp2, 7 = no softmax arithmetic at all
-#endif
-    const int f = VLY_VIT_DBG == 5 ? (blockIdx.x >> 4) & 3 : blockIdx.x >> 4;
-    const uint16_t* base = qkv + (size_t)(VLY_VIT_DBG >= 4 ? f & 3 : f) * VN * VLD + h * 64;
+    // (Timing variants of this kernel — staging only, no LDS reads, no stores, L2-resident inputs, no HBM traffic, no exp2, no
+    // softmax arithmetic — were compile-time switches here while profiles/r03/r03_vit_attn_timing_variants{,2}.jsonl were
+    // measured; they and the old 8-byte store pattern left with commit 49dfb3f's successor.)
+    const int f = blockIdx.x >> 4;
+    const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
 
-#ifndef VLY_VIT_STORE
-#define VLY_VIT_STORE 1    // 1: 32-byte runs per lane after a 4 x 4 lane transpose (store_tile_rows' pattern); 0: four 8-byte pieces (A/B)
-#endif
     // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7 ------------------------------------
-    for (int s = tid; s < (VLY_VIT_DBG == 2 ? 0 : VNT * 16 * 8); s += VNW * 64) {
+    for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
         const int row = s >> 3, c = s & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < VN) v = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
@@ -120,7 +114,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     // ---- V^T: [64 d][288 kv]; wave w transposes d = 16(w&3)..+15, lane <-> key pair; the key-pair groups
     //      pg = 0,1,2 are dealt to the wave quads (w>>2) round-robin
     const int dq = wave & 3;
-    for (int pg = wave >> 2; pg < (VLY_VIT_DBG == 2 ? 0 : 3); pg += VNW / 4) {
+    for (int pg = wave >> 2; pg < 3; pg += VNW / 4) {
         const int p = pg * 64 + lane;
         if (p < VNC * 16) {
             const int kv0 = 2 * p, kv1 = kv0 + 1;
@@ -143,7 +137,6 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         }
     }
     __syncthreads();
-    if (VLY_VIT_DBG == 1) return;
 
     const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
     // the Q fragments come straight from global memory: the next query tile's are requested before this tile's math
@@ -163,50 +156,8 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
         }
 
-#ifndef VLY_VIT_SOFTMAX
-#define VLY_VIT_SOFTMAX 0      // 0 (default): scale, then max / exp2(s - m); 1: scale folded into the exponent FMA + max3 chain — fewer VALU
-                               // instructions, measured 4 % SLOWER (tools/ab_lib.py run-vit-attn: 113.4 vs 109.0 us at 128 frames)
-#endif
-#if VLY_VIT_SOFTMAX == 1
-        // raw scores (K . q) stay unscaled: the softmax scale rides in the exponent's FMA, exp2(s * sc - m * sc)
-        // (one multiply per score less; v_max3 halves the max chain) — the softmax VALU work, not the MFMAs, is what a
-        // SIMD's four waves contend for in this kernel
-        f32x4 s[VNT];
-#pragma unroll
-        for (int t = 0; t < VNT; ++t) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                acc = mfma16(kf, qf[kk], acc);
-            }
-            s[t] = acc;
-            if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
-        }
-        // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
-
-        float m = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < VNT; ++t) m = fmaxf(fmaxf(m, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float msc = m * sc;
-        float l = 0.f;
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = sm_exp2(fmaf(s[t][r], sc, -msc));
-                s[t][r] = p;
-                l += p;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-
-#else
+        // (scale, then max / exp2(s - m).  Folding the scale into the exponent's FMA with a max3 chain — fewer VALU instructions —
+        // measured 4 % SLOWER: 113.4 vs 109.0 us at 128 frames, round 2.)
         f32x4 s[VNT];
 #pragma unroll
         for (int t = 0; t < VNT; ++t) {
@@ -226,7 +177,6 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 
         float m = NEG_BIG;
         float l = 0.f;
-        if (VLY_VIT_DBG != 7) {                                   // 7: no softmax arithmetic at all (scores go straight to the packs)
 #pragma unroll
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
@@ -237,15 +187,13 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = VLY_VIT_DBG == 6 ? s[t][r] - m : sm_exp2(s[t][r] - m);     // 6: no transcendentals
+                const float p = sm_exp2(s[t][r] - m);
                 s[t][r] = p;
                 l += p;
             }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        } else l = 1.f;
 
-#endif
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -273,21 +221,10 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             }
             asm volatile("" ::: "memory");
         }
-        if (VLY_VIT_DBG == 3) { asm volatile("" ::"v"(o[0][0]), "v"(o[1][0]), "v"(o[2][0]), "v"(o[3][0]), "v"(l)); continue; }
         {   // (every lane takes part in the lane swaps; rows past token 256 write to the clamped row's twin and are masked)
             const float inv = 1.f / l;
             uint16_t* op = out + ((size_t)f * VN + min(q, VN - 1)) * 1024 + h * 64;
-            if (VLY_VIT_STORE == 0) {
-                if (q < VN) {
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        u32x2 pk;
-                        pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
-                        pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
-                        *(u32x2*)(op + 4 * g + dt * 16) = pk;
-                    }
-                }
-            } else {
+            {   // 32-byte runs per lane after a 4 x 4 lane transpose (8-byte pieces per lane measured 3 % slower: r03_ab_vit_store.jsonl)
                 uint32_t y[2][4];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
