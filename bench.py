@@ -267,6 +267,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=list(CONFIGS))
     ap.add_argument("--prefill", default="sharded", choices=["sharded", "replicated"])
+    ap.add_argument("--simulate-ranks", type=int, default=1, metavar="R",
+                    help="N = 1 only, with --prefill replicated: run THIS rank's share of an R-rank job — local clips encoded once, "
+                         "their pooled tokens tiled R times in place of the all-gather, then the replicated prefill of all R x B "
+                         "sequences (configs[3] at R = 8: B = 64, M = 22528 rows per GEMM).  `value` counts the local frames only.")
     ap.add_argument("--decode", type=int, default=0, metavar="N",
                     help="instead of the prefill step: prefill once, then time N greedy hipGraph decode steps (configs[4])")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VALLEY_BENCH_STREAMS", "1")),
@@ -333,10 +337,11 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     frames = torch.randn((B, T, 3, 224, 224), generator=g, device=dev).to(runtime.HALF)
     ids = torch.from_numpy(W.synthetic_prompt(7, T, VOCAB_TEXT)).view(1, S)
-    Bp = B * world if args.prefill == "replicated" else B
+    sim = args.simulate_ranks if (world == 1 and args.prefill == "replicated") else 1
+    Bp = B * world * sim if args.prefill == "replicated" else B
     input_ids = ids.repeat(Bp, 1)
     cache = mm.llama.new_cache(Bp, S)
-    Ts_all = [T] * (B * world)
+    Ts_all = [T] * (B * world * sim)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     stage_events = []
@@ -411,6 +416,8 @@ def main():
             if record:
                 g1.record()
                 gather_events.append((g0, g1, pooled.shape[0] // world * pooled.shape[1] * pooled.element_size()))
+        if sim > 1:                                                      # stand-in for the all-gather of R ranks' pooled tokens
+            pooled = pooled.repeat(sim, 1)
         if record:
             e1.record()
         visual = mm.project_pooled(pooled)                               # all N*B clips' tokens, on every rank
@@ -493,7 +500,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DT, "data": "synthetic",
             "config": {"workload": cfg["label"] + f", S={S}, end-to-end hot path (encode+pool+project+splice+prefill+lm_head)",
                        "name": args.config, "clips_per_gpu": B, "frames_per_clip": T, "prefill_batch_per_gpu": Bp,
-                       "seq_len": S, "tune_passes": tune_passes, "streams": NS, "weights": "row-major + packed64" if args.pack_weights else "row-major", "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "")},
+                       "seq_len": S, "tune_passes": tune_passes, "streams": NS, "weights": "row-major + packed64" if args.pack_weights else "row-major", "parallelism": f"frame-dp{world}" + ("+replicated-prefill" if args.prefill == "replicated" else "") + (f" (one rank of a simulated {sim}-rank job)" if sim > 1 else "")},
             "stages": {"vit_frames_per_s_per_gpu": round(vit_fps, 1), "vit_ms": round(vit_ms, 3),
                        "vit_TFLOPs": round(vit_tf, 1), "vit_frac_of_bf16_peak": round(vit_tf / PEAK_BF16_TFLOPS, 4),
                        "prefill_tokens_per_s_per_gpu": round(pre_tps, 1), "prefill_ms": round(pre_ms, 3),
