@@ -227,8 +227,8 @@ class HipLlama:
                 ops.decode_attention(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, kv, B, self.heads, past,
                                      out=ws["att"])
             else:
-                # prefill: q|k|v GEMM, then RoPE + KV append (VALLEY_FUSE_ROPE=1: both in the GEMM's epilogue — bit-identical,
-                # one launch less, measured neutral)
+                # prefill: q|k|v GEMM, then RoPE + KV append (VALLEY_FUSE_ROPE, default auto: both in the GEMM's epilogue where that shape was measured — bit-identical,
+                # one launch less; +0.3 % on c3)
                 ops.gemm_qkv_rope(ws["x"], W["w_qkv"], ws["qkv"], ops.RopeKV(cache.k[li], cache.v[li], self.cos, self.sin, B, S,
                                                                             self.heads, past))
                 ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])

@@ -286,22 +286,26 @@ def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
 # (c3, same box, profiles/r02/r02_ab_rowsplit_rope.txt: q|k|v 355.7 us + rope_kv 27 us vs
 # 373.5 us fused, but the step moved 87.75 -> 88.22 ms, inside the noise) — the epilogue's 16 dependent cos / sin fetches
 # per thread cost what the removed pass over q|k|v saved.  Kept as a tested option (bit-identical to the unfused pair).
-FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "0") == "1"
+# Round 3, behind the LDS-DMA attention kernel: c3 54.2 -> 53.9 ms of prefill with the fused form, twice in a row
+# (profiles/r03/r03_fuse_rope_again.txt) — small, but free.  "auto" (default) fuses exactly the shapes whose fused decision
+# ships in the tuned table (i.e. was measured: the 13B q|k|v at M = 2688); 1 = always (new shapes are tuned online), 0 = never.
+FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "auto")
 
 
 def gemm_qkv_rope(a, w, qkv, rope: "RopeKV"):
     """The q|k|v projection of a prefill with RoPE + KV append fused into its epilogue, through the same dispatch as
     ops.gemm (whole-tile heuristic in "tiles" mode, online tuner otherwise — candidates that cannot host the epilogue,
-    i.e. stream-K and the 192-column tiles, drop out by themselves).  VALLEY_FUSE_ROPE=1 enables it; default: gemm + rope_kv."""
-    if not FUSE_ROPE or qkv.stride(0) % 8 or torch.cuda.is_current_stream_capturing():
+    i.e. stream-K and the 192-column tiles, drop out by themselves).  VALLEY_FUSE_ROPE=auto|0|1, see above."""
+    M, K = a.shape
+    N = w.shape[0]
+    key = _tune_key(M, N, K, EPI_QKV_ROPE, qkv.dtype, False, False, w)
+    fuse = FUSE_ROPE == "1" or (FUSE_ROPE == "auto" and GEMM_MODE == "tuned" and key in _TUNED)
+    if not fuse or qkv.stride(0) % 8 or torch.cuda.is_current_stream_capturing():
         gemm(a, w, out=qkv)
         rope_kv(qkv, rope.kcache, rope.vcache, rope.cos, rope.sin, rope.B, rope.S, rope.heads, rope.past)
         return qkv
-    M, K = a.shape
-    N = w.shape[0]
     if GEMM_MODE != "tuned":
         return gemm_mfma_qkv_rope(a, w, qkv, rope, 0)
-    key = _tune_key(M, N, K, EPI_QKV_ROPE, qkv.dtype, False, False, w)
     choice = _TUNED.get(key)
     if choice is None:
         if _multi_stream():
