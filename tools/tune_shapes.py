@@ -16,7 +16,7 @@ for spec in sys.argv[2].split(";"):
     a = torch.randn((M, K), device=d).to(torch.bfloat16)
     w = (torch.randn((N, K), device=d) * 0.02).to(torch.bfloat16)
     b = torch.randn((N,), device=d) if hb else None
-    key = (M, N, K, ops.EPI_NONE, torch.bfloat16, bool(hb), False)
+    key = ops._tune_key(M, N, K, ops.EPI_NONE, torch.bfloat16, bool(hb), False, None)
     n = 0
     while key not in ops._TUNED and n < 1000:
         ops.gemm(a, w, b)

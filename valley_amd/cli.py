@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from .runtime import HALF
+from . import runtime
 from .valley_model import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_VI_END_TOKEN,
                            DEFAULT_VI_START_TOKEN, DEFAULT_VIDEO_FRAME_TOKEN, ValleyLlamaForCausalLM)
 
@@ -37,6 +37,14 @@ SYSTEM_TURN = " ".join((
 ))
 
 GREEDY = {"do_sample": False, "temperature": 0.2, "max_new_tokens": 1024}
+
+
+
+def entry_dtype():
+    """The dtype the reference's entry points pass to ``from_pretrained`` is ``torch.float16`` (run_valley.py:39,
+    run_valley_llamma_v2.py / run_valley_conv.py alike): the same here — it selects libvalley_hip_f16.so — unless
+    VALLEY_PRECISION or an earlier model already bound this process to a storage type, which then wins."""
+    return runtime.HALF if runtime.half_bound() else torch.float16
 
 
 def init_vision_token(model, tokenizer) -> None:
@@ -79,7 +87,7 @@ def load(model_name: str):
     else:
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(path)
-        model = ValleyLlamaForCausalLM.from_pretrained(path, torch_dtype=HALF)
+        model = ValleyLlamaForCausalLM.from_pretrained(path, torch_dtype=entry_dtype())
     init_vision_token(model, tokenizer)
     return model.to(device).eval(), tokenizer
 
@@ -193,7 +201,7 @@ def conv_inference(args, read_line=input, emit=print):
     random.seed(42)
     device = _require_gpu()
     tokenizer = LlamaTokenizer.from_pretrained(args.model_name)
-    model = ValleyLlamaForCausalLM.from_pretrained(os.path.expanduser(args.model_name), torch_dtype=HALF).to(device)
+    model = ValleyLlamaForCausalLM.from_pretrained(os.path.expanduser(args.model_name), torch_dtype=entry_dtype()).to(device)
     image_token_len = conv_bind_tokens(model, tokenizer)
     use_se = getattr(model.config, "mm_use_im_start_end", False)
     video_path, conv, image_tensor = "", None, None

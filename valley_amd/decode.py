@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .runtime import HALF
+from . import runtime
 from .llama import HipKVCache, HipLlama
 
 
@@ -38,7 +38,7 @@ class DecodeSession:
         self.tok = torch.zeros((B,), dtype=torch.int32, device=d)          # token fed to the next step
         self.pos = torch.zeros((B if per_row_positions else 1,), dtype=torch.int32, device=d)   # on the device: replays need no patching
         self.h = torch.empty((B, llama.H), dtype=torch.float32, device=d)
-        bf = HALF
+        bf = runtime.HALF
         self.x = torch.empty((B, llama.H), dtype=bf, device=d)
         self.qkv = torch.empty((B, 3 * llama.H), dtype=bf, device=d)
         self.att = torch.empty((B, llama.H), dtype=bf, device=d)

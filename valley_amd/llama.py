@@ -19,7 +19,6 @@ import numpy as np
 import torch
 
 from . import ops, runtime
-from .runtime import HALF
 
 
 def _dev(t, device, dtype):
@@ -33,8 +32,8 @@ class HipKVCache:
     (``past_key_values[0][0].shape[-2]``, serve/model_worker.py:381) and ``get_seq_length()``."""
 
     def __init__(self, layers: int, batch: int, heads: int, ctx_max: int, device):
-        self.k = [torch.zeros((batch, heads, ctx_max, 128), dtype=HALF, device=device) for _ in range(layers)]
-        self.v = [torch.zeros((batch, heads, ctx_max, 128), dtype=HALF, device=device) for _ in range(layers)]
+        self.k = [torch.zeros((batch, heads, ctx_max, 128), dtype=runtime.HALF, device=device) for _ in range(layers)]
+        self.v = [torch.zeros((batch, heads, ctx_max, 128), dtype=runtime.HALF, device=device) for _ in range(layers)]
         self.seq_len = 0
         self.ctx_max = ctx_max
         self.batch = batch
@@ -132,7 +131,7 @@ class HipLlama:
 
     def load_state_dict(self, sd: Dict) -> "HipLlama":
         """Reference key names (SURVEY.md §5 weight-loading contract)."""
-        d, bf, f32 = self.device, HALF, torch.float32
+        d, bf, f32 = self.device, runtime.HALF, torch.float32
         self.embed = _dev(sd["model.embed_tokens.weight"], d, bf)
         self.layers = []
         for i in range(self.L):
@@ -153,7 +152,7 @@ class HipLlama:
         return self
 
     def init_random(self, seed: int = 0, std: float = 0.02) -> "HipLlama":
-        d, bf, f32 = self.device, HALF, torch.float32
+        d, bf, f32 = self.device, runtime.HALF, torch.float32
         g = torch.Generator(device=d).manual_seed(seed)
         rn = lambda shape: (torch.randn(shape, generator=g, device=d, dtype=f32) * std).to(bf)  # noqa: E731
         self.embed = rn((self.V, self.H))
@@ -177,7 +176,7 @@ class HipLlama:
         key = (M, runtime.stream_key())                    # concurrent streams never share activations
         ws = self._ws.get(key)
         if ws is None:
-            d, bf = self.device, HALF
+            d, bf = self.device, runtime.HALF
             ws = dict(x=torch.empty((M, self.H), dtype=bf, device=d), qkv=torch.empty((M, 3 * self.H), dtype=bf, device=d),
                       att=torch.empty((M, self.H), dtype=bf, device=d), mlp=torch.empty((M, self.I), dtype=bf, device=d),
                       delta=torch.empty((M, self.H), dtype=bf, device=d), delta2=torch.empty((M, self.H), dtype=bf, device=d))

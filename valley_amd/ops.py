@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import lib as _lib
-from .runtime import HALF
+from . import runtime
 
 EPI_NONE, EPI_QUICK_GELU, EPI_SWIGLU, EPI_RELU, EPI_QKV_ROPE = 0, 1, 2, 3, 4
 OUT_BF16, OUT_F32 = 0, 1
@@ -64,14 +64,14 @@ class PackedWeight:
     write to ``plain`` afterwards."""
 
     def __init__(self, plain: torch.Tensor):
-        _chk(plain, HALF, "weight")
+        _chk(plain, runtime.HALF, "weight")
         N, K = plain.shape
         if K % 64:
             raise ValueError("PackedWeight: K must be a multiple of 64")
         self.plain = plain
         self.shape = plain.shape
         self.device = plain.device
-        self.blocks = torch.empty((K // 64, (N + 63) // 64, 64, 64), dtype=HALF, device=plain.device)
+        self.blocks = torch.empty((K // 64, (N + 63) // 64, 64, 64), dtype=runtime.HALF, device=plain.device)
         rc = _lib.load().vly_pack_weight_bf16(plain.data_ptr(), self.blocks.data_ptr(), N, K, plain.stride(0), _stream())
         _lib.check(rc, "vly_pack_weight_bf16")
 
@@ -80,12 +80,12 @@ def _w_args(w, tile_kernel: bool):
     """-> (tensor whose pointer is passed, ldw) for a plain tensor or a PackedWeight."""
     if isinstance(w, PackedWeight):
         return (w.blocks, LDW_PACKED64) if tile_kernel else (w.plain, w.plain.stride(0))
-    _chk(w, HALF, "w")
+    _chk(w, runtime.HALF, "w")
     return w, w.stride(0)
 
 
 def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra):
-    _chk(a, HALF, "a", contiguous=False)
+    _chk(a, runtime.HALF, "a", contiguous=False)
     # the block-ordered copy serves the tile kernels and the persistent kernel's stream-K form (hints 298 / 299)
     wt, ldw = _w_args(w, fn_name == "vly_gemm_bf16" or (fn_name == "vly_gemm_bf16_streamk" and extra[0] in (298, 299)))
     assert a.dim() == 2 and len(w.shape) == 2 and a.stride(1) == 1 and a.shape[1] == w.shape[1], (a.shape, w.shape)
@@ -132,8 +132,9 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     return out
 
 
-def gemm_mfma(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=None, tile_hint=0):
+def gemm_mfma(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None, tile_hint=0):
     """MFMA tile kernel (batch-invariant): out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual."""
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
     return _gemm_common("vly_gemm_bf16", a, w, bias, residual, epilogue, out_dtype, out, (tile_hint,))
 
 
@@ -194,9 +195,10 @@ def sk_check_polled(device) -> None:
                                   "results of that launch are invalid" % int(poll[0][0]))
 
 
-def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=None, tile_hint=0):
+def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None, tile_hint=0):
     """Persistent stream-K MFMA kernel: same contract as gemm_mfma, balanced over all CUs.  One stream per device
     may use it (sk_stream_allowed)."""
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
     if not sk_stream_allowed(a.device):
         raise _lib.ValleyHipError("vly_gemm_bf16_streamk: the persistent kernel is owned by another HIP stream of this device "
                                   "(two concurrent stream-K grids can starve each other's contributors); use gemm_mfma here")
@@ -207,20 +209,20 @@ def gemm_streamk(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HA
 
 def skinny_ok(M: int, N: int, K: int, epilogue: int, out_dtype, residual) -> bool:
     return 8 < M <= 256 and N % 32 == 0 and K % 128 == 0 and (K < 2048 or K % 512 == 0) and epilogue in (EPI_NONE, EPI_QUICK_GELU, EPI_RELU) and \
-        out_dtype == HALF and residual is None
+        out_dtype == runtime.HALF and residual is None
 
 
 def gemm_skinny(a, w, bias=None, epilogue=EPI_NONE, out=None):
     """Latency-optimised kernel for 8 < M <= 256 rows (vly_gemm_skinny_bf16): the F-row remainders of ops.row_split."""
-    _chk(a, HALF, "a", contiguous=False)
+    _chk(a, runtime.HALF, "a", contiguous=False)
     wt, ldw = _w_args(w, False)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.stride(1) == 1
     if out is None:
-        out = torch.empty((M, N), dtype=HALF, device=a.device)
+        out = torch.empty((M, N), dtype=runtime.HALF, device=a.device)
     else:
-        _chk(out, HALF, "out", contiguous=False)
+        _chk(out, runtime.HALF, "out", contiguous=False)
         assert tuple(out.shape) == (M, N) and out.stride(1) == 1
     if bias is not None:
         _chk(bias, torch.float32, "bias")
@@ -248,11 +250,11 @@ class RopeKV:
 def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
     """vly_gemm_bf16_qkv_rope: qkv[:, :H] = RoPE(a @ Wq^T), kcache / vcache appended with RoPE(a @ Wk^T) / a @ Wv^T —
     bit-identical to gemm + rope_kv (the k / v columns of ``qkv`` are not written)."""
-    _chk(a, HALF, "a", contiguous=False)
+    _chk(a, runtime.HALF, "a", contiguous=False)
     wt, ldw = _w_args(w, True)
-    _chk(qkv, HALF, "qkv", contiguous=False)
-    _chk(rope.kcache, HALF, "kcache")
-    _chk(rope.vcache, HALF, "vcache")
+    _chk(qkv, runtime.HALF, "qkv", contiguous=False)
+    _chk(rope.kcache, runtime.HALF, "kcache")
+    _chk(rope.vcache, runtime.HALF, "vcache")
     _chk(rope.cos, torch.float32, "cos")
     _chk(rope.sin, torch.float32, "sin")
     M, K = a.shape
@@ -314,14 +316,16 @@ def gemm_qkv_rope(a, w, qkv, rope: "RopeKV"):
     return gemm_mfma_qkv_rope(a, w, qkv, rope, choice[1])
 
 
-def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=None):
+def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None):
     """Weight-streaming kernel for M <= 8 rows (decode)."""
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
 
-def gemv_rmsnorm(h, gamma, eps, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=None):
+def gemv_rmsnorm(h, gamma, eps, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None):
     """vly_gemv_rmsnorm_bf16: gemv(rmsnorm(h, gamma, eps), w, ...) in one launch (M <= 2 rows, 2048 <= K <= 6144) — bit-identical
     to the pair; the decode step's norm -> projection seams."""
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
     _chk(h, torch.float32, "h", contiguous=False)
     _chk(gamma, torch.float32, "gamma")
     wt, ldw = _w_args(w, False)
@@ -364,7 +368,9 @@ def gemv_rmsnorm_ok(M: int, K: int) -> bool:
 GEMM_MODE = os.environ.get("VALLEY_GEMM_MODE", "tuned")
 _TUNED = {}
 _TUNE_CACHE = os.environ.get("VALLEY_TUNE_CACHE", "")        # JSON file: tuned choices survive the process
-_DT = {"torch.bfloat16": HALF, "torch.float16": HALF, "torch.float32": torch.float32}   # the shipped table serves both storage types
+# the 16-bit storage type appears in tuner keys as "half": the shipped table serves both libraries, and the type may still be
+# chosen (runtime.request_half) after this module was imported
+_DT = {"torch.bfloat16": "half", "torch.float16": "half", "half": "half", "torch.float32": torch.float32}
 
 
 def load_tune_cache(path: str) -> int:
@@ -431,7 +437,7 @@ def _multi_stream() -> bool:
 
 def _tune_key(M, N, K, epi, dtype, has_bias, has_res, w):
     """Tuner key; weights in the block layout are tuned on their own (8th element "p64")."""
-    k = (M, N, K, epi, dtype, has_bias, has_res)
+    k = (M, N, K, epi, torch.float32 if dtype == torch.float32 else "half", has_bias, has_res)
     return k + ("p64",) if isinstance(w, PackedWeight) else k
 
 
@@ -442,10 +448,10 @@ def tuning_pending() -> int:
 
 def gemm_mfma_splitk2(a, w, bias, out, out2, tile_hint=0):
     """One launch, two bf16 partial products: out = a[:, :K/2] @ w[:, :K/2]^T + bias, out2 = the other half of K."""
-    _chk(a, HALF, "a", contiguous=False)
+    _chk(a, runtime.HALF, "a", contiguous=False)
     wt, ldw = _w_args(w, True)
-    _chk(out, HALF, "out", contiguous=False)
-    _chk(out2, HALF, "out2", contiguous=False)
+    _chk(out, runtime.HALF, "out", contiguous=False)
+    _chk(out2, runtime.HALF, "out2", contiguous=False)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and tuple(out.shape) == (M, N) == tuple(out2.shape) and out.stride() == out2.stride()
@@ -473,7 +479,7 @@ def gemm2(a, w, out, out2, bias=None) -> int:
     """out (+ out2) = a @ w^T (+ bias) for a consumer that adds two bf16 partials (add_norm(..., delta2=)): the tuner
     may pick a split-K-by-two launch (returns 2: both buffers hold partial sums) or any ordinary kernel (returns 1:
     out holds the product, out2 is untouched).  For projections with fewer output tiles than CUs."""
-    _chk(a, HALF, "a", contiguous=False)
+    _chk(a, runtime.HALF, "a", contiguous=False)
     M = a.shape[0]
     if M <= 8 or GEMM_MODE in ("tiles", "streamk") or torch.cuda.is_current_stream_capturing():
         gemm(a, w, bias, out=out)
@@ -528,7 +534,7 @@ def gemm_split(a, w, bias=None, epilogue=EPI_NONE, out=None):
     if Mm == M:
         return gemm(a, w, bias, epilogue=epilogue, out=out)
     if out is None:
-        out = torch.empty((M, w.shape[0] // 2 if epilogue == EPI_SWIGLU else w.shape[0]), dtype=HALF, device=a.device)
+        out = torch.empty((M, w.shape[0] // 2 if epilogue == EPI_SWIGLU else w.shape[0]), dtype=runtime.HALF, device=a.device)
     gemm(a[:Mm], w, bias, epilogue=epilogue, out=out[:Mm])
     _gemm_rem(a[Mm:], w, bias, epilogue, out[Mm:])
     return out
@@ -669,10 +675,11 @@ def _tune(key, a, w, bias, residual, epilogue, out):
     return best
 
 
-def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=HALF, out=None, tile_hint=0):
+def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None, tile_hint=0):
     """Dispatch on M: <= 8 rows stream the weights (HBM-bound); otherwise an MFMA kernel chosen by
     GEMM_MODE (see above)."""
-    _chk(a, HALF, "a", contiguous=False)
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
+    _chk(a, runtime.HALF, "a", contiguous=False)
     M = a.shape[0]
     if M <= 8:
         return gemv(a, w, bias, residual, epilogue, out_dtype, out)
@@ -717,7 +724,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
               out: Optional[torch.Tensor] = None):
     _chk(x, torch.float32, "x")
     M, D = x.shape
-    y16 = out if out is not None else torch.empty((M, D), dtype=HALF, device=x.device)
+    y16 = out if out is not None else torch.empty((M, D), dtype=runtime.HALF, device=x.device)
     y32 = torch.empty_like(x) if want_f32 else None
     rc = _lib.load().vly_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y16.data_ptr(), _ptr(y32), M, D, eps,
                                    _stream())
@@ -728,7 +735,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(x, torch.float32, "x")
     M, D = x.shape
-    y = out if out is not None else torch.empty((M, D), dtype=HALF, device=x.device)
+    y = out if out is not None else torch.empty((M, D), dtype=runtime.HALF, device=x.device)
     rc = _lib.load().vly_rmsnorm(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), M, D, eps, _stream())
     _lib.check(rc, "vly_rmsnorm")
     return y
@@ -739,15 +746,15 @@ def add_norm(h: torch.Tensor, delta: torch.Tensor, gamma: Optional[torch.Tensor]
     """h (fp32, in place) += delta (bf16) [+ delta2: the second split-K partial of gemm2]; returns norm(h) as bf16
     (None when gamma is None: add only)."""
     _chk(h, torch.float32, "h")
-    _chk(delta, HALF, "delta")
+    _chk(delta, runtime.HALF, "delta")
     M, D = h.shape
     assert tuple(delta.shape) == (M, D)
     y = None
     if gamma is not None:
-        y = out if out is not None else torch.empty((M, D), dtype=HALF, device=h.device)
+        y = out if out is not None else torch.empty((M, D), dtype=runtime.HALF, device=h.device)
     L = _lib.load()
     if delta2 is not None:
-        _chk(delta2, HALF, "delta2")
+        _chk(delta2, runtime.HALF, "delta2")
         assert tuple(delta2.shape) == (M, D)
         if rms:
             rc = L.vly_add2_rmsnorm(h.data_ptr(), delta.data_ptr(), delta2.data_ptr(), _ptr(gamma), _ptr(y), M, D, eps, _stream())
@@ -766,11 +773,11 @@ def add_norm(h: torch.Tensor, delta: torch.Tensor, gamma: Optional[torch.Tensor]
 
 def patchify(images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[F,3,224,224] bf16 -> [F*256, 640] bf16."""
-    _chk(images, HALF, "images")
+    _chk(images, runtime.HALF, "images")
     F = images.shape[0]
     assert tuple(images.shape[1:]) == (3, 224, 224), images.shape
     if out is None:
-        out = torch.empty((F * 256, 640), dtype=HALF, device=images.device)
+        out = torch.empty((F * 256, 640), dtype=runtime.HALF, device=images.device)
     rc = _lib.load().vly_patchify(images.data_ptr(), out.data_ptr(), F, _stream())
     _lib.check(rc, "vly_patchify")
     return out
@@ -787,10 +794,10 @@ def vit_embed_ln(patch_out: torch.Tensor, cls, pos, gamma, beta, F: int, eps: fl
 
 
 def vit_attention(qkv: torch.Tensor, F: int, out=None) -> torch.Tensor:
-    _chk(qkv, HALF, "qkv")
+    _chk(qkv, runtime.HALF, "qkv")
     assert tuple(qkv.shape) == (F * 257, 3072), qkv.shape
     if out is None:
-        out = torch.empty((F * 257, 1024), dtype=HALF, device=qkv.device)
+        out = torch.empty((F * 257, 1024), dtype=runtime.HALF, device=qkv.device)
     rc = _lib.load().vly_vit_attention(qkv.data_ptr(), out.data_ptr(), F, _stream())
     _lib.check(rc, "vly_vit_attention")
     return out
@@ -813,7 +820,7 @@ def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN, scor
     _chk(feats, torch.float32, "feats")
     W = feats.shape[-1]
     assert feats.numel() == B * T * 257 * W
-    out = torch.empty((B, 256 + T, W), dtype=HALF, device=feats.device)
+    out = torch.empty((B, 256 + T, W), dtype=runtime.HALF, device=feats.device)
     rc = _lib.load().vly_pool_tokens(feats.data_ptr(), out.data_ptr(), B, T, W, mode, _ptr(scores), _stream())
     _lib.check(rc, "vly_pool_tokens")
     return out
@@ -821,10 +828,10 @@ def pool_tokens(feats: torch.Tensor, B: int, T: int, mode: int = POOL_MEAN, scor
 
 def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[torch.Tensor], out=None) -> torch.Tensor:
     _chk(row_map, torch.int32, "row_map")
-    _chk(embed, HALF, "embed")
+    _chk(embed, runtime.HALF, "embed")
     R, H = row_map.numel(), embed.shape[1]
     if visual is not None:
-        _chk(visual, HALF, "visual")
+        _chk(visual, runtime.HALF, "visual")
     if out is None:
         out = torch.empty((R, H), dtype=torch.float32, device=embed.device)
     rc = _lib.load().vly_embed_splice(row_map.data_ptr(), embed.data_ptr(), _ptr(visual), out.data_ptr(), R, H, _stream())
@@ -834,9 +841,9 @@ def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[to
 
 def rope_kv(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
             B: int, S: int, heads: int, past_len: int, past_dev: Optional[torch.Tensor] = None):
-    _chk(qkv, HALF, "qkv")
-    _chk(kcache, HALF, "kcache")
-    _chk(vcache, HALF, "vcache")
+    _chk(qkv, runtime.HALF, "qkv")
+    _chk(kcache, runtime.HALF, "kcache")
+    _chk(vcache, runtime.HALF, "vcache")
     ctx_max = kcache.shape[2]
     assert tuple(kcache.shape) == (B, heads, ctx_max, 128) and vcache.shape == kcache.shape
     assert cos.shape[0] >= past_len + S and cos.shape[1] == 64 and cos.dtype == torch.float32 and cos.is_contiguous()
@@ -847,7 +854,7 @@ def rope_kv(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: 
 
 def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, key_valid: Optional[torch.Tensor],
                     B: int, S: int, heads: int, past_len: int, out=None, past_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk(qkv, HALF, "qkv")
+    _chk(qkv, runtime.HALF, "qkv")
     ctx_max = kcache.shape[2]
     kv_stride = 0
     if key_valid is not None:
@@ -855,7 +862,7 @@ def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
         assert key_valid.shape[0] == B and key_valid.shape[1] >= past_len + S
         kv_stride = key_valid.stride(0)
     if out is None:
-        out = torch.empty((B * S, heads * 128), dtype=HALF, device=qkv.device)
+        out = torch.empty((B * S, heads * 128), dtype=runtime.HALF, device=qkv.device)
     rc = _lib.load().vly_llama_attention(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), _ptr(key_valid), kv_stride,
                                          out.data_ptr(), B, S, heads, past_len, _ptr(past_dev), ctx_max, _stream())
     _lib.check(rc, "vly_llama_attention")
@@ -867,7 +874,7 @@ def decode_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tens
                      past_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One new token per sequence: RoPE + KV append + attention over 0..past_len in one launch
     (= rope_kv followed by llama_attention with S = 1; qkv holds the unrotated q|k|v and is not modified)."""
-    _chk(qkv, HALF, "qkv")
+    _chk(qkv, runtime.HALF, "qkv")
     _chk(cos, torch.float32, "cos")
     _chk(sin, torch.float32, "sin")
     ctx_max = kcache.shape[2]
@@ -877,7 +884,7 @@ def decode_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tens
         assert key_valid.shape[0] == B and key_valid.shape[1] >= past_len + 1
         kv_stride = key_valid.stride(0)
     if out is None:
-        out = torch.empty((B, heads * 128), dtype=HALF, device=qkv.device)
+        out = torch.empty((B, heads * 128), dtype=runtime.HALF, device=qkv.device)
     rc = _lib.load().vly_decode_attention(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                                           _ptr(key_valid), kv_stride, out.data_ptr(), B, heads, past_len, _ptr(past_dev),
                                           ctx_max, _stream())
@@ -888,7 +895,7 @@ def decode_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tens
 def decode_attention_rows(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                           key_valid: Optional[torch.Tensor], B: int, heads: int, pos_rows: torch.Tensor, out=None) -> torch.Tensor:
     """decode_attention for a batch of independent sequences: row b sits at position pos_rows[b] (device int32 [B])."""
-    _chk(qkv, HALF, "qkv")
+    _chk(qkv, runtime.HALF, "qkv")
     _chk(pos_rows, torch.int32, "pos_rows")
     assert pos_rows.numel() == B
     ctx_max = kcache.shape[2]
@@ -903,7 +910,7 @@ def decode_attention_rows(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch
         assert key_valid.shape[0] == B and key_valid.shape[1] >= ctx_max
         kv_stride = key_valid.stride(0)
     if out is None:
-        out = torch.empty((B, heads * 128), dtype=HALF, device=qkv.device)
+        out = torch.empty((B, heads * 128), dtype=runtime.HALF, device=qkv.device)
     rc = _lib.load().vly_decode_attention_rows(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                                                _ptr(key_valid), kv_stride, out.data_ptr(), B, heads, pos_rows.data_ptr(), ctx_max,
                                                _stream())
@@ -924,7 +931,7 @@ def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torc
                            past_dev: Optional[torch.Tensor] = None, per_row: bool = False) -> torch.Tensor:
     """vly_decode_attention_split: decode_attention (or decode_attention_rows with ``per_row``) with every head split over
     DECODE_SPLITS workgroups; leaves the per-split (max, sum, P·V) in ``partials`` for gemv_attnmerge."""
-    _chk(qkv, HALF, "qkv")
+    _chk(qkv, runtime.HALF, "qkv")
     _chk(cos, torch.float32, "cos")
     _chk(sin, torch.float32, "sin")
     _chk(partials, torch.float32, "partials")
@@ -948,8 +955,9 @@ def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torc
     return partials
 
 
-def gemv_attnmerge(partials: torch.Tensor, w, bias=None, residual=None, out_dtype=HALF, out=None):
+def gemv_attnmerge(partials: torch.Tensor, w, bias=None, residual=None, out_dtype=None, out=None):
     """vly_gemv_attnmerge_bf16: the o projection over the merge of decode_attention_split's partials (M = B <= 2 rows)."""
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
     _chk(partials, torch.float32, "partials")
     B, heads = partials.shape[0], partials.shape[1]
     assert tuple(partials.shape) == (B, heads, DECODE_SPLITS, 132)
@@ -986,7 +994,7 @@ def argmax(x: torch.Tensor, out=None) -> torch.Tensor:
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     _chk(x, torch.float32, "x")
-    y = torch.empty(x.shape, dtype=HALF, device=x.device)
+    y = torch.empty(x.shape, dtype=runtime.HALF, device=x.device)
     rc = _lib.load().vly_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream())
     _lib.check(rc, "vly_cast_f32_bf16")
     return y
@@ -1004,8 +1012,8 @@ def delta_prep(feats: torch.Tensor, pos: torch.Tensor, B: int, T: int):
     _chk(pos, torch.float32, "pos")
     H, d = feats.shape[-1], feats.device
     assert feats.numel() == B * T * 257 * H and pos.shape[0] >= T and pos.shape[1] == H
-    x_all = torch.empty((B * 256 * T, H), dtype=HALF, device=d)
-    x16 = torch.empty((B * 256, H), dtype=HALF, device=d)
+    x_all = torch.empty((B * 256 * T, H), dtype=runtime.HALF, device=d)
+    x16 = torch.empty((B * 256, H), dtype=runtime.HALF, device=d)
     x32 = torch.empty((B * 256, H), dtype=torch.float32, device=d)
     mean = torch.empty((B * 256, H), dtype=torch.float32, device=d)
     rc = _lib.load().vly_delta_prep(feats.data_ptr(), pos.data_ptr(), x_all.data_ptr(), x16.data_ptr(), x32.data_ptr(),
@@ -1015,8 +1023,8 @@ def delta_prep(feats: torch.Tensor, pos: torch.Tensor, B: int, T: int):
 
 
 def delta_attention(q: torch.Tensor, kv: torch.Tensor, T: int, nhead: int) -> torch.Tensor:
-    _chk(q, HALF, "q")
-    _chk(kv, HALF, "kv")
+    _chk(q, runtime.HALF, "q")
+    _chk(kv, runtime.HALF, "kv")
     nseq, H = q.shape
     assert tuple(kv.shape) == (nseq * T, 2 * H)
     out = torch.empty_like(q)
@@ -1029,7 +1037,7 @@ def delta_finish(delta: torch.Tensor, mean: torch.Tensor, feats: torch.Tensor, B
     _chk(delta, torch.float32, "delta")
     _chk(mean, torch.float32, "mean")
     H = delta.shape[-1]
-    out = torch.empty((B, 256 + T, H), dtype=HALF, device=delta.device)
+    out = torch.empty((B, 256 + T, H), dtype=runtime.HALF, device=delta.device)
     rc = _lib.load().vly_delta_finish(delta.data_ptr(), mean.data_ptr(), feats.data_ptr(), out.data_ptr(), B, T, H, _stream())
     _lib.check(rc, "vly_delta_finish")
     return out

@@ -21,7 +21,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-from .runtime import HALF
+from . import runtime
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -80,7 +80,7 @@ def encode_clips_dp(encode_pool: Callable[[list], Tuple[torch.Tensor, List[int]]
             dist.all_reduce(wt, op=dist.ReduceOp.MAX, group=group)
             width = int(wt.item())
         if local is None:
-            local = torch.empty((0, width), dtype=HALF, device=device)
+            local = torch.empty((0, width), dtype=runtime.HALF, device=device)
     return all_gather_rows(local, rows, group), Ts
 
 

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .runtime import HALF
+from . import runtime
 from .ops import _chk, _stream
 
 PRECISION_BITS = 22
@@ -62,9 +62,10 @@ def resample_tables(in_size: int, out_size: int):
     return bounds, taps
 
 
-def preprocess_frames_gpu(frames_u8: torch.Tensor, out_dtype=HALF, scale_size: int = 256, crop: int = 224) -> torch.Tensor:
+def preprocess_frames_gpu(frames_u8: torch.Tensor, out_dtype=None, scale_size: int = 256, crop: int = 224) -> torch.Tensor:
     """frames uint8 [T,H,W,3] on the device -> [T,3,224,224] (the hot path's frame layout; the reference's
     ``load_video`` returns the same values as [3,T,224,224] fp32)."""
+    out_dtype = runtime.HALF if out_dtype is None else out_dtype
     _chk(frames_u8, torch.uint8, "frames")
     T, H, Wd, C = frames_u8.shape
     assert C == 3

@@ -22,7 +22,6 @@ import numpy as np
 import torch
 
 from . import ops, ops_f32, runtime
-from .runtime import HALF
 from .llama import HipKVCache, HipLlama
 from .precise import F32KVCache, PreciseCLIPVisionTower, PreciseLlama
 from .splice import build_row_map
@@ -71,6 +70,38 @@ def default_precision() -> str:
     return runtime.PRECISION
 
 
+def resolve_precision(config) -> str:
+    """The precision a model object is built in: ``config.valley_precision`` ("bf16" | "fp16" | "fp32") when the config names
+    one, else the process default.  A 16-bit name is a REQUEST for that storage type (runtime.request_half): it selects the
+    matching library while the choice is open and raises when the process is already bound to the other one — a config that
+    says fp16 never runs in bf16 silently."""
+    p = getattr(config, "valley_precision", None)
+    if p is None:
+        return default_precision()
+    p = str(p).lower()
+    if p not in ("bf16", "fp16", "fp32"):
+        raise ValueError(f"valley_precision must be bf16, fp16 or fp32, got {p!r}")
+    if p != "fp32":
+        runtime.request_half(p, f"ValleyConfig.valley_precision={p!r}")
+    return p
+
+
+def apply_torch_dtype(config, torch_dtype, who: str) -> None:
+    """``from_pretrained(..., torch_dtype=torch.float16)`` of the reference (run_valley.py:39, serve/model_worker.py:61,79):
+    the caller's dtype decides the precision the model is built in — fp16 / bf16 select the library with that storage type
+    (or raise when the process already holds the other one), fp32 the validation engines."""
+    if torch_dtype is None or torch_dtype == "auto":
+        return
+    if isinstance(torch_dtype, str):
+        torch_dtype = getattr(torch, torch_dtype.replace("torch.", ""))
+    name = {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "fp32"}.get(torch_dtype)
+    if name is None:
+        raise ValueError(f"{who}: unsupported dtype (float16, bfloat16 or float32)")
+    if name != "fp32":
+        runtime.request_half(torch_dtype, who)
+    config.valley_precision = name
+
+
 def build_vision_tower(config_or_name=None, device="cuda:0", state_dict: Optional[Dict] = None, precision: Optional[str] = None,
                        **kw) -> HipCLIPVisionTower:
     """Factory named by the north star (absent in the reference snapshot).  Accepts a
@@ -106,7 +137,7 @@ class HipLinear:
         if self.weight.dtype == torch.float32:               # fp32 "precise" mode
             y = ops_f32.gemm(x.reshape(-1, shp[-1]).to(torch.float32).contiguous(), self.weight, self.bias)
         else:
-            y = ops.gemm(x.reshape(-1, shp[-1]).to(HALF).contiguous(), self.weight, self.bias)
+            y = ops.gemm(x.reshape(-1, shp[-1]).to(runtime.HALF).contiguous(), self.weight, self.bias)
         return y.view(*shp[:-1], self.out_features)
 
 
@@ -120,8 +151,8 @@ class ValleyLlamaModel:
         self.training = False
         self.patch_pooling_method = "mean"                   # :27
         c = config
-        self.precision = getattr(config, "valley_precision", None) or default_precision()
-        self.wdtype = torch.float32 if self.precision == "fp32" else HALF      # dtype of GEMM weights / activations
+        self.precision = resolve_precision(config)
+        self.wdtype = torch.float32 if self.precision == "fp32" else runtime.HALF      # dtype of GEMM weights / activations
         engine = PreciseLlama if self.precision == "fp32" else HipLlama
         self.llama = engine(c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers,
                             c.vocab_size, c.rms_norm_eps, getattr(c, "rope_theta", None) or _rope_theta(c),
@@ -372,7 +403,8 @@ class ValleyLlamaForCausalLM:
 
     def __init__(self, config, device="cuda:0"):
         from . import lib
-        lib.load()                                           # fail loudly right here if the HIP library is absent
+        resolve_precision(config)                            # a 16-bit type named by the config picks the library ...
+        lib.load()                                           # ... which is loaded here: fail loudly if it is absent
         self.config = config
         self.device = torch.device(device)
         self.model = ValleyLlamaModel(config, device=device)
@@ -386,22 +418,49 @@ class ValleyLlamaForCausalLM:
 
     def to(self, *args, **kwargs):
         """``model.to(device)`` / ``.to(dtype)`` of the entry points (run_valley.py:39): the engines were built on their
-        device in their storage dtype, so a matching request is a no-op — and a request for ANOTHER device raises instead
-        of silently answering from the old one."""
-        want = kwargs.get("device")
+        device in their storage dtype, so a matching request is a no-op — a request for ANOTHER device or ANOTHER dtype
+        raises instead of silently answering from what was built."""
+        want, dt = kwargs.get("device"), kwargs.get("dtype")
         for a in args:
             if isinstance(a, (str, torch.device, int)):
                 want = a
+            elif isinstance(a, torch.dtype):
+                dt = a
         if want is not None:
             want = torch.device("cuda", want) if isinstance(want, int) else torch.device(want)
             have = self.device
             if want.type != have.type or (want.index is not None and have.index is not None and want.index != have.index):
                 raise ValueError(f"this model was built on {have}; build it with device={want!s} instead of moving it "
                                  f"(from_pretrained(..., device=...) / ValleyLlamaForCausalLM(config, device=...))")
+        if dt is not None:
+            self._require_dtype(dt, f".to({dt})")
         return self
 
+    def _require_dtype(self, dt, who: str):
+        have = self.model.wdtype
+        if dt == have or not dt.is_floating_point:
+            return
+        raise ValueError(f"{who}: this model stores its weights and activations in {have} — the storage type is fixed when "
+                         f"the model is built and is not converted afterwards.  Ask for it up front: "
+                         f"from_pretrained(..., torch_dtype={dt}) / ValleyConfig.valley_precision / VALLEY_PRECISION")
+
     def half(self):
-        return self                                      # storage dtype is fixed at construction (VALLEY_PRECISION)
+        """``model.half()`` = ``.to(torch.float16)`` (valley_model.py:430 does it to the frames): a no-op on an fp16 model, an
+        error on a bf16 / fp32 one."""
+        self._require_dtype(torch.float16, ".half()")
+        return self
+
+    def bfloat16(self):
+        self._require_dtype(torch.bfloat16, ".bfloat16()")
+        return self
+
+    def float(self):
+        self._require_dtype(torch.float32, ".float()")
+        return self
+
+    @property
+    def dtype(self):
+        return self.model.wdtype
 
     @property
     def lm_head(self):
@@ -421,7 +480,7 @@ class ValleyLlamaForCausalLM:
                 bias=_dev(sd["model.pooling_layer.bias"], self.device, torch.float32).reshape(-1))
         pfx = "model.transformer_delta_encoder.layers.0."
         if pfx + "self_attn.in_proj_weight" in sd:            # v3 temporal transformer (valley_model.py:45-52)
-            d, bf, f32 = self.device, HALF, torch.float32
+            d, bf, f32 = self.device, runtime.HALF, torch.float32
             H = self.config.hidden_size
             win, bin_ = _dev(sd[pfx + "self_attn.in_proj_weight"], d, bf), _dev(sd[pfx + "self_attn.in_proj_bias"], d, f32)
             self.model.delta_encoder = dict(
@@ -448,6 +507,7 @@ class ValleyLlamaForCausalLM:
         from .checkpoint import load_valley_checkpoint
         config, sd = load_valley_checkpoint(path, ValleyConfig)
         config.mm_vision_tower_name = getattr(config, "mm_vision_tower", None)
+        apply_torch_dtype(config, torch_dtype, "from_pretrained(torch_dtype=%s)" % torch_dtype)
         return cls.from_state_dict(config, sd, device=device)
 
     @classmethod
