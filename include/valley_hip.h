@@ -174,7 +174,8 @@ int vly_vit_embed_ln(const float *patch_out_f32, const float *cls, const float *
 
 /* ViT self-attention, non-causal, no mask, 16 heads x 64, N = 257 tokens per frame:
  *   qkv bf16 [F*257, 3072] (q | k | v, biases already added) -> out bf16 [F*257, 1024].
- *   softmax in fp32, scale 64^-0.5.  hf:clip/modeling_clip.py:258-277, 317-330. */
+ *   softmax in fp32, scale 64^-0.5.  qkv and out 16-byte aligned (16-byte loads and stores).
+ *   hf:clip/modeling_clip.py:258-277, 317-330. */
 int vly_vit_attention(const void *qkv_bf16, void *out_bf16, int F, void *stream);
 
 /* Temporal pooling + per-frame CLS pick for B clips of T frames:
@@ -284,7 +285,8 @@ int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *
  *   H the fp32 residual stream [M, K] (row stride ldh), M <= 2, 2048 <= K <= 6144.  Replaces the pairs
  *   input_layernorm -> q|k|v, post_attention_layernorm -> gate|up and norm -> lm_head of a decode step
  *   (HF LlamaDecoderLayer.forward / LlamaModel.norm + lm_head behind serve/model_worker.py:380-387): two launches and two
- *   kernel boundaries per layer less.  Bit-identical to vly_rmsnorm followed by vly_gemv_bf16. */
+ *   kernel boundaries per layer less.  Bit-identical to vly_rmsnorm followed by vly_gemv_bf16.  C must not overlap H
+ *   (-22): every workgroup re-reads the H row for the norm while others write C; `residual` may be any other buffer. */
 int vly_gemv_rmsnorm_bf16(const float *H, const float *gamma, float eps, const void *W, const float *bias,
                           const float *residual, void *C, int M, int N, int K, int ldh, int ldw, int ldc, int ldr,
                           int epilogue, int out_dtype, void *stream);

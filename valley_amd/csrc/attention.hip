@@ -1221,7 +1221,9 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
         for (int u = 0; u < 16; ++u) {
             const int jl = kg + 16 * u;
             const float pj = sc[jl];
-            if (c0 + jl == pos) {
+            // only the OWNER filled vnew: in another split the new position can fall into the padding of a 256-key pass
+            // (kv_len = 337: split 1 covers [128, 256), c0 + jl reaches 336), where pj = 0 but 0 x stale LDS may be NaN
+            if (owner && c0 + jl == pos) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = fmaf(pj, vnew[8 * dc + i], o[i]);
             } else {
@@ -1249,7 +1251,8 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
 }  // namespace
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
-    if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { vly_set_error("vly_vit_attention: bad args F=%d", F); return -22; }
+    // (out: the kernels store 16 bytes per lane since round 3)
+    if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) { vly_set_error("vly_vit_attention: bad args F=%d (qkv and out 16-byte aligned)", F); return -22; }
     // VLY_VIT_ATTN=4 launches vit_attn4_kernel (persistent, LDS-DMA staged; measured 2 % faster at >= 128 frames, equal at 32)
     static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 1;
     if (ver == 4) {

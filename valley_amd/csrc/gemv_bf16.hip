@@ -433,6 +433,15 @@ extern "C" int vly_gemv_rmsnorm_bf16(const float* H, const float* gamma, float e
                       ldh, ldw);
         return -22;
     }
+    {   // no aliasing of the output with H: every workgroup re-reads the whole H row for its norm while others write C
+        const char *h0 = (const char*)H, *h1 = h0 + ((size_t)(M - 1) * ldh + K) * 4;
+        const int No = epilogue == VLY_EPI_SWIGLU ? N / 2 : N;
+        const char *c0 = (const char*)C, *c1 = c0 + ((size_t)(M - 1) * ldc + No) * (out_dtype == VLY_OUT_F32 ? 4 : 2);
+        if (c0 < h1 && h0 < c1) {
+            vly_set_error("vly_gemv_rmsnorm_bf16: C overlaps H (the norm re-reads H while C is written: not an in-place operation)");
+            return -22;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (M == 1) return launch_norm_mr<1, 0>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st, "vly_gemv_rmsnorm_bf16");
     return launch_norm_mr<2, 0>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st, "vly_gemv_rmsnorm_bf16");

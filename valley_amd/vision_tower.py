@@ -286,7 +286,10 @@ class HipCLIPVisionTower:
             states = [h.clone()] if keep_all else None
             Mm = ops.row_split(F * 257)
             want2 = (F * 257 < 32768) if TWO_STREAM is None else TWO_STREAM
-            two = want2 and Mm < F * 257 and not keep_all and not torch.cuda.is_current_stream_capturing()
+            # (single-stream while the online tuner still times main-stream kernels: a side-stream kernel beside a trial would
+            # pollute its timing, and the side stream's direct kernel calls are invisible to ops._multi_stream — ADVICE r3)
+            two = (want2 and Mm < F * 257 and not keep_all and not torch.cuda.is_current_stream_capturing()
+                   and not (ops.GEMM_MODE == "tuned" and ops.tuning_pending()))
             side = self._side_stream() if two else None
             for li, L in enumerate(self.layers[:nl]):
                 last = li == nl - 1
