@@ -224,6 +224,10 @@ ALSO = {
     "c2": (["--config", "c2", "--steps", "10", "--warmup", "3"], "configs[1]"),
     "c4_n1": (["--config", "c4", "--steps", "5", "--warmup", "2"], "configs[3], per-GPU shape at N = 1"),
     "c5_decode": (["--config", "c5", "--decode", "256", "--warmup", "8"], "configs[4]"),
+    # the headline workload on libvalley_hip_f16.so: IEEE fp16 storage is the reference's own inference dtype
+    # (valley/inference/run_valley.py:39 `torch_dtype=torch.float16`); the child is told through VALLEY_PRECISION
+    "c3_fp16": (["--config", "c3", "--steps", "10", "--warmup", "3"], "configs[2] at the reference's inference dtype (fp16 storage)",
+                {"VALLEY_PRECISION": "fp16"}),
 }
 
 
@@ -234,12 +238,13 @@ def run_also(names, pack_weights):
     import subprocess
     out = {}
     for name in names:
-        extra, what = ALSO[name]
+        extra, what = ALSO[name][:2]
+        env = dict(os.environ, **(ALSO[name][2] if len(ALSO[name]) > 2 else {}))
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *extra, "--no-cpu-baseline", "--traffic", "none", "--also", "none",
                "--pack-weights", str(pack_weights)]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             line = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 out[name] = {"error": f"rc={r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
@@ -285,7 +290,8 @@ def main():
     ap.add_argument("--also", default="auto",
                     help="extra workloads measured after the timed region, each in a child run of this script, and attached to the "
                          "line under `also` (N = 1 only): comma list of c2 (configs[1]), c4 (configs[3]'s per-GPU shape at N = 1), "
-                         "decode (configs[4]: 13B, 256 tokens, hipGraph step); 'auto' = all three for the default c3 run, 'none' = off")
+                         "decode (configs[4]: 13B, 256 tokens, hipGraph step), c3_fp16 (the headline workload on the fp16 library); "
+                         "'auto' = all four for the default c3 run, 'none' = off")
     args = ap.parse_args()
     os.environ["VALLEY_PACK_WEIGHTS"] = str(args.pack_weights)      # read by the engines when they load their weights
 
@@ -484,6 +490,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    vit_enc_ms_max = 0.0
+    if world > 1:
+        # encode stage of THIS rank without its all-gather (e0 -> e1 minus g0 -> g1), MAX over ranks
+        mine = (sum(a.elapsed_time(b) for a, b, _ in stage_events) - sum(a.elapsed_time(b) for a, b, _ in gather_events)) / max(1, len(stage_events))
+        t = torch.tensor([mine], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vit_enc_ms_max = float(t.item())
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         frames_total = B * T * world
@@ -566,12 +579,22 @@ def main():
                               "allgather_us_per_step": round(sum(a.elapsed_time(b) for a, b, _ in gather_events) / max(1, len(gather_events)) * 1e3, 1),
                               "allgather_bytes_per_rank": gather_events[0][2] if gather_events else None,
                               "allgather_calls": len(gather_events)}
+            # the north star's ">= 6x frame-encode throughput at 8 GPUs vs 1" read off this one line, whatever the prefill mode:
+            # aggregate encode rate = all ranks' frames / the SLOWEST rank's encode stage (its all-gather excluded), and what the
+            # collective costs the step
+            ag_ms = result["dist"]["allgather_us_per_step"] * 1e-3
+            result["dist"].update({
+                "vit_ms_max_over_ranks": round(vit_enc_ms_max, 3),
+                "vit_frames_per_s_all_gpus": round(frames_total / (vit_enc_ms_max * 1e-3), 1),
+                "vit_frames_per_s_per_gpu_min": round(B * T / (vit_enc_ms_max * 1e-3), 1),
+                "allgather_share_of_step": round(ag_ms / ms_step, 5),
+                "compare_with": "stages.vit_frames_per_s_per_gpu of the N = 1 line (same per-GPU workload: weak scaling)"})
         also = [] if (args.also == "none" or world > 1) else \
             (list(ALSO) if args.config == "c3" else []) if args.also == "auto" else [a for a in args.also.split(",") if a]
         also = [{"c4": "c4_n1", "decode": "c5_decode"}.get(a, a) for a in also]
         bad = [a for a in also if a not in ALSO]
         if bad:
-            raise SystemExit(f"--also: unknown workload(s) {bad}; choose from c2, c4, decode")
+            raise SystemExit(f"--also: unknown workload(s) {bad}; choose from c2, c4, decode, c3_fp16")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline()

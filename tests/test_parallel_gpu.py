@@ -41,3 +41,9 @@ def test_bench_multi_rank_launch_path():
         j = json.loads(line[0])
         assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
         assert j["config"]["parallelism"].startswith("frame-dp2") and ("replicated" in j["config"]["parallelism"]) == (mode == "replicated")
+        # the N > 1 line carries what the north star's scaling target is read from (round 4): the aggregate encode rate over
+        # all ranks and the all-gather's share of the step
+        d = j["dist"]
+        assert d["world_size"] == 2 and d["allgather_calls"] == 2
+        assert d["vit_frames_per_s_all_gpus"] > 0 and abs(d["vit_frames_per_s_all_gpus"] - 2 * d["vit_frames_per_s_per_gpu_min"]) < 1.0
+        assert 0 < d["allgather_share_of_step"] < 1

@@ -136,6 +136,16 @@ HOT = [  # M, N, K, epilogue, bias, label
     (8224, 1024, 4096, 0, True, "ViT fc2"),
     (8224, 1024, 1024, 0, True, "ViT out"),
     (2688, 32008, 5120, 0, False, "c3 lm_head"),
+    # configs[3]: the per-GPU shapes at N = 1 (8 clips x 32 frames, S = 352: M = 2816) and the REPLICATED prefill of all
+    # 64 sequences (M = 64 x 352 = 22528) — VERDICT r3 item 1a
+    (2816, 27648, 5120, 2, False, "c4 gate|up SwiGLU"),
+    (2816, 15360, 5120, 0, False, "c4 q|k|v"),
+    (2816, 5120, 13824, 0, False, "c4 down"),
+    (2816, 5120, 5120, 0, False, "c4 o"),
+    (22528, 27648, 5120, 2, False, "c4x8 gate|up SwiGLU"),
+    (22528, 15360, 5120, 0, False, "c4x8 q|k|v"),
+    (22528, 5120, 13824, 0, False, "c4x8 down"),
+    (22528, 5120, 5120, 0, False, "c4x8 o"),
 ]
 
 
@@ -182,7 +192,7 @@ def test_gemm_hot_shapes_vs_fp32(M, N, K, epi, has_bias, label, monkeypatch):
     # 2. what the step really runs: the tuned dispatch with the shipped table, on the block-ordered weight copy
     #    for the Llama projections (ops.PackedWeight), through gemm2 for the split-K pairs
     monkeypatch.setattr(ops, "GEMM_MODE", "tuned")
-    wp = ops.PackedWeight(w) if (M in (1312, 2688) and N % 64 == 0) else w
+    wp = ops.PackedWeight(w) if (M in (1312, 2688, 2816, 22528) and N % 64 == 0) else w
     e_tuned = e_pair = None
     for _ in range(200):
         out = ops.gemm(a, wp, bias, epilogue=epi)
@@ -269,6 +279,67 @@ def test_temporal_pooling_at_production_width_vs_oracle(method):
     print(f"N4 {method}: visual tokens [B={B}, {256 + T}, H={H}] rel-L2 {e:.2e} max-abs {maxabs(vis, ref):.3e} "
           f"(|ref| max {float(np.abs(ref).max()):.2f}); pooling+projection stage {ev[2].elapsed_time(ev[3]) - ev[0].elapsed_time(ev[1]):.3f} ms")
     assert e < 8e-3
+
+
+# ---- BASELINE.json configs[3]: the replicated prefill of all 64 sequences ---------------------------------------------------
+def test_c4_replicated_prefill_64_sequences_vs_oracle(monkeypatch):
+    """configs[3]'s LLM step as every rank runs it: B = 64 sequences x S = 352 through 2 decoder layers at the 13B shapes
+    (M = 22528 rows per GEMM, tuned dispatch with the shipped M = 22528 decisions) + lm_head, into a KV cache whose per-layer
+    K / V tensors are > 4 GB each (ctx_max 6656: 64 x 40 x 6656 x 256 B = 4.36 GB) — the size at which round 3's LDS-DMA
+    attention kernel fell back to the register-staged one; its descriptors now start at the (batch, head) slice.  Sequences
+    are independent (valley_model.py:249-254 -> hf LlamaModel.forward), so the oracle evaluates a SLICE of them — rows 0, 31
+    (left-padded by 9) and 63 — and the HIP rows are held to it; attention of BOTH kernels on the big cache is compared too."""
+    from oracle import valley_oracle as O
+    from valley_amd import ops, weights as W
+    monkeypatch.setattr(ops, "GEMM_MODE", "tuned")
+    ll, sd, cfg = _llama("13b")
+    B, S, H, CTX = 64, 352, 5120, 6656
+    rows = [0, 31, 63]
+    emb = W.det_normal(19, "emb.c4", (B, S, H), 0.5)
+    mask = np.ones((B, S), np.int64)
+    mask[31, :9] = 0
+    cache = ll.new_cache(B, CTX)
+    assert cache.k[0].numel() * 2 > (1 << 32)                      # the > 4 GB case itself
+    cache.key_valid = torch.ones((B, cache.ctx_max), dtype=torch.uint8, device="cuda")
+    cache.key_valid[:, :S] = torch.from_numpy(mask).to(torch.uint8).cuda()
+    x0 = torch.from_numpy(emb).cuda().view(B * S, H)
+    for it in range(260):                                            # (the shipped table decides these shapes: one pass)
+        cache.seq_len = 0
+        x = ll.forward(x0.clone(), B, S, cache)
+        torch.cuda.synchronize()
+        if ops.tuning_pending() == 0:
+            break
+    got_h = x.float().view(B, S, H)[rows].cpu().numpy()
+    got_l = ll.logits(x).view(B, S, -1)[rows].cpu().numpy()
+    with torch.no_grad():
+        ref_h, _ = O.llama_forward(torch.from_numpy(emb[rows]), sd, cfg, torch.from_numpy(mask[rows]))
+        ref_l = torch.nn.functional.linear(ref_h, torch.from_numpy(sd["lm_head.weight"]))
+    v = mask[rows].astype(bool)
+    rh, rl = rel(got_h[v], ref_h.numpy()[v]), rel(got_l[v], ref_l.numpy()[v])
+    print(f"c4 replicated prefill B=64 S=352 (M=22528), cache {cache.k[0].numel() * 2 / 2**30:.2f} GB per tensor: rows {rows} "
+          f"hidden rel-L2 {rh:.2e} logits rel-L2 {rl:.2e} max-abs {maxabs(got_l[v], ref_l.numpy()[v]):.3e}")
+    assert rh < 2.2e-2 and rl < 2.2e-2                                # the 13B-shape bound of test_llama_layers_vs_oracle
+    assert ops.sk_error_flag("cuda:0") == 0
+    # the attention call of that step on the > 4 GB cache: LDS-DMA kernel (default) == register-staged kernel (bit-identical)
+    import os, subprocess, sys
+    qkv = (torch.randn((B * S, 3 * H), device="cuda") * 0.5).to(torch.bfloat16)
+    a2 = ops.llama_attention(qkv, cache.k[1], cache.v[1], cache.key_valid, B, S, ll.heads, 0)
+    torch.cuda.synchronize()
+    code = ("import torch,sys; sys.path.insert(0, %r); from valley_amd import ops; "
+            "B,S,H,CTX=64,352,5120,6656; torch.manual_seed(3); "
+            "k=(torch.randn((B,40,CTX,128),device='cuda')*0.5).to(torch.bfloat16); v=(torch.randn((B,40,CTX,128),device='cuda')*0.5).to(torch.bfloat16); "
+            "q=(torch.randn((B*S,3*H),device='cuda')*0.5).to(torch.bfloat16); kv=torch.ones((B,CTX),dtype=torch.uint8,device='cuda'); kv[5,:17]=0; "
+            "o=ops.llama_attention(q,k,v,kv,B,S,40,0); torch.cuda.synchronize(); print('SUM', float(o.float().abs().sum()), float(o.float()[-1].sum()))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for ver in ("2", "1"):                                           # the env switch is read once per process: two children
+        env = dict(os.environ, VLY_LLAMA_ATTN=ver)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("SUM")][-1])
+    print("attention on a 4.36 GB cache, llama_attn2 vs llama_attn:", outs)
+    assert outs[0] == outs[1]
+    assert torch.isfinite(a2.float()).all()
 
 
 # ---- BASELINE.json configs[2] end to end --------------------------------------------------------------------------------

@@ -747,9 +747,14 @@ __global__ void __launch_bounds__(LNW * 64, 4) llama_attn2_kernel(const uint16_t
     const int ntiles = (kv_end + 63) >> 6;
 
     // ---- staging: wave w issues K pieces 2w, 2w + 1 and V pieces 2w, 2w + 1 of a tile (piece p = rows 4p .. 4p + 3)
-    const __amdgpu_buffer_rsrc_t rsK = vly_rsrc(kc), rsV = vly_rsrc(vc), rsM = vly_rsrc(key_valid);
+    // the descriptors start at THIS (batch, head)'s rows (a 64-bit, workgroup-uniform base): the 32-bit lane offsets below only
+    // span one head's ctx_max x 256 bytes, so the cache may be of any size (configs[3]'s replicated prefill holds 18 GB;
+    // round 3 offset from the cache base and fell back to llama_attn_kernel at >= 4 GB)
+    const size_t head_off = ((size_t)b * heads + h) * (size_t)ctx_max * 128;
+    const __amdgpu_buffer_rsrc_t rsK = vly_rsrc(kc + head_off), rsV = vly_rsrc(vc + head_off);
+    const __amdgpu_buffer_rsrc_t rsM = vly_rsrc(key_valid ? key_valid + (size_t)b * kv_stride : key_valid);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t hb = (uint32_t)((b * heads + h) * ctx_max) * 256u;                        // byte offset of this head's rows
+    const uint32_t hb = 0u;
     uint32_t okraw = 1u;
     bool okin = false;
     auto stage = [&](int kt, int buf) {
@@ -770,7 +775,7 @@ __global__ void __launch_bounds__(LNW * 64, 4) llama_attn2_kernel(const uint16_t
         }
         const int kvl = kv0 + lane;                                    // (a buffer load: no 64-bit per-lane pointer to keep alive)
         okin = kvl < kv_len;                                           // (the loaded byte is only looked at at the ballot: no wait for it here)
-        if (key_valid) okraw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsM, (uint32_t)(b * kv_stride + min(kvl, kv_len - 1)), 0, 0);
+        if (key_valid) okraw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsM, (uint32_t)min(kvl, kv_len - 1), 0, 0);
     };
     // per-lane byte offset of the V fragment of d tile dt inside a V tile image: row 4g + t (t = l15 >> 2), 8-byte half l15 & 1,
     // chunk (2 dt + ((l15 & 3) >> 1)) ^ ((row & 7) << 1); + 8192 c per 32-key chunk (+ 4096 = 16 rows for the second read)
@@ -1288,9 +1293,9 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
         return vly_check_launch("vly_llama_attention(decode)");
     }
     // llama_attn2_kernel (LDS-DMA tiles, two workgroups per CU: 59.3 -> 45.0 us per 13B layer at B = 8, S = 336; 77 -> 53 at S = 1024,
-    // profiles/r03/r03_llama_attn2.txt); its 32-bit row offsets need a cache < 4 GB.  VLY_LLAMA_ATTN=1 keeps llama_attn_kernel.
+    // profiles/r03/r03_llama_attn2.txt).  VLY_LLAMA_ATTN=1 keeps the register-staged llama_attn_kernel (A/B runs and its tests).
     static const int ver = getenv("VLY_LLAMA_ATTN") ? atoi(getenv("VLY_LLAMA_ATTN")) : 2;
-    if (ver == 2 && (size_t)B * heads * ctx_max * 256 < ((size_t)1 << 32)) {
+    if (ver == 2 && (size_t)ctx_max * 256 < ((size_t)1 << 32)) {          // (per-head descriptors: no limit on the cache as a whole)
         hipLaunchKernelGGL(llama_attn2_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,
                            (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
                            S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
