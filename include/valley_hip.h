@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 4   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
-                               vly_decode_attention_split, vly_gemv_attnmerge_bf16 */
+#define VLY_ABI_VERSION 5   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
+                               vly_decode_attention_split, vly_gemv_attnmerge_bf16; 5: + vly_decode_layers(_supported) */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -296,6 +296,37 @@ int vly_gemv_rmsnorm_bf16(const float *H, const float *gamma, float eps, const v
  *   (HF LlamaAttention.forward: attn_output -> o_proj, behind serve/model_worker.py:380-387.) */
 int vly_gemv_attnmerge_bf16(const float *partials, const void *W, const float *bias, const float *residual, void *C,
                             int M, int N, int heads, int ldw, int ldc, int ldr, int out_dtype, void *stream);
+
+/* ALL decoder layers of a batch-1/2 decode step in ONE persistent launch (round 4; decode_step.hip): per layer the five
+ *   phases input_layernorm + q|k|v, RoPE + KV append + split attention, merge + o + residual, post_attention_layernorm +
+ *   gate|up + SwiGLU, down + residual — the launches vly_gemv_rmsnorm_bf16 / vly_decode_attention_split /
+ *   vly_gemv_attnmerge_bf16 / vly_gemv_rmsnorm_bf16 / vly_gemv_bf16 of a layer, with the same arithmetic (the step is
+ *   BIT-identical to them) — separated by grid barriers inside the launch, the weight stream running across every barrier.
+ *   Replaces the loop body of serve/model_worker.py:380-387 (one-token forward) x num_hidden_layers.
+ *     layers_dev : DEVICE array of n_layers descriptors (weights in the layouts of the entry points above: q|k|v fused
+ *                  [3H, H], o [H, H], gate|up row-interleaved [2I, H], down [H, I], 16-bit storage type, row-major,
+ *                  16-byte aligned; the two RMSNorm weights fp32 [H]; this layer's K / V cache [B, heads, ctx_max, 128])
+ *     h          : fp32 [B, H] residual stream, in (token embeddings) and out (input of the final norm)
+ *     qkv_scratch (16-bit [B, 3H]), partials (fp32 [B, heads, VLY_DECODE_SPLITS, 132]), mlp_scratch (fp32 [B, I]): workspaces
+ *     pos_dev    : device int32, the position of the new token (pos_stride 0: one value; 1: one per batch row)
+ *     sync       : VLY_DECODE_SYNC_WORDS uint32 of device memory, 64-byte aligned, private to this stream; zeroed by a memset
+ *                  the entry point enqueues itself.  After the launch completed, sync[VLY_DECODE_SYNC_ABORT] != 0 means a
+ *                  workgroup gave up waiting at a grid barrier (not every workgroup was resident: another kernel was holding
+ *                  CUs) and h is invalid — every wait is bounded, the launch always ends.
+ *   Needs the whole GPU: one 1024-thread workgroup per CU, all resident.  B <= 2, heads * 128 == H, (H, I) in the 7B / 13B
+ *   classes (vly_decode_layers_supported); -22 otherwise. */
+typedef struct vly_decode_layer {
+    const void *w_qkv, *w_o, *w_gu, *w_down;
+    const float *ln1, *ln2;
+    void *kcache, *vcache;
+} vly_decode_layer;
+#define VLY_DECODE_SYNC_WORDS 512
+#define VLY_DECODE_SYNC_ABORT 272
+int vly_decode_layers_supported(int B, int H, int heads, int I);
+int vly_decode_layers(const vly_decode_layer *layers_dev, int n_layers, float *h, void *qkv_scratch, float *partials,
+                      float *mlp_scratch, const float *cos_table, const float *sin_table, const uint8_t *key_valid,
+                      int key_valid_stride, const int32_t *pos_dev, int pos_stride, int B, int H, int heads, int I, float eps,
+                      int ctx_max, uint32_t *sync, void *stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) over n contiguous elements, n % 8 == 0: the `.to(dtype)`
  *   between an fp32 tensor and a GEMM input (only used on the `max`-pooling path, where the

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvalley_hip.so")
 LIB_F16 = os.path.join(LIBDIR, "libvalley_hip_f16.so")      # the same sources with -DVLY_FP16=1 (IEEE fp16 storage)
-SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip"]
+SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip", "decode_step.hip"]
 
 
 def hipcc() -> str:

@@ -1,0 +1,742 @@
+// One persistent launch for ALL decoder layers of a batch-1/2 decode step (BASELINE.json configs[4];
+// serve/model_worker.py:380-394 -> hf LlamaDecoderLayer.forward x L).
+//
+// Round 3's step was five launches per layer (norm+q|k|v GEMV, split attention, merge+o GEMV, norm+gate|up GEMV, down GEMV):
+// 118 us per 13B layer of which the weight stream itself is 92 us at the 6.9 TB/s the longest GEMV reaches — the rest is
+// five kernel boundaries (MI355X_MICROARCH "boundary": 1.2-1.9 us each) and, at every one of them, a drained memory pipe that
+// has to fill again.  Here ONE 16-wave workgroup per CU walks the five phases of every layer, separated by a grid barrier,
+// and the weight stream never stops: a workgroup is four 256-thread groups, each of which owns a strided sequence of weight
+// UNITS (a row pair, or one row of the K = I down projection) and keeps TWO units in flight in registers; the units of the
+// NEXT phase are requested before the barrier that ends the current one (they depend on nothing a barrier orders), so the
+// barrier's latency, the activation hand-off and the norm run under ~200 KB per CU of weights already in flight
+// (MI355X_MICROARCH "prefetch-credit": what a run-ahead loader saves per dependency edge).  The attention phase uses 160 of
+// the 1024 groups; every other group spends it fetching the o projection.
+//
+// Arithmetic: per output element exactly that of the launches it replaces — the same chunk-to-thread mapping, the same wave
+// sums, the same fixed-order sum over four waves, norm_row_kernel's norm, decode_split_kernel's attention,
+// gemv_norm_kernel's merge — so the step is BIT-IDENTICAL to the five-launch step (tests/test_decode_persistent_gpu.py).
+//
+// Hand-offs between workgroups (cdna_hip_programming §6 Guideline 16, form R1): every value another CU reads inside the
+// launch (q|k|v, attention partials, the residual stream, the MLP intermediate: 10-84 KB per phase) is stored WRITE-THROUGH
+// (sc1, agent-scope relaxed atomic stores of 4-8 bytes), the storing waves drain vmcnt before the workgroup arrives at the
+// barrier, and readers use sc1 loads after it: no release / acquire fences (a fence per phase would cost 1.7 us x 200).
+// The barrier is the XCD-hierarchical counter barrier of MI355X_MICROARCH "barrier-xcd" over LOGICAL groups (block % 8:
+// placement only affects speed): per-group counter -> top counter -> per-group generation word, relaxed sc1 polls by one
+// lane with s_sleep, every spin BOUNDED: a workgroup that gives up sets the abort word, everyone leaves at their next
+// barrier, and the host reads the word (vly_decode_layers_status).  All sync words are zeroed by a memset node the entry
+// point enqueues ahead of the launch, every call (Guideline 16 "re-initialise every call").
+#include "common.hpp"
+#include "../../include/valley_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int SPLITS = VLY_DECODE_SPLITS;
+constexpr int WG_THREADS = 512;          // two 256-thread groups, 256 registers per lane: FOUR units in flight per thread
+constexpr int NGRP = WG_THREADS / 256;
+#ifndef VLY_DL_SLOTS
+#define VLY_DL_SLOTS 4
+#endif
+constexpr int NS = VLY_DL_SLOTS;           // weight units in flight per group (7 x 16 bytes per thread each)
+constexpr int ATTN_SCRATCH_FLOATS = 256 + 3 * 128 + 8 + 16 * 128;      // sc, qs, knew, vnew, red, acc_s (per 256-thread group)
+constexpr unsigned SPIN_LIMIT = 1u << 20;                                  // ~1 s of polling before a workgroup gives up
+
+// sync words (uint32), each polled word on its own 64-byte line
+constexpr int SY_CNT = 0;            // [8] x 16
+constexpr int SY_TOP = 8 * 16;
+constexpr int SY_GEN = 9 * 16;       // [8] x 16
+constexpr int SY_ABORT = 17 * 16;
+static_assert(SY_ABORT + 16 <= VLY_DECODE_SYNC_WORDS, "sync area");
+
+struct Args {
+    const vly_decode_layer* layers;
+    int n_layers;
+    float* h;                   // [B, H] fp32 residual stream (in / out)
+    uint32_t* qkv;              // [B, 3H] 16-bit, as pairs
+    float* partials;            // [B, heads, SPLITS, 132]
+    float* mlp;                 // [B, I] fp32 (silu(gate) * up before its 16-bit rounding)
+    const float* cos_t;
+    const float* sin_t;
+    const uint8_t* key_valid;
+    int kv_stride;
+    const int32_t* pos_dev;
+    int pos_stride;
+    int B, H, heads, I;
+    float eps;
+    int ctx_max;
+    uint32_t* sync;
+};
+
+// ---- cross-CU accesses: write-through stores, L1-bypassing loads ------------------------------------------------------
+VLY_DEVICE void st_cc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VLY_DEVICE void st_cc(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VLY_DEVICE void st_cc2(float* p, float a, float b) {            // 8 bytes, 8-byte aligned
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+VLY_DEVICE uint32_t ld_cc(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VLY_DEVICE float ld_cc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VLY_DEVICE u32x2 ld_cc2(const void* p) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return u32x2{(uint32_t)v, (uint32_t)(v >> 32)};
+}
+VLY_DEVICE float4 ld_cc4(const float* p) {                       // 16 bytes as two 8-byte agent-scope loads
+    const u32x2 a = ld_cc2(p), b = ld_cc2(p + 2);
+    return make_float4(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// Pointers that come out of the layer table are generic to the compiler (it only knows kernel ARGUMENTS to be global):
+// loads through them would be flat_load with a 64-bit per-lane address, counted on lgkmcnt AND vmcnt.  Everything read
+// through a table pointer goes through these.
+#define VLY_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+VLY_DEVICE const VLY_GLOBAL T* as_global(const void* p) { return (const VLY_GLOBAL T*)(uintptr_t)p; }
+template <typename T>
+VLY_DEVICE VLY_GLOBAL T* as_global_rw(void* p) { return (VLY_GLOBAL T*)(uintptr_t)p; }
+
+// The layer table is read with vector loads (the kernel stores to memory, so hipcc does not scalarise them) and its pointers
+// arrive in VGPRs: a buffer descriptor built from one gets a WATERFALL loop around every load that uses it.  They are
+// workgroup-uniform by construction: say so.
+template <typename T>
+VLY_DEVICE T* uniform_ptr(T* p) {
+    const uintptr_t v = (uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T*)((uintptr_t)lo | ((uintptr_t)hi << 32));
+}
+VLY_DEVICE vly_decode_layer load_layer(const vly_decode_layer* t, int l) {
+    const vly_decode_layer r = t[l];
+    return vly_decode_layer{uniform_ptr(r.w_qkv), uniform_ptr(r.w_o), uniform_ptr(r.w_gu), uniform_ptr(r.w_down),
+                            uniform_ptr(r.ln1), uniform_ptr(r.ln2), uniform_ptr(r.kcache), uniform_ptr(r.vcache)};
+}
+
+// Lane-constant addresses are loop-invariant across the LAYER loop: left alone, hipcc hoists every set-up function's address
+// arithmetic (a dozen 64-bit lane values each) to kernel entry and carries ~120 registers through the unit loops, next to the
+// slots.  Every phase re-derives its lane index from a value the optimiser cannot see through.
+VLY_DEVICE int opaque_i32(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {          // gemv_bf16.hip's, operation for operation
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s = fmaf(h_lo(w[i]), h_lo(a[i]), s);
+        s = fmaf(h_hi(w[i]), h_hi(a[i]), s);
+    }
+    return s;
+}
+
+// ---- the weight stream ------------------------------------------------------------------------------------------------
+// A UNIT is NR weight rows (NR = 2: a row pair of q|k|v / o / gate|up — gate and up of one SwiGLU output; NR = 1: one row
+// of the down projection, whose K = I is 2.7 x longer); a thread of the owning group holds chunks tid + 256 i of each row.
+// Whatever the phase, a unit is SEVEN 16-byte loads per thread (2 rows x 3 chunks + 1 spare, or 1 row x 7) plus the
+// residual words of its outputs: the same instruction count on every path, so hipcc's vmcnt bookkeeping stays exact across
+// the phase changes (a branch around a load makes it wait vmcnt(0): gemv_bf16.hip load_pair).  Chunks past the row, rows
+// past N and the spare slot read W[0..7] and are never accumulated.
+struct WPhase {
+    const uint16_t* W;
+    int N;                  // rows of the projection (0: no unit is live — the spare requests of a phase without a successor)
+    int kind;               // 0: [N, H] rows in pairs; 1: the same, outputs added to the residual stream; 2: [N, I] single rows + residual
+};
+
+template <int MR>
+struct Slot {
+    u32x4 r[7];
+    u32x2 res[MR];
+};
+
+// The requests go through a BUFFER descriptor of the weight matrix (base, bytes): the row offset is a scalar (soffset), the
+// lane offset ONE register shared by the whole kernel (16 tid; chunk i adds 4096 i to the scalar side), and a lane that has
+// nothing to fetch — the ragged last chunk, a row past N, the spare request, a phase without a successor — presents an
+// offset beyond the descriptor's range: the hardware returns zeros without touching memory.  No 64-bit lane arithmetic, no
+// branch, the same seven instructions on every path.
+constexpr uint32_t OOB = 0x80000000u;                        // beyond any matrix (all are < 2 GB)
+template <int MR, int CHH, int CHI>
+VLY_DEVICE void issue(Slot<MR>& s, const WPhase& p, int unit, int tid, const Args& a) {
+    const bool down = p.kind == 2;
+    const int ldw = down ? a.I : a.H, nch = ldw >> 3;
+    const int n0 = down ? unit : 2 * unit;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, (uint32_t)p.N * (uint32_t)ldw * 2u, 0x00020000);
+    const uint32_t vfull = 16u * (uint32_t)tid;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int rh = i >= CHH ? 1 : 0, cih = i - rh * CHH;             // (row, chunk) of request i in a row pair
+        const int row = n0 + (down ? 0 : rh), ci = down ? i : cih;
+        const bool row_live = (down ? (i < CHI) : (cih < CHH)) && row < p.N;   // workgroup-uniform
+        const uint32_t soff = row_live ? (uint32_t)row * (uint32_t)ldw * 2u + 4096u * (uint32_t)ci : 0u;
+        const uint32_t voff = (row_live && tid + 256 * ci < nch) ? vfull : OOB;
+        s.r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2 /* nt */));
+    }
+    // the residual words this unit's outputs are added to: final since the last barrier (h is only written by the phase that
+    // owns the row), the same address for the whole group (one request per wave)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const bool live = p.kind != 0 && n0 < p.N;
+        const float* rp = a.h + (live ? (size_t)m * a.H + (n0 & ~1) : (size_t)0);
+        s.res[m] = ld_cc2(rp);
+    }
+}
+
+enum { K_QKV = 0, K_RES2 = 1, K_SWIGLU = 2, K_RES1 = 3 };
+
+// dot products of one unit against the activation rows in LDS, wave sums, the four waves' partials through LDS (fixed order),
+// epilogue and write-through store by thread 0 of the group.  ONE workgroup barrier per unit (rd alternates between units).
+template <int MR, int CH, int NR, int KIND>
+VLY_DEVICE void consume(Slot<MR>& s, const uint16_t* xs, int K, int N, int unit, int tid, float* rd, const Args& a) {
+    const int lane = tid & 63, wave = tid >> 6, nch = K >> 3;
+    // The dot products only depend on registers: nothing orders them behind the previous unit's barrier, and hipcc computes the
+    // sums of ALL slots at the top of a round, behind one wait for every slot in flight — the stream would drain once per
+    // round.  An empty asm on the slot's registers pins this unit's arithmetic (and the wait for its loads) here.
+    {
+        u32x4 r0 = s.r[0], r1 = s.r[1], r2 = s.r[2], r3 = s.r[3], r4 = s.r[4], r5 = s.r[5], r6 = s.r[6];
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6));
+        s.r[0] = r0; s.r[1] = r1; s.r[2] = r2;
+        s.r[3] = r3; s.r[4] = r4; s.r[5] = r5;
+        s.r[6] = r6;
+        // (the residual words too: where a phase does not read them they are dead on arrival, the allocator hands their registers
+        // to temporaries, and every write to one waits for the load still in flight into it — a vmcnt(0) per unit)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            u32x2 q = s.res[m];
+            asm volatile("" : "+v"(q));
+            s.res[m] = q;
+        }
+    }
+    float acc[NR][MR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {                           // chunk order per thread: tid, tid + 256, ... (gemv_kernel<.., 4, .>)
+        // a chunk past the row holds ZEROS (issue: out-of-range lanes fetch nothing) and adds + 0 to the sums — the launches skip
+        // it, same bits; its activation chunk is clamped to one that exists (0 x finite, never 0 x stale LDS)
+        const int c = min(tid + 256 * i, nch - 1);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const u32x4 av = *(const u32x4*)(xs + (size_t)m * K + 8 * c);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r][m] += dot8(s.r[r * CH + i], av);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) rd[(wave * MR + m) * NR + r] = acc[r][m];
+    }
+    __syncthreads();
+    const int n0 = unit * NR;
+    if (tid != 0 || n0 >= N) return;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        if (m >= a.B) break;
+        float v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float t = rd[m * NR + r];                        // fixed order: wave 0 + 1 + 2 + 3
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) t += rd[(wv * MR + m) * NR + r];
+            v[r] = t + 0.f;                                  // (+ bias, absent on this path: the launches' own expression)
+        }
+        if constexpr (KIND == K_QKV) {
+            st_cc(a.qkv + ((size_t)m * 3 * a.H + n0) / 2, pack_h2(v[0], v[1]));
+        } else if constexpr (KIND == K_SWIGLU) {
+            st_cc(a.mlp + (size_t)m * a.I + (n0 >> 1), x_sigmoid(v[0], 1.f) * v[1]);
+        } else if constexpr (KIND == K_RES2) {
+            st_cc2(a.h + (size_t)m * a.H + n0, v[0] + __uint_as_float(s.res[m][0]), v[1] + __uint_as_float(s.res[m][1]));
+        } else {
+            st_cc(a.h + (size_t)m * a.H + n0, v[0] + __uint_as_float((n0 & 1) ? s.res[m][1] : s.res[m][0]));
+        }
+    }
+}
+
+// the units of one phase, NS in flight per group; the slots freed by its last NS units already fetch the first NS of `nxt`
+template <int MR, int CHH, int CHI, int KIND>
+VLY_DEVICE void run_phase(Slot<MR> (&S)[NS], const WPhase& cur, const WPhase& nxt, const uint16_t* xs, int gid, int G,
+                          int tid, float* rd0, float* rd1, const Args& a) {
+    constexpr int NR = KIND == K_RES1 ? 1 : 2, CH = KIND == K_RES1 ? CHI : CHH;
+    const int K = KIND == K_RES1 ? a.I : a.H;
+    tid = opaque_i32(tid);
+    const int units = cur.N / NR;
+    const int trips = (((units + G - 1) / G) + NS - 1) / NS * NS;    // every group makes the same number of trips, a multiple of NS
+#pragma unroll 1
+    for (int t = 0; t < trips; t += NS) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            // (rd alternates between consecutive units: with NS odd the parity of a slot flips from one round to the next)
+            // (pinned: left alone the scheduler hoists the dot products of ALL slots to the top of the round — they only depend on
+            // registers — behind one wait for every slot: the stream would drain once per round)
+            __builtin_amdgcn_sched_barrier(0);
+            consume<MR, CH, NR, KIND>(S[k], xs, K, cur.N, gid + G * (t + k), tid, ((t + k) & 1) ? rd1 : rd0, a);
+            const bool in = t + k + NS < trips;
+            issue<MR, CHH, CHI>(S[k], in ? cur : nxt, gid + G * (in ? t + k + NS : t + k + NS - trips), tid, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- activation set-up of a phase (after the barrier): the rows every unit is multiplied with, 16-bit, into LDS ----------
+// RMSNorm of the fp32 residual stream: norm_row_kernel's arithmetic operation for operation, by group 0; the other groups
+// meet it at the same 2 MR barriers (gemv_norm_kernel's prologue).  gamma comes from LDS (`gs`, staged a phase or more ahead
+// by stage_gamma: two slots of weights are in flight in registers here, 24 more for gamma do not fit beside the row)
+template <int MR, int CH>
+VLY_DEVICE void setup_norm(const float* H, const float* gs, float eps, uint16_t* xs, float* nred, int K, int M, int grp, int tid_) {
+    const int tid = opaque_i32(tid_);
+    const int nvec = K >> 2, lane = tid & 63, wave = tid >> 6;
+    if (grp == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float4 v[2 * CH];
+            const float* hr = H + (size_t)min(m, M - 1) * K;
+#pragma unroll
+            for (int i = 0; i < 2 * CH; ++i) {
+                const int c = tid + 256 * i;
+                const float4 t = ld_cc4(hr + 4 * min(c, nvec - 1));
+                v[i] = (c < nvec) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * CH; ++i) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            s = wave_sum(s);
+            if (lane == 0) nred[wave] = s;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            s = nred[0] + nred[1] + nred[2] + nred[3];
+            const float rstd = rsqrtf(s / (float)K + eps);
+#pragma unroll
+            for (int i = 0; i < 2 * CH; ++i) {
+                const int c = tid + 256 * i;
+                if (c >= nvec) continue;
+                const float4 gm = *(const float4*)(gs + 4 * c);
+                float4 o;
+                o.x = gm.x * (v[i].x * rstd); o.y = gm.y * (v[i].y * rstd);
+                o.z = gm.z * (v[i].z * rstd); o.w = gm.w * (v[i].w * rstd);
+                u32x2 pk;
+                pk[0] = pack_h2(o.x, o.y);
+                pk[1] = pack_h2(o.z, o.w);
+                *(u32x2*)(xs + (size_t)m * K + 4 * c) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+    }
+}
+
+// An RMSNorm weight vector on its way into LDS: requested (two float4 per thread cover K <= 8192) before a phase's unit loop,
+// written after it — the loads complete under the loop, nothing waits for them
+struct GammaRegs {
+    f32x4 g[4];                                              // 512 threads x 4 float4 cover K <= 8192
+};
+VLY_DEVICE void stage_gamma_issue(GammaRegs& r, const float* gamma, int K) {
+    const int nvec = K >> 2, t = opaque_i32(threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.g[i] = as_global<f32x4>(gamma)[min(t + WG_THREADS * i, nvec - 1)];
+}
+VLY_DEVICE void stage_gamma_commit(const GammaRegs& r, float* gs, int K) {
+    const int nvec = K >> 2, t = opaque_i32(threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = t + WG_THREADS * i;
+        if (c < nvec) *(f32x4*)(gs + 4 * c) = r.g[i];
+    }
+}
+
+// merge of the attention partials (gemv_norm_kernel PRO = 1): all threads, unit u = dims 4 (u & 31) .. + 3 of head u >> 5
+template <int MR>
+VLY_DEVICE void setup_merge(const float* partials, uint16_t* xs, int heads, int M) {
+    const int K = heads * 128, nvec = K >> 2, t0 = opaque_i32(threadIdx.x);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float* pb_ = partials + (size_t)min(m, M - 1) * heads * (SPLITS * 132);
+#pragma unroll 2
+        for (int u = t0; u < nvec; u += WG_THREADS) {
+            const float* hb = pb_ + (size_t)(u >> 5) * (SPLITS * 132);
+            float ms[SPLITS], ls[SPLITS];
+            float4 os[SPLITS];
+#pragma unroll
+            for (int sp = 0; sp < SPLITS; ++sp) {
+                const u32x2 ml = ld_cc2(hb + sp * 132);
+                ms[sp] = __uint_as_float(ml[0]);
+                ls[sp] = __uint_as_float(ml[1]);
+                os[sp] = ld_cc4(hb + sp * 132 + 4 + 4 * (u & 31));
+            }
+            float mx = ms[0];
+#pragma unroll
+            for (int sp = 1; sp < SPLITS; ++sp) mx = fmaxf(mx, ms[sp]);
+            float L = 0.f;
+            float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sp = 0; sp < SPLITS; ++sp) {            // split order: deterministic
+                const float w = exp2f(ms[sp] - mx);
+                L = fmaf(ls[sp], w, L);
+                O.x = fmaf(os[sp].x, w, O.x); O.y = fmaf(os[sp].y, w, O.y);
+                O.z = fmaf(os[sp].z, w, O.z); O.w = fmaf(os[sp].w, w, O.w);
+            }
+            u32x2 pk;
+            pk[0] = pack_h2(O.x / L, O.y / L);
+            pk[1] = pack_h2(O.z / L, O.w / L);
+            *(u32x2*)(xs + (size_t)m * K + 4 * u) = pk;
+        }
+    }
+    __syncthreads();
+}
+
+// the MLP intermediate: fp32 silu(gate) * up -> its 16-bit rounding (what vly_gemv's SwiGLU epilogue stores)
+template <int MR>
+VLY_DEVICE void setup_mlp(const float* mlp, uint16_t* xs, int I, int M) {
+    const int nvec = I >> 2, t0 = opaque_i32(threadIdx.x);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float* src = mlp + (size_t)min(m, M - 1) * I;
+#pragma unroll 4
+        for (int c = t0; c < nvec; c += WG_THREADS) {
+            const float4 v = ld_cc4(src + 4 * c);
+            u32x2 pk;
+            pk[0] = pack_h2(v.x, v.y);
+            pk[1] = pack_h2(v.z, v.w);
+            *(u32x2*)(xs + (size_t)m * I + 4 * c) = pk;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- attention of the new token, one (batch, head, key split) per 256-thread group: decode_split_kernel's arithmetic ---------
+// Register-lean form for a 1024-thread workgroup (128 registers per lane): a thread's 256-byte K row and its sixteen V chunks
+// arrive in two halves each (same accumulation order).  `trips` is the workgroup's (uniform) count of 256-key passes:
+// 3 trips + 2 workgroup barriers, matched one for one by the groups that hold no item (attn_idle).
+VLY_DEVICE void attn_item(const Args& a, const vly_decode_layer& Lp, int b, int h, int sp, int tid_, float* scratch, int trips) {
+    const int tid = opaque_i32(tid_);
+    float* sc = scratch;
+    float* qs = sc + 256;
+    float* knew = qs + 128;
+    float* vnew = knew + 128;
+    float* red = vnew + 128;
+    float* acc_s = red + 8;                                  // [16][128]
+    const int lane = tid & 63, wave = tid >> 6;
+    const int heads = a.heads, Hq = heads * 128, ctx_max = a.ctx_max;
+    const int pos = min(a.pos_dev[(size_t)b * a.pos_stride], ctx_max - 1), kv_len = pos + 1;
+    const int chunk = (((kv_len + SPLITS - 1) / SPLITS) + 63) & ~63;
+    const int lo = sp * chunk, hi = min(lo + chunk, kv_len);
+    const bool owner = pos >= lo && pos < hi;
+    const uint32_t* qp32 = a.qkv + ((size_t)b * 3 * Hq + h * 128) / 2;
+    VLY_GLOBAL uint16_t* kbase = as_global_rw<uint16_t>(Lp.kcache) + ((size_t)b * heads + h) * ctx_max * 128;
+    VLY_GLOBAL uint16_t* vbase = as_global_rw<uint16_t>(Lp.vcache) + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint8_t* kvld = a.key_valid ? a.key_valid + (size_t)b * a.kv_stride : nullptr;
+    float* part = a.partials + (((size_t)b * heads + h) * SPLITS + sp) * 132;
+    auto half_of = [](uint32_t w, int i) -> uint16_t { return (uint16_t)((i & 1) ? (w >> 16) : (w & 0xffffu)); };
+    if (tid < 64) {
+        const float cs = a.cos_t[(size_t)pos * 64 + tid], sn = a.sin_t[(size_t)pos * 64 + tid];
+        const float q0 = h2f(half_of(ld_cc(qp32 + (tid >> 1)), tid)), q1 = h2f(half_of(ld_cc(qp32 + ((tid + 64) >> 1)), tid));
+        const float scale = 0.08838834764831845f * LOG2E;
+        qs[tid] = h2f(f2h(rope_rot(q0, q1, cs, sn, -1.f))) * scale;
+        qs[tid + 64] = h2f(f2h(rope_rot(q1, q0, cs, sn, 1.f))) * scale;
+        if (owner) {
+            const float k0 = h2f(half_of(ld_cc(qp32 + ((Hq + tid) >> 1)), tid)), k1 = h2f(half_of(ld_cc(qp32 + ((Hq + tid + 64) >> 1)), tid));
+            const uint16_t r0 = f2h(rope_rot(k0, k1, cs, sn, -1.f)), r1 = f2h(rope_rot(k1, k0, cs, sn, 1.f));
+            knew[tid] = h2f(r0);
+            knew[tid + 64] = h2f(r1);
+            kbase[(size_t)pos * 128 + tid] = r0;
+            kbase[(size_t)pos * 128 + tid + 64] = r1;
+        }
+    } else if (tid < 192 && owner) {
+        const int d = tid - 64;
+        const uint16_t v = half_of(ld_cc(qp32 + ((2 * Hq + d) >> 1)), d);
+        vnew[d] = h2f(v);
+        vbase[(size_t)pos * 128 + d] = v;
+    }
+    __syncthreads();
+
+    const int kg = tid >> 4, dc = tid & 15;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < trips; ++it) {
+        const int c0 = lo + 256 * it;                        // (passes beyond this item's range leave m, l, o as they are)
+        u32x4 va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = c0 + kg + 16 * u;
+            va[u] = (j < hi && j < pos) ? *(const VLY_GLOBAL u32x4*)(vbase + (size_t)j * 128 + 8 * dc) : u32x4{0u, 0u, 0u, 0u};
+        }
+        const int jk = c0 + tid;
+        float s = NEG_BIG;
+        if (jk < hi && (!kvld || kvld[jk])) {
+            float ac = 0.f;
+            if (jk < pos) {
+                const VLY_GLOBAL u32x4* kr = (const VLY_GLOBAL u32x4*)(kbase + (size_t)jk * 128);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    u32x4 kk[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) kk[c] = kr[8 * hf + c];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x4 q0 = *(const f32x4*)(qs + 8 * (8 * hf + c)), q1 = *(const f32x4*)(qs + 8 * (8 * hf + c) + 4);
+                        ac = fmaf(h_lo(kk[c][0]), q0[0], ac); ac = fmaf(h_hi(kk[c][0]), q0[1], ac);
+                        ac = fmaf(h_lo(kk[c][1]), q0[2], ac); ac = fmaf(h_hi(kk[c][1]), q0[3], ac);
+                        ac = fmaf(h_lo(kk[c][2]), q1[0], ac); ac = fmaf(h_hi(kk[c][2]), q1[1], ac);
+                        ac = fmaf(h_lo(kk[c][3]), q1[2], ac); ac = fmaf(h_hi(kk[c][3]), q1[3], ac);
+                    }
+                }
+            } else {                                             // the new token's key: still in LDS
+#pragma unroll 8
+                for (int d = 0; d < 128; ++d) ac = fmaf(knew[d], qs[d], ac);
+            }
+            s = ac;
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (not above the K rows: va + vb + kk would be 96 registers)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                        // second half of the V rows: in flight under the softmax reductions
+            const int j = c0 + kg + 16 * (u + 8);
+            vb[u] = (j < hi && j < pos) ? *(const VLY_GLOBAL u32x4*)(vbase + (size_t)j * 128 + 8 * dc) : u32x4{0u, 0u, 0u, 0u};
+        }
+        float mc = wave_max(s);
+        if (lane == 0) red[wave] = mc;
+        __syncthreads();
+        mc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float m_new = fmaxf(m_run, mc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float p = s > 0.5f * NEG_BIG ? __builtin_amdgcn_exp2f(s - m_new) : 0.f;
+        sc[tid] = p;
+        float lc = wave_sum(p);
+        if (lane == 0) red[4 + wave] = lc;
+        __syncthreads();
+        lc = red[4] + red[5] + red[6] + red[7];
+        l_run = l_run * alpha + lc;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int jl = kg + 16 * u;
+            const float pj = sc[jl];
+            const u32x4 vv = u < 8 ? va[u & 7] : vb[u & 7];
+            if (owner && c0 + jl == pos) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(pj, vnew[8 * dc + i], o[i]);
+            } else {
+                o[0] = fmaf(pj, h_lo(vv[0]), o[0]); o[1] = fmaf(pj, h_hi(vv[0]), o[1]);
+                o[2] = fmaf(pj, h_lo(vv[1]), o[2]); o[3] = fmaf(pj, h_hi(vv[1]), o[3]);
+                o[4] = fmaf(pj, h_lo(vv[2]), o[4]); o[5] = fmaf(pj, h_hi(vv[2]), o[5]);
+                o[6] = fmaf(pj, h_lo(vv[3]), o[6]); o[7] = fmaf(pj, h_hi(vv[3]), o[7]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc_s[kg * 128 + 8 * dc + i] = o[i];
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += acc_s[k2 * 128 + tid];
+        st_cc(part + 4 + tid, t);
+    } else if (tid < 132) {
+        st_cc(part + (tid - 128), tid == 128 ? m_run : tid == 129 ? l_run : 0.f);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partials have left before this workgroup arrives at the barrier
+}
+
+VLY_DEVICE void attn_idle(int trips) {
+    const int nb = 3 * trips + 2;
+#pragma unroll 1
+    for (int i = 0; i < nb; ++i) asm volatile("s_barrier" ::: "memory");
+}
+
+// ---- grid barrier (MI355X_MICROARCH "barrier-xcd" over logical groups block % 8; bounded) -------------------------------
+VLY_DEVICE bool grid_barrier(uint32_t* sync, unsigned epoch, int* flag, bool storing_wave) {
+    if (storing_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned nwg = gridDim.x, g = blockIdx.x & 7u, ngr = nwg < 8u ? nwg : 8u, members = (nwg - g + 7u) / 8u;
+        int ok = 1;
+        if (ld_cc(sync + SY_ABORT) != 0u) ok = 0;
+        else {
+            const unsigned old = __hip_atomic_fetch_add(sync + SY_CNT + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == members * epoch) {
+                const unsigned o2 = __hip_atomic_fetch_add(sync + SY_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o2 + 1u == ngr * epoch)
+                    for (unsigned gg = 0; gg < ngr; ++gg) st_cc(sync + SY_GEN + 16 * gg, epoch);
+            }
+            unsigned spins = 0;
+            while ((int)(ld_cc(sync + SY_GEN + 16 * g) - epoch) < 0) {
+                if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u && ld_cc(sync + SY_ABORT) != 0u)) {
+                    st_cc(sync + SY_ABORT, 1u + epoch);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+template <int MR, int CHH, int CHI>
+__global__ void __launch_bounds__(WG_THREADS) decode_layers_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char dl_smem[];
+    const int H = a.H, I = a.I, B = a.B;
+    const int Kmax = I > H ? I : H;
+    uint16_t* xs = (uint16_t*)dl_smem;                                   // [MR][Kmax]
+    float* fl = (float*)(dl_smem + (((size_t)MR * Kmax * 2 + 15) & ~(size_t)15));
+    float* gs1 = fl;                                                     // [H] input_layernorm weight of the layer ahead
+    float* gs2 = gs1 + H;                                                // [H] post_attention_layernorm weight
+    float* red = gs2 + H;                                                // [2][NGRP][4 * MR * 2]
+    float* nred = red + 2 * NGRP * (4 * MR * 2);                         // [4]
+    int* flag = (int*)(nred + 4);                                        // [4]
+    float* attn = nred + 8;                                              // [NGRP][ATTN_SCRATCH_FLOATS]
+    const int tid = threadIdx.x & 255;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const bool storing_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const int nwg = gridDim.x, G = nwg * NGRP, gid = (int)blockIdx.x * NGRP + grp;
+    float* rd0 = red + grp * (4 * MR * 2);
+    float* rd1 = red + (NGRP + grp) * (4 * MR * 2);
+    unsigned epoch = 0;
+
+    // workgroup-uniform pass count of the attention phase (longest row; per-row positions allowed)
+    int trips = 1;
+    for (int b = 0; b < B; ++b) {
+        const int kvl = min(a.pos_dev[(size_t)b * a.pos_stride], a.ctx_max - 1) + 1;
+        const int chunk = (((kvl + SPLITS - 1) / SPLITS) + 63) & ~63;
+        trips = max(trips, (chunk + 255) >> 8);
+    }
+    const int items = B * a.heads * SPLITS;
+
+    const vly_decode_layer* Lt = a.layers;
+    const vly_decode_layer L0 = load_layer(Lt, 0);
+    const WPhase dummy{(const uint16_t*)L0.w_qkv, 0, 0};
+    Slot<MR> S[NS];
+    {
+        const WPhase pq{(const uint16_t*)L0.w_qkv, 3 * H, 0};
+#pragma unroll
+        for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI>(S[k], pq, gid + G * k, tid, a);
+        GammaRegs g1;
+        stage_gamma_issue(g1, L0.ln1, H);                             // (the first norm of the step waits for its weights once)
+        stage_gamma_commit(g1, gs1, H);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+        const vly_decode_layer L = load_layer(Lt, l);
+        const bool more = l + 1 < a.n_layers;
+        const vly_decode_layer Ln = load_layer(Lt, more ? l + 1 : l);
+        const WPhase pq{(const uint16_t*)L.w_qkv, 3 * H, 0}, po{(const uint16_t*)L.w_o, H, 1}, pg{(const uint16_t*)L.w_gu, 2 * I, 0},
+            pd{(const uint16_t*)L.w_down, H, 2};
+        GammaRegs gr;
+        // ---- input_layernorm + q|k|v --------------------------------------------------------------------------------
+        setup_norm<MR, CHH>(a.h, gs1, a.eps, xs, nred, H, B, grp, tid);
+        stage_gamma_issue(gr, L.ln2, H);
+        run_phase<MR, CHH, CHI, K_QKV>(S, pq, dummy, xs, gid, G, tid, rd0, rd1, a);
+        stage_gamma_commit(gr, gs2, H);
+        if (!grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        // ---- RoPE + KV append + attention of the new token (items on the first groups), o-projection weights on their way -----
+        {
+            const int item = grp * nwg + (int)blockIdx.x;
+            if (item < items) {
+                const int sp = item % SPLITS, hh = (item / SPLITS) % a.heads, bb = item / (SPLITS * a.heads);
+                attn_item(a, L, bb, hh, sp, tid, attn + grp * ATTN_SCRATCH_FLOATS, trips);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI>(S[k], po, gid + G * k, tid, a);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI>(S[k], po, gid + G * k, tid, a);
+                attn_idle(trips);
+            }
+        }
+        if (!grid_barrier(a.sync, ++epoch, flag, false)) return;
+        // ---- merge + o projection + residual ---------------------------------------------------------------------------
+        setup_merge<MR>(a.partials, xs, a.heads, B);
+        run_phase<MR, CHH, CHI, K_RES2>(S, po, pg, xs, gid, G, tid, rd0, rd1, a);
+        if (!grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        // ---- post_attention_layernorm + gate|up + SwiGLU ----------------------------------------------------------------
+        setup_norm<MR, CHH>(a.h, gs2, a.eps, xs, nred, H, B, grp, tid);
+        stage_gamma_issue(gr, Ln.ln1, H);
+        run_phase<MR, CHH, CHI, K_SWIGLU>(S, pg, pd, xs, gid, G, tid, rd0, rd1, a);
+        stage_gamma_commit(gr, gs1, H);
+        if (!grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        // ---- down projection + residual; the next layer's q|k|v rows follow it in the stream ----------------------------
+        setup_mlp<MR>(a.mlp, xs, I, B);
+        const WPhase nq{(const uint16_t*)Ln.w_qkv, more ? 3 * H : 0, 0};
+        run_phase<MR, CHH, CHI, K_RES1>(S, pd, nq, xs, gid, G, tid, rd0, rd1, a);
+        if (more && !grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+    }
+}
+
+int cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
+template <int MR, int CHH, int CHI>
+int launch(const Args& a, size_t lds, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)decode_layers_kernel<MR, CHH, CHI>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) {
+        vly_set_error("vly_decode_layers: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+        return -(1000 + (int)attr);
+    }
+    // every workgroup must be resident for the grid barrier: one workgroup per CU, never more than the CUs
+    hipLaunchKernelGGL((decode_layers_kernel<MR, CHH, CHI>), dim3(cu_count()), dim3(WG_THREADS), lds, st, a);
+    return vly_check_launch("vly_decode_layers");
+}
+
+}  // namespace
+
+extern "C" int vly_decode_layers_supported(int B, int H, int heads, int I) {
+    const int chh = (H + 2047) / 2048, chi = (I + 2047) / 2048;
+    return B >= 1 && B <= 2 && heads * 128 == H && H % 8 == 0 && I % 8 == 0 && ((chh == 2 && chi == 6) || (chh == 3 && chi == 7)) ? 1 : 0;
+}
+
+extern "C" int vly_decode_layers(const vly_decode_layer* layers_dev, int n_layers, float* h, void* qkv_scratch, float* partials,
+                                 float* mlp_scratch, const float* cos_table, const float* sin_table, const uint8_t* key_valid,
+                                 int key_valid_stride, const int32_t* pos_dev, int pos_stride, int B, int H, int heads, int I, float eps,
+                                 int ctx_max, uint32_t* sync, void* stream) {
+    if (!layers_dev || n_layers <= 0 || !h || !qkv_scratch || !partials || !mlp_scratch || !cos_table || !sin_table || !pos_dev || !sync ||
+        pos_stride < 0 || pos_stride > 1 || ctx_max <= 0 || ((uintptr_t)h & 15) || ((uintptr_t)qkv_scratch & 15) || ((uintptr_t)partials & 15) ||
+        ((uintptr_t)mlp_scratch & 15) || ((uintptr_t)sync & 63) || (key_valid && key_valid_stride < ctx_max)) {
+        vly_set_error("vly_decode_layers: bad arguments (B=%d H=%d heads=%d I=%d ctx_max=%d)", B, H, heads, I, ctx_max);
+        return -22;
+    }
+    if (!vly_decode_layers_supported(B, H, heads, I)) {
+        vly_set_error("vly_decode_layers: unsupported shape B=%d H=%d heads=%d I=%d (B <= 2, heads * 128 = H, (H, I) in the 7B / 13B "
+                      "classes: 2048 < H <= 4096 with 10240 < I <= 12288, or 4096 < H <= 6144 with 12288 < I <= 14336)", B, H, heads, I);
+        return -22;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sync, 0, VLY_DECODE_SYNC_WORDS * sizeof(uint32_t), st);      // re-initialised every call
+    if (e != hipSuccess) {
+        vly_set_error("vly_decode_layers: hipMemsetAsync: %s", hipGetErrorString(e));
+        return -(1000 + (int)e);
+    }
+    Args a{layers_dev, n_layers, h, (uint32_t*)qkv_scratch, partials, mlp_scratch, cos_table, sin_table, key_valid, key_valid_stride,
+           pos_dev, pos_stride, B, H, heads, I, eps, ctx_max, sync};
+    const int Kmax = I > H ? I : H;
+    const int chh = (H + 2047) / 2048;
+#define VLY_DL(MR)                                                                                                    \
+    do {                                                                                                              \
+        const size_t lds = (((size_t)MR * Kmax * 2 + 15) & ~(size_t)15) + ((size_t)2 * H + 2 * NGRP * (4 * MR * 2) + 8 + NGRP * ATTN_SCRATCH_FLOATS) * 4; \
+        return chh == 2 ? launch<MR, 2, 6>(a, lds, st) : launch<MR, 3, 7>(a, lds, st);                               \
+    } while (0)
+    if (B == 1) VLY_DL(1);
+    VLY_DL(2);
+#undef VLY_DL
+}

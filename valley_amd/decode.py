@@ -23,6 +23,9 @@ from .llama import HipKVCache, HipLlama
 
 FUSE_NORM = os.environ.get("VALLEY_DECODE_FUSE_NORM", "1") != "0"
 SPLIT_ATTN = os.environ.get("VALLEY_DECODE_SPLIT_ATTN", "1") != "0"       # flash-decoding split + merge inside the o GEMV (B <= 2)
+# round 4: every decoder layer of the step in ONE persistent launch (vly_decode_layers: grid barriers between the five phases of
+# a layer, the weight stream running across them; bit-identical to the five launches per layer).  "0" keeps the launches.
+PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "1") != "0"
 
 
 class DecodeSession:
@@ -45,6 +48,15 @@ class DecodeSession:
         self.partials = ops.decode_partials(B, llama.heads, d)
         self.mlp = torch.empty((B, llama.I), dtype=bf, device=d)
         self.logits = torch.empty((B, llama.Vpad), dtype=torch.float32, device=d)
+        # the persistent form takes the whole GPU (one workgroup per CU, all resident): shapes it supports, and only with the
+        # fused norm / split attention arithmetic it reproduces
+        self.persistent = (PERSISTENT and FUSE_NORM and SPLIT_ATTN and llama.heads * 128 == llama.H
+                           and ops.decode_layers_ok(B, llama.H, llama.heads, llama.I))
+        if self.persistent:
+            self.mlp32 = torch.empty((B, llama.I), dtype=torch.float32, device=d)
+            self.sync = torch.zeros((ops.DECODE_SYNC_WORDS,), dtype=torch.int32, device=d)
+            self.table = None
+            self._table_gen = None
         self.use_graph = use_graph
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._gen = cache.generation
@@ -57,7 +69,13 @@ class DecodeSession:
         fused = FUSE_NORM and ops.gemv_rmsnorm_ok(B, ll.H)
         split = SPLIT_ATTN and ops.gemv_rmsnorm_ok(B, ll.H) and ll.heads * 128 == ll.H
         ops.embed_splice(self.tok, ll.embed, None, out=self.h)
-        for li in range(ll.L):
+        if self.persistent:
+            if self.table is None or self._table_gen != c.generation:      # raw pointers: the cache's storage may have moved
+                self.table = ops.decode_layer_table(ll.layers, c.k, c.v, ll.device)
+                self._table_gen = c.generation
+            ops.decode_layers(self.table, self.h, self.qkv, self.partials, self.mlp32, ll.cos, ll.sin, c.key_valid, self.pos,
+                              self.per_row, ll.heads, ll.I, ll.eps, c.ctx_max, self.sync)
+        for li in range(0 if self.persistent else ll.L):
             L = ll.layers[li]
             if fused:
                 ops.gemv_rmsnorm(self.h, L["ln1"], ll.eps, L["w_qkv"], out=self.qkv)      # input_layernorm inside the q|k|v GEMV
@@ -120,6 +138,13 @@ class DecodeSession:
             self._enqueue_step()
         self.graph = g
         self._gen = self.cache.generation
+
+    def check(self) -> None:
+        """Raise if a workgroup of the persistent launch gave up at a grid barrier in the last step (it needs every CU: a kernel
+        of another stream was holding some).  Costs a device-to-host copy: callers check once per generation, tests per step."""
+        if self.persistent and int(self.sync[ops.DECODE_SYNC_ABORT].item()) != 0:
+            raise RuntimeError("vly_decode_layers: a grid barrier timed out (not every workgroup was resident); the step's "
+                               "output is invalid — rerun with VALLEY_DECODE_PERSISTENT=0 or keep the GPU to this stream")
 
     def step(self) -> torch.Tensor:
         """Run one decode step; returns the (device) int32 [B] buffer holding the newly chosen token.

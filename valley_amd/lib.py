@@ -49,6 +49,8 @@ _SIGS = {
     "vly_decode_attention_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "vly_gemv_attnmerge_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemv_rmsnorm_bf16": (c_int, [_P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_decode_layers_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "vly_decode_layers": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P]),
     "vly_decode_attention": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_decode_attention_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_int, _P]),
     "vly_gemm_bf16_splitk2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -71,7 +73,7 @@ _SIGS = {
     "vly_embed_splice_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ValleyHipError(RuntimeError):

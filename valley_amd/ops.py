@@ -980,6 +980,62 @@ def gemv_attnmerge(partials: torch.Tensor, w, bias=None, residual=None, out_dtyp
     return out
 
 
+DECODE_SYNC_WORDS = 512    # VLY_DECODE_SYNC_WORDS
+DECODE_SYNC_ABORT = 272    # VLY_DECODE_SYNC_ABORT
+
+
+def decode_layers_ok(B: int, H: int, heads: int, I: int) -> bool:
+    """Shapes vly_decode_layers takes: B <= 2, heads * 128 == H, (H, I) of the 7B / 13B classes."""
+    return bool(_lib.load().vly_decode_layers_supported(B, H, heads, I))
+
+
+def decode_layer_table(layers, kcaches, vcaches, device) -> torch.Tensor:
+    """The device array of ``vly_decode_layer`` descriptors vly_decode_layers walks: int64 [L, 8] = w_qkv, w_o, w_gu, w_down, ln1,
+    ln2, kcache, vcache.  Holds raw pointers: rebuild it whenever any of those tensors is reallocated."""
+    rows = []
+    for L, k, v in zip(layers, kcaches, vcaches):
+        for key in ("w_qkv", "w_o", "w_gu", "w_down"):
+            _chk(L[key], runtime.HALF, key)
+        _chk(L["ln1"], torch.float32, "ln1")
+        _chk(L["ln2"], torch.float32, "ln2")
+        _chk(k, runtime.HALF, "kcache")
+        _chk(v, runtime.HALF, "vcache")
+        rows.append([L["w_qkv"].data_ptr(), L["w_o"].data_ptr(), L["w_gu"].data_ptr(), L["w_down"].data_ptr(), L["ln1"].data_ptr(),
+                     L["ln2"].data_ptr(), k.data_ptr(), v.data_ptr()])
+    return torch.tensor(rows, dtype=torch.int64).to(device)
+
+
+def decode_layers(table: torch.Tensor, h: torch.Tensor, qkv: torch.Tensor, partials: torch.Tensor, mlp: torch.Tensor, cos: torch.Tensor,
+                  sin: torch.Tensor, key_valid: Optional[torch.Tensor], pos_dev: torch.Tensor, per_row: bool, heads: int, I: int, eps: float,
+                  ctx_max: int, sync: torch.Tensor) -> torch.Tensor:
+    """vly_decode_layers: every decoder layer of a batch-1/2 decode step in one persistent launch (h in place)."""
+    _chk(table, torch.int64, "table")
+    _chk(h, torch.float32, "h")
+    _chk(qkv, runtime.HALF, "qkv")
+    _chk(partials, torch.float32, "partials")
+    _chk(mlp, torch.float32, "mlp")
+    _chk(cos, torch.float32, "cos")
+    _chk(sin, torch.float32, "sin")
+    _chk(pos_dev, torch.int32, "pos_dev")
+    _chk(sync, torch.int32, "sync")
+    B, H = h.shape
+    assert table.dim() == 2 and table.shape[1] == 8 and tuple(qkv.shape) == (B, 3 * H) and tuple(mlp.shape) == (B, I)
+    assert tuple(partials.shape) == (B, heads, DECODE_SPLITS, 132) and sync.numel() >= DECODE_SYNC_WORDS
+    assert pos_dev.numel() == (B if per_row else 1)
+    if cos.shape[0] < ctx_max or sin.shape[0] < ctx_max or cos.shape[-1] != 64 or sin.shape[-1] != 64:
+        raise ValueError(f"RoPE tables {tuple(cos.shape)} / {tuple(sin.shape)} do not cover ctx_max = {ctx_max} positions x 64")
+    kv_stride = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        assert key_valid.shape[0] == B and key_valid.shape[1] >= ctx_max
+        kv_stride = key_valid.stride(0)
+    rc = _lib.load().vly_decode_layers(table.data_ptr(), table.shape[0], h.data_ptr(), qkv.data_ptr(), partials.data_ptr(), mlp.data_ptr(),
+                                       cos.data_ptr(), sin.data_ptr(), _ptr(key_valid), kv_stride, pos_dev.data_ptr(), 1 if per_row else 0,
+                                       B, H, heads, I, eps, ctx_max, sync.data_ptr(), _stream())
+    _lib.check(rc, "vly_decode_layers")
+    return h
+
+
 def argmax(x: torch.Tensor, out=None) -> torch.Tensor:
     """x fp32 [M,N] (row stride may exceed N) -> int32 [M]."""
     _chk(x, torch.float32, "x", contiguous=False)
