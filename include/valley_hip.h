@@ -309,10 +309,11 @@ int vly_gemv_attnmerge_bf16(const float *partials, const void *W, const float *b
  *     h          : fp32 [B, H] residual stream, in (token embeddings) and out (input of the final norm)
  *     qkv_scratch (16-bit [B, 3H]), partials (fp32 [B, heads, VLY_DECODE_SPLITS, 132]), mlp_scratch (fp32 [B, I]): workspaces
  *     pos_dev    : device int32, the position of the new token (pos_stride 0: one value; 1: one per batch row)
- *     sync       : VLY_DECODE_SYNC_WORDS uint32 of device memory, 64-byte aligned, private to this stream; zeroed by a memset
- *                  the entry point enqueues itself.  After the launch completed, sync[VLY_DECODE_SYNC_ABORT] != 0 means a
- *                  workgroup gave up waiting at a grid barrier (not every workgroup was resident: another kernel was holding
- *                  CUs) and h is invalid — every wait is bounded, the launch always ends.
+ *     sync       : VLY_DECODE_SYNC_WORDS uint32 of device memory, 64-byte aligned, private to this stream and to this
+ *                  (n_layers) — zeroed ONCE by the caller before the first launch; the barrier counters continue from launch to
+ *                  launch.  After a launch completed, sync[VLY_DECODE_SYNC_ABORT] != 0 means a workgroup gave up waiting at a
+ *                  grid barrier (not every workgroup was resident: another kernel was holding CUs) and h is invalid — every
+ *                  wait is bounded, the launch always ends; zero the words again before the next launch.
  *   Needs the whole GPU: one 1024-thread workgroup per CU, all resident.  B <= 2, heads * 128 == H, (H, I) in the 7B / 13B
  *   classes (vly_decode_layers_supported); -22 otherwise. */
 typedef struct vly_decode_layer {

@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
         lc = red[8];
 #pragma unroll
         for (int w = 1; w < 8; ++w) lc += red[8 + w];
-        l_run = l_run * alpha + lc;
+        l_run = vly_mul_add(l_run, alpha, lc);
         m_run = m_new;
         // ---- P.V for this chunk ---------------------------------------------------------------------------
 #pragma unroll
@@ -1218,7 +1218,7 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
         if (lane == 0) red[4 + wave] = lc;
         __syncthreads();
         lc = red[4] + red[5] + red[6] + red[7];
-        l_run = l_run * alpha + lc;
+        l_run = vly_mul_add(l_run, alpha, lc);
         m_run = m_new;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] *= alpha;

@@ -78,14 +78,53 @@ VLY_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {            // (bf16x8 = 8
 #endif
 }
 
-VLY_DEVICE float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Expressions whose rounding must not depend on the kernel they are inlined into.  hipcc (-ffp-contract=fast) turns a*b + c into an
+// fma wherever its vectoriser has not already paired the multiplies: the SAME source line was two roundings in one kernel (v_pk_mul +
+// v_add) and one in another (v_mul + v_fmac), and the persistent decode step disagreed with the launches it replaces in 0.4 % of
+// steps (one RMSNorm sum a last bit apart -> one 16-bit activation rounded the other way).  Pinned here: never contracted.
+VLY_DEVICE float vly_sumsq4(float x, float y, float z, float w) {
+#pragma clang fp contract(off)
+    return x * x + y * y + z * z + w * w;
+}
+VLY_DEVICE float vly_mul_add(float a, float b, float c) {       // a * b + c, two roundings
+#pragma clang fp contract(off)
+    return a * b + c;
+}
+
+// Butterfly reductions over the 64 lanes: v (+)= v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 — every lane ends with the total, summed in
+// that fixed order.  __shfl_xor compiles to ds_bpermute (an LDS-crossbar round trip per step, ~12 issue slots + 6 lgkmcnt waits per
+// sum); the same partners are reachable without the LDS: the two gfx950 swaps for 32 and 16, then DPP inside rows of 16 — a
+// rotation by 8 IS xor 8, a rotation by 4 reaches lane i ^ 4 or (i ^ 4) ^ 8, which hold equal values after the xor-8 step, the quad
+// permutes are xor 2 and xor 1.  Same operands in every add: the result is BIT-identical to the __shfl_xor form (round 4; the decode
+// GEMVs reduce two sums per row pair and wave).
+template <typename OP>
+VLY_DEVICE float wave_reduce(float v, OP op) {
+    {
+        const uint32_t x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);     // r[0] = {lo, lo}, r[1] = {hi, hi}
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        const uint32_t x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);     // rows {0, 0, 2, 2} and {1, 1, 3, 3}
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false)));   // row_ror:8
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false)));   // row_ror:4
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4e, 0xf, 0xf, false)));    // quad_perm [2,3,0,1]
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xb1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
     return v;
 }
+VLY_DEVICE float wave_sum(float v) {
+    return wave_reduce(v, [](float a, float b) { return a + b; });
+}
 VLY_DEVICE float wave_max(float v) {
+    return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
+}
+// the __shfl_xor forms (tests/c_abi and A/B builds: -DVLY_SHFL_REDUCE=1 restores them everywhere)
+VLY_DEVICE float wave_sum_shfl(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 

@@ -23,8 +23,8 @@
 // The barrier is the XCD-hierarchical counter barrier of MI355X_MICROARCH "barrier-xcd" over LOGICAL groups (block % 8:
 // placement only affects speed): per-group counter -> top counter -> per-group generation word, relaxed sc1 polls by one
 // lane with s_sleep, every spin BOUNDED: a workgroup that gives up sets the abort word, everyone leaves at their next
-// barrier, and the host reads the word (vly_decode_layers_status).  All sync words are zeroed by a memset node the entry
-// point enqueues ahead of the launch, every call (Guideline 16 "re-initialise every call").
+// barrier, and the host reads the word.  The sync words are zeroed ONCE by the caller and count on from launch to launch (every
+// launch passes the same number of barriers; see the kernel), and again by the caller after an abort.
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -36,7 +36,7 @@ constexpr int SPLITS = VLY_DECODE_SPLITS;
 constexpr int WG_THREADS = 512;          // two 256-thread groups, 256 registers per lane: FOUR units in flight per thread
 constexpr int NGRP = WG_THREADS / 256;
 #ifndef VLY_DL_SLOTS
-#define VLY_DL_SLOTS 4
+#define VLY_DL_SLOTS 3
 #endif
 constexpr int NS = VLY_DL_SLOTS;           // weight units in flight per group (7 x 16 bytes per thread each)
 constexpr int ATTN_SCRATCH_FLOATS = 256 + 3 * 128 + 8 + 16 * 128;      // sc, qs, knew, vnew, red, acc_s (per 256-thread group)
@@ -66,19 +66,24 @@ struct Args {
     float eps;
     int ctx_max;
     uint32_t* sync;
+    unsigned long long* timing; // debugging aid (vlydbg_decode_timing): [workgroup][layer][5 phases][5 stamps] of s_memrealtime, or nullptr
+    int stop;                   // debugging aid (VLY_DL_STOP): leave after grid barrier `stop` of the first layer (0: never)
 };
 
 // ---- cross-CU accesses: write-through stores, L1-bypassing loads ------------------------------------------------------
-VLY_DEVICE void st_cc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-VLY_DEVICE void st_cc(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef VLY_DL_SCOPE
+#define VLY_DL_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+VLY_DEVICE void st_cc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, VLY_DL_SCOPE); }
+VLY_DEVICE void st_cc(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, VLY_DL_SCOPE); }
 VLY_DEVICE void st_cc2(float* p, float a, float b) {            // 8 bytes, 8-byte aligned
     const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, VLY_DL_SCOPE);
 }
-VLY_DEVICE uint32_t ld_cc(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-VLY_DEVICE float ld_cc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VLY_DEVICE uint32_t ld_cc(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, VLY_DL_SCOPE); }
+VLY_DEVICE float ld_cc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, VLY_DL_SCOPE); }
 VLY_DEVICE u32x2 ld_cc2(const void* p) {
-    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, VLY_DL_SCOPE);
     return u32x2{(uint32_t)v, (uint32_t)(v >> 32)};
 }
 VLY_DEVICE float4 ld_cc4(const float* p) {                       // 16 bytes as two 8-byte agent-scope loads
@@ -130,16 +135,10 @@ VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {          // gemv_bf16.hi
 
 // ---- the weight stream ------------------------------------------------------------------------------------------------
 // A UNIT is NR weight rows (NR = 2: a row pair of q|k|v / o / gate|up — gate and up of one SwiGLU output; NR = 1: one row
-// of the down projection, whose K = I is 2.7 x longer); a thread of the owning group holds chunks tid + 256 i of each row.
-// Whatever the phase, a unit is SEVEN 16-byte loads per thread (2 rows x 3 chunks + 1 spare, or 1 row x 7) plus the
-// residual words of its outputs: the same instruction count on every path, so hipcc's vmcnt bookkeeping stays exact across
-// the phase changes (a branch around a load makes it wait vmcnt(0): gemv_bf16.hip load_pair).  Chunks past the row, rows
-// past N and the spare slot read W[0..7] and are never accumulated.
-struct WPhase {
-    const uint16_t* W;
-    int N;                  // rows of the projection (0: no unit is live — the spare requests of a phase without a successor)
-    int kind;               // 0: [N, H] rows in pairs; 1: the same, outputs added to the residual stream; 2: [N, I] single rows + residual
-};
+// of the down projection, whose K = I is 2.7 x longer); a thread of the owning group holds chunks tid + 256 i of each row:
+// NR x CH 16-byte loads per unit and thread (6 or 7 at the 13B shapes), plus the residual words of its outputs where the
+// phase adds to the residual stream.  Group g owns units g, g + G, g + 2 G, ... and keeps NS of them in flight.
+enum { K_QKV = 0, K_RES2 = 1, K_SWIGLU = 2, K_RES1 = 3, K_NONE = -1 };
 
 template <int MR>
 struct Slot {
@@ -147,56 +146,68 @@ struct Slot {
     u32x2 res[MR];
 };
 
+struct WPhase {
+    const uint16_t* W;
+    int units;              // live units (rows / NR); a unit index beyond them fetches nothing
+};
+
+// what a lane contributes to every request of the kernel: its 16-byte column inside a 4096-byte row segment, and the same
+// with the ragged last chunk of an H-wide / I-wide row masked out
+struct Lane {
+    uint32_t vfull, vlastH, vlastI;
+};
+
 // The requests go through a BUFFER descriptor of the weight matrix (base, bytes): the row offset is a scalar (soffset), the
-// lane offset ONE register shared by the whole kernel (16 tid; chunk i adds 4096 i to the scalar side), and a lane that has
-// nothing to fetch — the ragged last chunk, a row past N, the spare request, a phase without a successor — presents an
-// offset beyond the descriptor's range: the hardware returns zeros without touching memory.  No 64-bit lane arithmetic, no
-// branch, the same seven instructions on every path.
+// lane offset a register shared by the whole phase (16 tid; chunk i adds 4096 i on the scalar side), and a lane that has
+// nothing to fetch — the ragged last chunk, a unit past the end — presents an offset beyond the descriptor's range: the
+// hardware returns zeros without touching memory.  No 64-bit lane arithmetic and no branch: hipcc's vmcnt bookkeeping stays
+// exact (a branch around a load makes it wait vmcnt(0): gemv_bf16.hip load_pair), ~20 instructions per unit.
 constexpr uint32_t OOB = 0x80000000u;                        // beyond any matrix (all are < 2 GB)
-template <int MR, int CHH, int CHI>
-VLY_DEVICE void issue(Slot<MR>& s, const WPhase& p, int unit, int tid, const Args& a) {
-    const bool down = p.kind == 2;
-    const int ldw = down ? a.I : a.H, nch = ldw >> 3;
-    const int n0 = down ? unit : 2 * unit;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, (uint32_t)p.N * (uint32_t)ldw * 2u, 0x00020000);
-    const uint32_t vfull = 16u * (uint32_t)tid;
+template <int MR, int CHH, int CHI, int KIND>
+VLY_DEVICE void issue(Slot<MR>& s, const WPhase& p, int unit, const Lane& ln, const Args& a) {
+    constexpr bool down = KIND == K_RES1;
+    constexpr int NR = down ? 1 : 2, CH = down ? CHI : CHH;
+    const uint32_t row_bytes = 2u * (uint32_t)(down ? a.I : a.H);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, (uint32_t)p.units * NR * row_bytes, 0x00020000);
+    const bool live = unit < p.units;                        // workgroup-uniform
+    const uint32_t base = live ? (uint32_t)unit * NR * row_bytes : 0u;
+    const uint32_t vf = live ? ln.vfull : OOB, vl = live ? (down ? ln.vlastI : ln.vlastH) : OOB;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int rh = i >= CHH ? 1 : 0, cih = i - rh * CHH;             // (row, chunk) of request i in a row pair
-        const int row = n0 + (down ? 0 : rh), ci = down ? i : cih;
-        const bool row_live = (down ? (i < CHI) : (cih < CHH)) && row < p.N;   // workgroup-uniform
-        const uint32_t soff = row_live ? (uint32_t)row * (uint32_t)ldw * 2u + 4096u * (uint32_t)ci : 0u;
-        const uint32_t voff = (row_live && tid + 256 * ci < nch) ? vfull : OOB;
-        s.r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2 /* nt */));
-    }
-    // the residual words this unit's outputs are added to: final since the last barrier (h is only written by the phase that
-    // owns the row), the same address for the whole group (one request per wave)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        const bool live = p.kind != 0 && n0 < p.N;
-        const float* rp = a.h + (live ? (size_t)m * a.H + (n0 & ~1) : (size_t)0);
-        s.res[m] = ld_cc2(rp);
+        for (int i = 0; i < CH; ++i)
+            s.r[r * CH + i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, i == CH - 1 ? vl : vf,
+                                                                                               base + r * row_bytes + 4096u * i, 2 /* nt */));
+    if constexpr (KIND == K_RES2 || KIND == K_RES1) {
+        // the residual words this unit's outputs are added to: final since the last barrier (h is only written by the phase
+        // that owns the row), one address for the whole group (one request per wave)
+        const int n0 = unit * NR;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) s.res[m] = ld_cc2(a.h + (live ? (size_t)m * a.H + (n0 & ~1) : (size_t)0));
     }
 }
 
-enum { K_QKV = 0, K_RES2 = 1, K_SWIGLU = 2, K_RES1 = 3 };
-
 // dot products of one unit against the activation rows in LDS, wave sums, the four waves' partials through LDS (fixed order),
 // epilogue and write-through store by thread 0 of the group.  ONE workgroup barrier per unit (rd alternates between units).
-template <int MR, int CH, int NR, int KIND>
-VLY_DEVICE void consume(Slot<MR>& s, const uint16_t* xs, int K, int N, int unit, int tid, float* rd, const Args& a) {
-    const int lane = tid & 63, wave = tid >> 6, nch = K >> 3;
+template <int MR, int CHH, int CHI, int KIND>
+VLY_DEVICE void consume(Slot<MR>& s, const uint16_t* xs, int units, int unit, int tid, float* rd, const Args& a) {
+    constexpr bool down = KIND == K_RES1;
+    constexpr int NR = down ? 1 : 2, CH = down ? CHI : CHH;
+    const int K = down ? a.I : a.H, nch = K >> 3;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tq = opaque_i32(tid);                          // (the clamped LDS offsets below are recomputed per unit, not carried)
     // The dot products only depend on registers: nothing orders them behind the previous unit's barrier, and hipcc computes the
     // sums of ALL slots at the top of a round, behind one wait for every slot in flight — the stream would drain once per
-    // round.  An empty asm on the slot's registers pins this unit's arithmetic (and the wait for its loads) here.
-    {
-        u32x4 r0 = s.r[0], r1 = s.r[1], r2 = s.r[2], r3 = s.r[3], r4 = s.r[4], r5 = s.r[5], r6 = s.r[6];
-        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6));
-        s.r[0] = r0; s.r[1] = r1; s.r[2] = r2;
-        s.r[3] = r3; s.r[4] = r4; s.r[5] = r5;
-        s.r[6] = r6;
-        // (the residual words too: where a phase does not read them they are dead on arrival, the allocator hands their registers
-        // to temporaries, and every write to one waits for the load still in flight into it — a vmcnt(0) per unit)
+    // round.  An empty asm on the slot's registers pins this unit's arithmetic (and the wait for its loads) here.  (The
+    // residual words too: a register the phase never reads is dead on arrival, the allocator hands it to temporaries, and
+    // every write to one waits for the load still in flight into it.)
+#pragma unroll
+    for (int i = 0; i < NR * CH; ++i) {
+        u32x4 q = s.r[i];
+        asm volatile("" : "+v"(q));
+        s.r[i] = q;
+    }
+    if constexpr (KIND == K_RES2 || KIND == K_RES1) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             u32x2 q = s.res[m];
@@ -213,7 +224,7 @@ VLY_DEVICE void consume(Slot<MR>& s, const uint16_t* xs, int K, int N, int unit,
     for (int i = 0; i < CH; ++i) {                           // chunk order per thread: tid, tid + 256, ... (gemv_kernel<.., 4, .>)
         // a chunk past the row holds ZEROS (issue: out-of-range lanes fetch nothing) and adds + 0 to the sums — the launches skip
         // it, same bits; its activation chunk is clamped to one that exists (0 x finite, never 0 x stale LDS)
-        const int c = min(tid + 256 * i, nch - 1);
+        const int c = min(tq + 256 * i, nch - 1);
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const u32x4 av = *(const u32x4*)(xs + (size_t)m * K + 8 * c);
@@ -232,8 +243,8 @@ VLY_DEVICE void consume(Slot<MR>& s, const uint16_t* xs, int K, int N, int unit,
             for (int r = 0; r < NR; ++r) rd[(wave * MR + m) * NR + r] = acc[r][m];
     }
     __syncthreads();
+    if (tid != 0 || unit >= units) return;
     const int n0 = unit * NR;
-    if (tid != 0 || n0 >= N) return;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         if (m >= a.B) break;
@@ -257,28 +268,29 @@ VLY_DEVICE void consume(Slot<MR>& s, const uint16_t* xs, int K, int N, int unit,
     }
 }
 
-// the units of one phase, NS in flight per group; the slots freed by its last NS units already fetch the first NS of `nxt`
-template <int MR, int CHH, int CHI, int KIND>
+// The units of one phase: trips = ceil(units / G) passes for every group (a group whose last unit does not exist makes the
+// pass with zeros and stores nothing: the workgroup's barriers stay matched).  Full rounds re-request a slot for the same
+// phase as soon as it is consumed; in the LAST round (1 .. NS units) a consumed slot is handed to the first units of the
+// NEXT phase, which depend on nothing a barrier orders: they are in flight under the barrier and the next set-up.
+template <int MR, int CHH, int CHI, int KIND, int NEXT>
 VLY_DEVICE void run_phase(Slot<MR> (&S)[NS], const WPhase& cur, const WPhase& nxt, const uint16_t* xs, int gid, int G,
-                          int tid, float* rd0, float* rd1, const Args& a) {
-    constexpr int NR = KIND == K_RES1 ? 1 : 2, CH = KIND == K_RES1 ? CHI : CHH;
-    const int K = KIND == K_RES1 ? a.I : a.H;
-    tid = opaque_i32(tid);
-    const int units = cur.N / NR;
-    const int trips = (((units + G - 1) / G) + NS - 1) / NS * NS;    // every group makes the same number of trips, a multiple of NS
+                          int tid, const Lane& ln, float* rd0, float* rd1, const Args& a) {
+    const int trips = (cur.units + G - 1) / G;               // >= 1
+    const int full = (trips - 1) / NS;                       // rounds before the last one
 #pragma unroll 1
-    for (int t = 0; t < trips; t += NS) {
+    for (int rnd = 0; rnd < full; ++rnd) {
+        const int t = rnd * NS;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            // (rd alternates between consecutive units: with NS odd the parity of a slot flips from one round to the next)
-            // (pinned: left alone the scheduler hoists the dot products of ALL slots to the top of the round — they only depend on
-            // registers — behind one wait for every slot: the stream would drain once per round)
-            __builtin_amdgcn_sched_barrier(0);
-            consume<MR, CH, NR, KIND>(S[k], xs, K, cur.N, gid + G * (t + k), tid, ((t + k) & 1) ? rd1 : rd0, a);
-            const bool in = t + k + NS < trips;
-            issue<MR, CHH, CHI>(S[k], in ? cur : nxt, gid + G * (in ? t + k + NS : t + k + NS - trips), tid, a);
-            __builtin_amdgcn_sched_barrier(0);
+            consume<MR, CHH, CHI, KIND>(S[k], xs, cur.units, gid + G * (t + k), tid, ((t + k) & 1) ? rd1 : rd0, a);
+            issue<MR, CHH, CHI, KIND>(S[k], cur, gid + G * (t + k + NS), ln, a);      // (beyond the last pass: fetches nothing)
         }
+    }
+    const int t = full * NS, rem = trips - t;                // 1 .. NS passes left
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (k < rem) consume<MR, CHH, CHI, KIND>(S[k], xs, cur.units, gid + G * (t + k), tid, ((t + k) & 1) ? rd1 : rd0, a);
+        if constexpr (NEXT != K_NONE) issue<MR, CHH, CHI, NEXT>(S[k], nxt, gid + G * k, ln, a);
     }
 }
 
@@ -303,7 +315,7 @@ VLY_DEVICE void setup_norm(const float* H, const float* gs, float eps, uint16_t*
             }
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2 * CH; ++i) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            for (int i = 0; i < 2 * CH; ++i) s += vly_sumsq4(v[i].x, v[i].y, v[i].z, v[i].w);
             s = wave_sum(s);
             if (lane == 0) nred[wave] = s;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -515,7 +527,7 @@ VLY_DEVICE void attn_item(const Args& a, const vly_decode_layer& Lp, int b, int 
         if (lane == 0) red[4 + wave] = lc;
         __syncthreads();
         lc = red[4] + red[5] + red[6] + red[7];
-        l_run = l_run * alpha + lc;
+        l_run = vly_mul_add(l_run, alpha, lc);
         m_run = m_new;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] *= alpha;
@@ -556,13 +568,25 @@ VLY_DEVICE void attn_idle(int trips) {
     for (int i = 0; i < nb; ++i) asm volatile("s_barrier" ::: "memory");
 }
 
+VLY_DEVICE void stamp(const Args& a, int layer, int phase, int k) {
+    if (a.timing != nullptr && threadIdx.x == 0)
+        a.timing[(((size_t)blockIdx.x * a.n_layers + layer) * 5 + phase) * 5 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
 // ---- grid barrier (MI355X_MICROARCH "barrier-xcd" over logical groups block % 8; bounded) -------------------------------
-VLY_DEVICE bool grid_barrier(uint32_t* sync, unsigned epoch, int* flag, bool storing_wave) {
+VLY_DEVICE bool grid_barrier(const Args& a, int layer, int phase, unsigned epoch, int* flag, bool storing_wave) {
+    uint32_t* sync = a.sync;
+    stamp(a, layer, phase, 2);
     if (storing_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have completed
     __syncthreads();
+    stamp(a, layer, phase, 3);
     if (threadIdx.x == 0) {
         const unsigned nwg = gridDim.x, g = blockIdx.x & 7u, ngr = nwg < 8u ? nwg : 8u, members = (nwg - g + 7u) / 8u;
         int ok = 1;
+#if VLY_DL_RELEASE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         if (ld_cc(sync + SY_ABORT) != 0u) ok = 0;
         else {
             const unsigned old = __hip_atomic_fetch_add(sync + SY_CNT + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -574,16 +598,20 @@ VLY_DEVICE bool grid_barrier(uint32_t* sync, unsigned epoch, int* flag, bool sto
             unsigned spins = 0;
             while ((int)(ld_cc(sync + SY_GEN + 16 * g) - epoch) < 0) {
                 if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u && ld_cc(sync + SY_ABORT) != 0u)) {
-                    st_cc(sync + SY_ABORT, 1u + epoch);
+                    st_cc(sync + SY_ABORT, 1u | (epoch << 1));        // (never 0, whatever the epoch)
                     ok = 0;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
+#if VLY_DL_ACQUIRE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         *flag = ok;
     }
     __syncthreads();
+    stamp(a, layer, phase, 4);
     return *flag != 0;
 }
 
@@ -606,7 +634,12 @@ __global__ void __launch_bounds__(WG_THREADS) decode_layers_kernel(const Args a)
     const int nwg = gridDim.x, G = nwg * NGRP, gid = (int)blockIdx.x * NGRP + grp;
     float* rd0 = red + grp * (4 * MR * 2);
     float* rd1 = red + (NGRP + grp) * (4 * MR * 2);
-    unsigned epoch = 0;
+    // The barrier words are never reset: every launch passes the same number of barriers, so the generation word of this
+    // workgroup's group still holds the last epoch of the previous launch (complete by stream order) and the counters are
+    // whole multiples of it; this launch counts on from there, in wrap-around arithmetic.  (A memset node ahead of the launch,
+    // the other way to re-initialise, was observed to race with the kernel under hipGraph replay.)  After an ABORT the words
+    // are inconsistent: the host zeroes them (DecodeSession.check).
+    unsigned epoch = ld_cc(a.sync + SY_GEN + 16 * ((int)blockIdx.x & 7));
 
     // workgroup-uniform pass count of the attention phase (longest row; per-row positions allowed)
     int trips = 1;
@@ -619,12 +652,18 @@ __global__ void __launch_bounds__(WG_THREADS) decode_layers_kernel(const Args a)
 
     const vly_decode_layer* Lt = a.layers;
     const vly_decode_layer L0 = load_layer(Lt, 0);
-    const WPhase dummy{(const uint16_t*)L0.w_qkv, 0, 0};
+    Lane ln;
+    {
+        const int t = opaque_i32(tid);
+        ln.vfull = 16u * (uint32_t)t;
+        ln.vlastH = t + 256 * (CHH - 1) < (H >> 3) ? ln.vfull : OOB;
+        ln.vlastI = t + 256 * (CHI - 1) < (I >> 3) ? ln.vfull : OOB;
+    }
     Slot<MR> S[NS];
     {
-        const WPhase pq{(const uint16_t*)L0.w_qkv, 3 * H, 0};
+        const WPhase pq{(const uint16_t*)L0.w_qkv, 3 * H / 2};
 #pragma unroll
-        for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI>(S[k], pq, gid + G * k, tid, a);
+        for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI, K_QKV>(S[k], pq, gid + G * k, ln, a);
         GammaRegs g1;
         stage_gamma_issue(g1, L0.ln1, H);                             // (the first norm of the step waits for its weights once)
         stage_gamma_commit(g1, gs1, H);
@@ -634,46 +673,57 @@ __global__ void __launch_bounds__(WG_THREADS) decode_layers_kernel(const Args a)
     for (int l = 0; l < a.n_layers; ++l) {
         const vly_decode_layer L = load_layer(Lt, l);
         const bool more = l + 1 < a.n_layers;
-        const vly_decode_layer Ln = load_layer(Lt, more ? l + 1 : l);
-        const WPhase pq{(const uint16_t*)L.w_qkv, 3 * H, 0}, po{(const uint16_t*)L.w_o, H, 1}, pg{(const uint16_t*)L.w_gu, 2 * I, 0},
-            pd{(const uint16_t*)L.w_down, H, 2};
+        const vly_decode_layer* Lnp = Lt + (more ? l + 1 : l);
+        const void* nxt_wqkv = uniform_ptr(Lnp->w_qkv);
+        const float* nxt_ln1 = uniform_ptr(Lnp->ln1);
+        const WPhase pq{(const uint16_t*)L.w_qkv, 3 * H / 2}, po{(const uint16_t*)L.w_o, H / 2}, pg{(const uint16_t*)L.w_gu, I},
+            pd{(const uint16_t*)L.w_down, H}, nq{(const uint16_t*)nxt_wqkv, more ? 3 * H / 2 : 0};
         GammaRegs gr;
         // ---- input_layernorm + q|k|v --------------------------------------------------------------------------------
+        stamp(a, l, 0, 0);
         setup_norm<MR, CHH>(a.h, gs1, a.eps, xs, nred, H, B, grp, tid);
+        stamp(a, l, 0, 1);
         stage_gamma_issue(gr, L.ln2, H);
-        run_phase<MR, CHH, CHI, K_QKV>(S, pq, dummy, xs, gid, G, tid, rd0, rd1, a);
+        run_phase<MR, CHH, CHI, K_QKV, K_RES2>(S, pq, po, xs, gid, G, tid, ln, rd0, rd1, a);
         stage_gamma_commit(gr, gs2, H);
-        if (!grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        if (!grid_barrier(a, l, 0, ++epoch, flag, storing_wave)) return;
         // ---- RoPE + KV append + attention of the new token (items on the first groups), o-projection weights on their way -----
+        stamp(a, l, 1, 0);
         {
             const int item = grp * nwg + (int)blockIdx.x;
+            // (the first units of the o projection were requested at the end of the q|k|v phase, by every group: they landed under
+            // the barrier, the attention's three dependent round trips see a quiet memory system, and 80 % of the o projection
+            // is on chip when the phase ends.  Requested HERE, by the idle groups, 58 MB of weights queued in front of the
+            // attention's loads: 14.8 us for a phase whose stand-alone kernel takes 6.9)
             if (item < items) {
                 const int sp = item % SPLITS, hh = (item / SPLITS) % a.heads, bb = item / (SPLITS * a.heads);
                 attn_item(a, L, bb, hh, sp, tid, attn + grp * ATTN_SCRATCH_FLOATS, trips);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI>(S[k], po, gid + G * k, tid, a);
             } else {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) issue<MR, CHH, CHI>(S[k], po, gid + G * k, tid, a);
                 attn_idle(trips);
             }
         }
-        if (!grid_barrier(a.sync, ++epoch, flag, false)) return;
+        if (!grid_barrier(a, l, 1, ++epoch, flag, false)) return;
         // ---- merge + o projection + residual ---------------------------------------------------------------------------
+        stamp(a, l, 2, 0);
         setup_merge<MR>(a.partials, xs, a.heads, B);
-        run_phase<MR, CHH, CHI, K_RES2>(S, po, pg, xs, gid, G, tid, rd0, rd1, a);
-        if (!grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        stamp(a, l, 2, 1);
+        run_phase<MR, CHH, CHI, K_RES2, K_SWIGLU>(S, po, pg, xs, gid, G, tid, ln, rd0, rd1, a);
+        if (!grid_barrier(a, l, 2, ++epoch, flag, storing_wave)) return;
+        if (a.stop == 3) return;
         // ---- post_attention_layernorm + gate|up + SwiGLU ----------------------------------------------------------------
+        stamp(a, l, 3, 0);
         setup_norm<MR, CHH>(a.h, gs2, a.eps, xs, nred, H, B, grp, tid);
-        stage_gamma_issue(gr, Ln.ln1, H);
-        run_phase<MR, CHH, CHI, K_SWIGLU>(S, pg, pd, xs, gid, G, tid, rd0, rd1, a);
+        stamp(a, l, 3, 1);
+        stage_gamma_issue(gr, nxt_ln1, H);
+        run_phase<MR, CHH, CHI, K_SWIGLU, K_RES1>(S, pg, pd, xs, gid, G, tid, ln, rd0, rd1, a);
         stage_gamma_commit(gr, gs1, H);
-        if (!grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        if (!grid_barrier(a, l, 3, ++epoch, flag, storing_wave)) return;
         // ---- down projection + residual; the next layer's q|k|v rows follow it in the stream ----------------------------
+        stamp(a, l, 4, 0);
         setup_mlp<MR>(a.mlp, xs, I, B);
-        const WPhase nq{(const uint16_t*)Ln.w_qkv, more ? 3 * H : 0, 0};
-        run_phase<MR, CHH, CHI, K_RES1>(S, pd, nq, xs, gid, G, tid, rd0, rd1, a);
-        if (more && !grid_barrier(a.sync, ++epoch, flag, storing_wave)) return;
+        stamp(a, l, 4, 1);
+        run_phase<MR, CHH, CHI, K_RES1, K_QKV>(S, pd, nq, xs, gid, G, tid, ln, rd0, rd1, a);
+        if (more && !grid_barrier(a, l, 4, ++epoch, flag, storing_wave)) return;
     }
 }
 
@@ -699,7 +749,12 @@ int launch(const Args& a, size_t lds, hipStream_t st) {
     return vly_check_launch("vly_decode_layers");
 }
 
+unsigned long long* g_timing = nullptr;
+
 }  // namespace
+
+// debugging aid, not part of the ABI (tools/decode_phase_times.py): per-workgroup phase time stamps of the next launches
+extern "C" void vlydbg_decode_timing(void* buf) { g_timing = (unsigned long long*)buf; }
 
 extern "C" int vly_decode_layers_supported(int B, int H, int heads, int I) {
     const int chh = (H + 2047) / 2048, chi = (I + 2047) / 2048;
@@ -722,13 +777,9 @@ extern "C" int vly_decode_layers(const vly_decode_layer* layers_dev, int n_layer
         return -22;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sync, 0, VLY_DECODE_SYNC_WORDS * sizeof(uint32_t), st);      // re-initialised every call
-    if (e != hipSuccess) {
-        vly_set_error("vly_decode_layers: hipMemsetAsync: %s", hipGetErrorString(e));
-        return -(1000 + (int)e);
-    }
+    static const int dl_stop = getenv("VLY_DL_STOP") ? atoi(getenv("VLY_DL_STOP")) : 0;
     Args a{layers_dev, n_layers, h, (uint32_t*)qkv_scratch, partials, mlp_scratch, cos_table, sin_table, key_valid, key_valid_stride,
-           pos_dev, pos_stride, B, H, heads, I, eps, ctx_max, sync};
+           pos_dev, pos_stride, B, H, heads, I, eps, ctx_max, sync, g_timing, dl_stop};
     const int Kmax = I > H ? I : H;
     const int chh = (H + 2047) / 2048;
 #define VLY_DL(MR)                                                                                                    \

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict
             if (m > 0) load_h(m);
             float s = 0.f;                                               // norm_row_kernel's arithmetic, operation for operation
 #pragma unroll
-            for (int i = 0; i < 2 * CH; ++i) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            for (int i = 0; i < 2 * CH; ++i) s += vly_sumsq4(v[i].x, v[i].y, v[i].z, v[i].w);
             s = wave_sum(s);
             if (lane == 0) nred[wave] = s;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // group 0's four waves only meet here: see below

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(128) norm_kernel(float* __restrict__ x, const 
                 xr[c] = v[i];
             }
         }
-        if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        if constexpr (RMS) s += vly_sumsq4(v[i].x, v[i].y, v[i].z, v[i].w);
         else s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     if (gamma == nullptr) return;            // ADD-only call (last residual update of the stack)
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) norm_row_kernel(float* __restrict__ x, co
                 xr[c] = v[i];
             }
         }
-        if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        if constexpr (RMS) s += vly_sumsq4(v[i].x, v[i].y, v[i].z, v[i].w);
         else s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     if (gamma == nullptr) return;                              // ADD-only call

@@ -23,10 +23,13 @@ from .llama import HipKVCache, HipLlama
 
 FUSE_NORM = os.environ.get("VALLEY_DECODE_FUSE_NORM", "1") != "0"
 SPLIT_ATTN = os.environ.get("VALLEY_DECODE_SPLIT_ATTN", "1") != "0"       # flash-decoding split + merge inside the o GEMV (B <= 2)
-# round 4: every decoder layer of the step in ONE persistent launch (vly_decode_layers: grid barriers between the five phases of
-# a layer, the weight stream running across them; bit-identical to the five launches per layer).  "0" keeps the launches.
-PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "1") != "0"
-
+# round 4: every decoder layer of the step in ONE persistent launch (vly_decode_layers: grid barriers between the five phases of a
+# layer, the next phase's first weight units requested before the barrier; BIT-identical to the five launches per layer,
+# tests/test_decode_persistent_gpu.py).  Measured (13B, 256 tokens, same box, profiles/r04): 198.7 tokens/s against the launches'
+# 208-209 — its weight loops stream at 6.9-7 TB/s, but a phase boundary inside the launch (arrival skew 3.5-8 us + barrier 1.5-2 us +
+# activation hand-off and norm 1.4-2.8 us) costs no less than a kernel boundary (1.3 us + ramp), and requests issued before the
+# barrier land before it ends (DESIGN.md "decode: the persistent step").  Kept as an option: VALLEY_DECODE_PERSISTENT=1.
+PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "0") != "0"
 
 class DecodeSession:
     def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True, per_row_positions: bool = False):
@@ -143,6 +146,7 @@ class DecodeSession:
         """Raise if a workgroup of the persistent launch gave up at a grid barrier in the last step (it needs every CU: a kernel
         of another stream was holding some).  Costs a device-to-host copy: callers check once per generation, tests per step."""
         if self.persistent and int(self.sync[ops.DECODE_SYNC_ABORT].item()) != 0:
+            self.sync.zero_()                                    # the barrier counters are inconsistent after an abort
             raise RuntimeError("vly_decode_layers: a grid barrier timed out (not every workgroup was resident); the step's "
                                "output is invalid — rerun with VALLEY_DECODE_PERSISTENT=0 or keep the GPU to this stream")
 
