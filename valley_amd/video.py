@@ -12,7 +12,7 @@ import os
 import numpy as np
 import torch
 
-from .runtime import HALF
+from . import runtime
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -94,7 +94,7 @@ def load_video(path, fixed_frame_number: int = 8) -> torch.Tensor:
     return preprocess_frames(frames[sample_indices(len(frames), fixed_frame_number)])
 
 
-def load_video_gpu(frames_u8, device="cuda:0", fixed_frame_number: int = 8, dtype=HALF) -> torch.Tensor:
+def load_video_gpu(frames_u8, device="cuda:0", fixed_frame_number: int = 8, dtype=None) -> torch.Tensor:
     """Decoded frames uint8 [N,H,W,3] (numpy or tensor) -> the hot path's input [1,T,3,224,224] on the
     device: uniform sampling of ``fixed_frame_number`` frames (data_util.py:264-265), then the GPU
     preprocessing kernels (valley_amd/preprocess.py; Pillow-exact resize, crop, normalise)."""

@@ -21,7 +21,6 @@ import numpy as np
 import torch
 
 from . import ops, runtime
-from .runtime import HALF
 
 
 class VisionConfig(SimpleNamespace):
@@ -72,7 +71,7 @@ class HipCLIPVisionTower:
         if prefix == "" and any(k.startswith("vision_model.") for k in sd):
             prefix = "vision_model."
         g = lambda k: sd[prefix + k]  # noqa: E731
-        d, bf, f32 = self.device, HALF, torch.float32
+        d, bf, f32 = self.device, runtime.HALF, torch.float32
         c = self.config
         wp = _dev(g("embeddings.patch_embedding.weight"), d, bf).reshape(1024, 588)
         self.w_patch = torch.zeros((1024, 640), dtype=bf, device=d)
@@ -115,7 +114,7 @@ class HipCLIPVisionTower:
         """Random weights generated on the device (bench only; parity tests use valley_amd.weights)."""
         c = self.config
         g = torch.Generator(device=self.device).manual_seed(seed)
-        d, bf, f32 = self.device, HALF, torch.float32
+        d, bf, f32 = self.device, runtime.HALF, torch.float32
         rn = lambda shape, std, dt=bf: (torch.randn(shape, generator=g, device=d, dtype=f32) * std).to(dt)  # noqa: E731
         H, I = c.hidden_size, c.intermediate_size
         self.w_patch = torch.zeros((1024, 640), dtype=bf, device=d)
@@ -142,14 +141,14 @@ class HipCLIPVisionTower:
         ws = self._ws.get(key)
         if ws is None:
             d, M, I = self.device, F * 257, self.config.intermediate_size
-            ws = dict(cols=torch.empty((F * 256, 640), dtype=HALF, device=d),
+            ws = dict(cols=torch.empty((F * 256, 640), dtype=runtime.HALF, device=d),
                       patch=torch.empty((F * 256, 1024), dtype=torch.float32, device=d),
-                      x=torch.empty((M, 1024), dtype=HALF, device=d),
-                      qkv=torch.empty((M, 3072), dtype=HALF, device=d),
-                      att=torch.empty((M, 1024), dtype=HALF, device=d),
-                      delta=torch.empty((M, 1024), dtype=HALF, device=d),
-                      delta2=torch.empty((M, 1024), dtype=HALF, device=d), split=False,
-                      mlp=torch.empty((M, I), dtype=HALF, device=d))
+                      x=torch.empty((M, 1024), dtype=runtime.HALF, device=d),
+                      qkv=torch.empty((M, 3072), dtype=runtime.HALF, device=d),
+                      att=torch.empty((M, 1024), dtype=runtime.HALF, device=d),
+                      delta=torch.empty((M, 1024), dtype=runtime.HALF, device=d),
+                      delta2=torch.empty((M, 1024), dtype=runtime.HALF, device=d), split=False,
+                      mlp=torch.empty((M, I), dtype=runtime.HALF, device=d))
             if len(self._ws) > 6:
                 self._ws.clear()
             self._ws[key] = ws
@@ -265,7 +264,7 @@ class HipCLIPVisionTower:
             raise RuntimeError("vision tower has no weights")
         if frames.dim() != 4 or tuple(frames.shape[1:]) != (3, 224, 224):
             raise ValueError(f"Input image size ({tuple(frames.shape)}) doesn't match model (3*224*224).")
-        frames = frames.to(device=self.device, dtype=HALF).contiguous()
+        frames = frames.to(device=self.device, dtype=runtime.HALF).contiguous()
         nl = self.n_layers_for(select_layer)
         if nl > len(self.layers):
             raise RuntimeError(f"need {nl} encoder layers, tower holds {len(self.layers)}")
