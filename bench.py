@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
                     help="roofline.traffic of the dominant kernel: measured now by two rocprofv3 --pmc child passes (live, N=1 "
-                         "only), read from the newest profiles/r*_traffic_<config>.json (file), or null (none)")
+                         "only), read from the newest profiles/**/r*_traffic_<config>.json (file), or null (none)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (rocprof runs)")
     ap.add_argument("--also", default="auto",
                     help="extra workloads measured after the timed region, each in a child run of this script, and attached to the "
@@ -542,7 +542,8 @@ def main():
                 traffic, traffic_src = live_traffic(args, name)
             if traffic is None and args.traffic != "none":           # newest committed PMC run of this config
                 import glob
-                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{args.config}.json")), reverse=True):
+                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", f"r*_traffic_{args.config}.json"), recursive=True),
+                                    key=os.path.basename, reverse=True):
                     tk = json.load(open(tpath)).get("kernels", {})
                     hit = [v for k, v in tk.items() if k.replace(" ", "") == name.replace(" ", "")]
                     if hit:

@@ -114,7 +114,7 @@ int vly_gemm_bf16_splitk2(const void *A, const void *W, const float *bias, void 
  *   packed [K/64][ceil(N/64)][64 rows][64 k], rows >= N zero-filled; ceil(N/64)*64*K elements.  In this layout the
  *   K tile of a weight panel that a workgroup stages per iteration is ONE contiguous run in HBM (8 KB per 64 rows)
  *   instead of one 128-byte line out of each 2*K-byte row: +1..3 % on the large GEMMs, +6..12 % on the N = 4096
- *   projections at M = 1312 (profiles/r01_ab_lib_v17.jsonl).  The GEMV (decode) and stream-K kernels read row-major
+ *   projections at M = 1312 (profiles/history/r01/r01_ab_lib_v17.jsonl).  The GEMV (decode) and stream-K kernels read row-major
  *   weights only, so a model that decodes keeps both copies (valley_amd.ops.PackedWeight). */
 int vly_pack_weight_bf16(const void *W, void *packed, int N, int K, int ldw, void *stream);
 

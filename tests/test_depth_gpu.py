@@ -8,7 +8,7 @@ CPU oracle / reference fixtures at < 1e-3, tests/test_precise_gpu.py) on identic
   (b) over a 256-token hipGraph-captured decode (8 layers at 13B shapes behind a 328-token prefix = configs[4]'s context),
       teacher-forced with the fp32 path's greedy tokens: logits error per step (no drift with the KV length) and top-1 agreement.
 Reference math: /root/reference/valley/model/valley_model.py:249-254 (decoder stack), valley/serve/model_worker.py:371-387 (KV loop).
-The CPU oracle at full depth (7B x 32 layers) runs in tools/full_depth_oracle.py; its result is committed under profiles/r03/."""
+The CPU oracle at full depth (7B x 32 layers) runs in tools/full_depth_oracle.py; its result is committed under profiles/history/r03/."""
 import numpy as np
 import pytest
 import torch

@@ -51,6 +51,7 @@ def build_golden_model(method="mean"):
     return model
 
 
+@pytest.mark.both_gemm_modes
 def test_tower_vs_golden():
     g = np.load(os.path.join(GOLD, "g1_tower.npz"))
     model = build_golden_model()
@@ -64,6 +65,7 @@ def test_tower_vs_golden():
         assert rel(h.cpu().numpy()[:, ::8, ::4], g[f"hs{i}"]) < 6e-3, i
 
 
+@pytest.mark.both_gemm_modes
 @pytest.mark.parametrize("method", ["mean", "max", "temporal_importance", "temporal_transformer"])
 def test_forward_vs_golden(method):
     g = np.load(os.path.join(GOLD, f"g2_forward_{method}.npz"))
@@ -88,6 +90,7 @@ def test_forward_vs_golden(method):
     assert maxabs(got[vv], ref[vv]) < LOGIT_TOL and rel(got[vv], ref[vv]) < 1e-2
 
 
+@pytest.mark.both_gemm_modes
 @pytest.mark.parametrize("case", ["mixed", "two_images", "frame_mismatch"])
 def test_splice_cases_vs_golden(case):
     g = np.load(os.path.join(GOLD, f"g3_{case}.npz"))
@@ -115,6 +118,7 @@ def test_splice_errors_match_reference():
         assert str(g[case]) == f"ValueError: {e.value}"
 
 
+@pytest.mark.both_gemm_modes
 def test_list_of_clips_vs_golden():
     g = np.load(os.path.join(GOLD, "g3_list.npz"))
     model = build_golden_model()
@@ -127,6 +131,7 @@ def test_list_of_clips_vs_golden():
     assert maxabs(out.logits.cpu().numpy()[:, ::4][v], g["logits"][v]) < LOGIT_TOL
 
 
+@pytest.mark.both_gemm_modes
 def test_greedy_decode_vs_golden():
     """Manual prefill + KV decode loop (serve/model_worker.py:371-394) against the reference's."""
     g = np.load(os.path.join(GOLD, "g5_decode.npz"))
@@ -178,6 +183,7 @@ def test_pooling_variant_without_weights_fails_loudly():
 
 
 # ---- full-size shapes ------------------------------------------------------------------------------
+@pytest.mark.both_gemm_modes
 def test_vit_l14_full_depth_vs_oracle():
     """ViT-L/14, all 23 contributing layers, 2 frames, against the CPU oracle (seconds on the host)."""
     from oracle import valley_oracle as O
@@ -291,6 +297,7 @@ def test_generate_graph_equals_eager_with_padding():
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.both_gemm_modes
 def test_from_pretrained_checkpoint_roundtrip(tmp_path):
     """an HF-layout checkpoint directory (config.json + safetensors, reference key names
     incl. ``model.vision_tower.vision_model.*`` of the pinned transformers and ``model.mm_projector.*``)
@@ -493,6 +500,7 @@ def test_llama_packed_weights_match_row_major():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.both_gemm_modes
 def test_greedy_decode2_tokens_exact_vs_reference():
     """G5b (tools/gen_goldens_r2.py): prefill + 8 greedy KV steps of the REFERENCE on a prompt whose top-2 logit gaps
     are all > 0.24 — the HIP path must produce the same 8 tokens, through the generic forward, the eager DecodeSession

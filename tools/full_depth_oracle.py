@@ -5,7 +5,7 @@ same bf16-representable values.  Three evaluations of the same problem at depths
     oracle fp32 (the reference arithmetic)   |   oracle with storage rounding at the HIP pipeline's storage points
     (oracle.rounding())   |   the HIP path.
 Prints one JSON object (relative L2 of the final-norm hidden state and of the logits at every depth); committed under
-profiles/r03/.  Runs ~1 min on the GPU box, most of it the host-side oracle."""
+profiles/history/r03/.  Runs ~1 min on the GPU box, most of it the host-side oracle."""
 import json
 import os
 import sys

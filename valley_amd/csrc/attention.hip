@@ -45,7 +45,7 @@ VLY_DEVICE uint32_t sel16(const u32x4& a, const u32x4& b, int dd) {   // element
 // The two 8-byte halves of a V^T fragment (keys 4g..4g+3 and 16+4g..) must stay TWO ds_read_b64: left alone, hipcc's
 // load/store optimizer fuses them into one ds_read2_b64 — half the LDS rate (8 instead of 2 x 2 cycles per wave
 // instruction, MI355X_MICROARCH §LDS) and banked mod 32 instead of mod 64, where the V^T row strides below (592 / 144 bytes,
-// chosen conflict-free for ds_read_b64) collide 2-way.  PMC, round 3 (profiles/r03/r03_pmc_attention.txt): 37 % of the ViT
+// chosen conflict-free for ds_read_b64) collide 2-way.  PMC, round 3 (profiles/history/r03/r03_pmc_attention.txt): 37 % of the ViT
 // kernel's LDS cycles were bank conflicts and its waves sat in s_waitcnt 56 % of the time.  An offset the compiler cannot
 // see through keeps the second read on its own base register.
 VLY_DEVICE int opaque_i32(int v) {
@@ -56,7 +56,7 @@ VLY_DEVICE int opaque_i32(int v) {
 // Output of one query tile: lane (q = l15, g) holds O[q][d = dt*16 + 4g + r] — four 8-byte pieces, one per dt, each a quarter
 // of a 32-byte run of its row.  Stored as they are, a wave instruction writes 16 rows x 32 bytes and every 128-byte line is
 // touched by four instructions: the timing variant without the stores runs 75 instead of 90 us per layer at 128 frames
-// (profiles/r03/r03_vit_attn_timing_variants.jsonl).  A 4 x 4 transpose across the four lanes of a row (the SwiGLU epilogue's
+// (profiles/history/r03/r03_vit_attn_timing_variants.jsonl).  A 4 x 4 transpose across the four lanes of a row (the SwiGLU epilogue's
 // v_permlane16/32_swap pattern, once per 32-bit word) leaves lane g with the whole 32-byte run d = 16g .. 16g + 15.
 VLY_DEVICE void store_tile_rows(uint16_t* row_ptr, const f32x4 (&o)[4], float inv, int g) {
     uint32_t y[2][4];
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     [[maybe_unused]] const int hi16 = opaque_i32(16);          // see opaque_i32
     const int h = blockIdx.x & 15;
     // (Timing variants of this kernel — staging only, no LDS reads, no stores, L2-resident inputs, no HBM traffic, no exp2, no
-    // softmax arithmetic — were compile-time switches here while profiles/r03/r03_vit_attn_timing_variants{,2}.jsonl were
+    // softmax arithmetic — were compile-time switches here while profiles/history/r03/r03_vit_attn_timing_variants{,2}.jsonl were
     // measured; they and the old 8-byte store pattern left with commit 49dfb3f's successor.)
     const int f = blockIdx.x >> 4;
     const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
@@ -247,277 +247,11 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     }
 }
 
-// ---- round 3: persistent, double-buffered, everything staged by LDS-DMA (VLY_VIT_ATTN=4; NOT the default) ----------------
-// The design round 2's review asked for.  ONE 16-wave workgroup per CU walks its heads (block id + k * grid), and while it
-// computes head i out of LDS buffer i & 1 the K and V of head i + 1 land in the other buffer by LDS-DMA — no registers, no
-// VALU, no barrier of their own:
-//   * K as in vit_attn_kernel ([272][128 B], chunk ^= row & 7 on the SOURCE address), V ROW-major ([288][128 B], chunk ^=
-//     row & 6) and read as the second product's A operand with ds_read_b64_tr_b16 (the hardware 4 x 4 transpose; semantics
-//     probed in profiles/r03/r03_tr_read_probe.txt: lanes 4t .. 4t+3 of a 16-lane block supply row t, lane j receives column
-//     j).  The swizzle keeps the 32 lanes of a half wave on 32 distinct 8-byte slots of a 256-byte bank window;
-//   * one barrier per head: vmcnt(0) + barrier says both "my pieces of this head landed" and "I am done with the other
-//     buffer"; the next head's pieces are issued right after it (asm buffer_load ... lds: behind the builtin hipcc drains the
-//     DMA queue before every ds_read) and fly under the whole head;
-//   * 17 query tiles on 16 waves: wave w owns tile w, and the 257th query is split over the KEYS (key tile w per wave, wave 0
-//     also the 17th, which holds key 256 alone; partial (max, sum, 64 outputs) per wave, merged by wave 0 through a
-//     double-buffered 4 KB area) instead of costing one wave a whole 16-row tile;
-//   * outputs leave as 32-byte runs per lane (store_tile_rows).
-// Measured (profiles/r03/r03_vit_attn_v4.jsonl, same box, medians): 89.7 vs vit_attn_kernel's 91.4 us at 128 frames, 176.1 vs
-// 179.8 at 256, 26.9 vs 27.0 at 32 — staging that costs nothing buys 2 %.  The timing variants of vit_attn_kernel
-// (r03_vit_attn_timing_variants{,2}.jsonl) say why: 87 us = 52 with no softmax arithmetic at all, 79 without the exp2, 64
-// with every byte served from L2, 76 without the output stores — nothing in this kernel overlaps with anything else well
-// enough for one removed cost to show in full, and none of them is dominant.  Three more structures measured the same or
-// worse and live in the history only (commit daf98f1): LDS-DMA K staging + packed softmax (v2, +-4 %), the split last query
-// alone (v3, 90.2 vs 90.6), two query tiles per wave with an online softmax to halve the LDS reads (v5, 99.9 vs 89.9).
-constexpr int VMERGE_F = 68;                     // floats per wave in the merge area: m, l, 2 pad, 64 outputs
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-constexpr int V4W = 16;
-constexpr int V4_KB = VNT * 16 * 128;              // 34816
-constexpr int V4_VB = VNC * 32 * 128;              // 36864
-constexpr int V4_QL = 1024;                        // one piece: rows 249..256 of Q (the last query is its row 7)
-constexpr int V4_BUF = V4_KB + V4_VB + V4_QL;      // 72704
-constexpr int V4_MG = V4W * VMERGE_F * 4;          // 4352
-
-VLY_DEVICE bf16x8 vt_frag(const char* lo_addr) {   // two transpose reads: keys +0..3 and +16..19 of this lane group's slots
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_addr));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_addr + 16 * 128));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-__global__ void __launch_bounds__(V4W * 64) vit_attn4_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int nheads) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * V4_BUF + 2 * V4_MG];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const int G = (int)gridDim.x;
-
-    // LDS-DMA pieces in asm (M0 = the wave's 1 KB destination, then buffer_load ... lds — gemm_p4_kernel's form): hipcc orders
-    // every later ds_read behind a builtin global_load_lds with vmcnt(0), because it cannot know that the pieces land in the
-    // OTHER buffer — which would put the whole DMA latency back in front of the second product.  The waits are explicit.
-    const __amdgpu_buffer_rsrc_t rsQ = vly_rsrc(qkv);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto stage = [&](int id, int buf) {              // 34 K pieces + 36 V pieces of 1 KB, dealt to the 16 waves
-        const uint32_t hb = ((uint32_t)(id >> 4) * (uint32_t)(VN * VLD) + (uint32_t)(id & 15) * 64u) * 2u;    // byte offset of (frame, head)
-        for (int pc = wave; pc < VNT * 2 + VNC * 4 + 1; pc += V4W) {
-            const bool isk = pc < VNT * 2, isq = pc == VNT * 2 + VNC * 4;   // wave-uniform
-            const int pv = isk ? pc : pc - VNT * 2;
-            const int sl = pv * 64 + lane, row = isq ? VN - 8 + (lane >> 3) : sl >> 3, cp = sl & 7;
-            const uint32_t vo = hb + ((uint32_t)min(row, VN - 1) * (uint32_t)VLD + (isq ? 0u : isk ? 1024u : 2048u) +
-                                      (uint32_t)((cp ^ (isq ? 0 : row & (isk ? 7 : 6))) << 3)) * 2u;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)buf * V4_BUF + (isk ? 0u : (uint32_t)V4_KB) + (uint32_t)pv * 1024u);
-            asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
-            asm volatile("s_nop 0" ::: "memory");
-            asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(rsQ) : "memory");
-        }
-    };
-    // per-lane byte offsets of the V fragments inside a buffer's V image: row 4g + t (t = l15 >> 2), 8-byte half l15 & 1,
-    // 16-byte chunk (2 dt + ((l15 & 3) >> 1)) ^ ((4g + t) & 6); + 4096 c per 32-key chunk, + 2048 for the second read
-    int voff[4];
-    {
-        const int t = l15 >> 2, r = 4 * g + t, key = r & 6;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) voff[dt] = V4_KB + r * 128 + (((2 * dt + ((l15 & 3) >> 1)) ^ key) << 4) + (l15 & 1) * 8;
-    }
-    const float sc = 0.125f * LOG2E;
-    const int id0 = (int)blockIdx.x;
-    if (id0 >= nheads) return;
-    stage(id0, 0);
-    bf16x8 qn[2];                                    // Q fragments of this wave's tile of the CURRENT head (loaded one head ahead)
-    {
-        const uint16_t* base = qkv + (size_t)(id0 >> 4) * VN * VLD + (id0 & 15) * 64;
-        qn[0] = *(const bf16x8*)(base + (size_t)(wave * 16 + l15) * VLD + g * 8);
-        qn[1] = *(const bf16x8*)(base + (size_t)(wave * 16 + l15) * VLD + 32 + g * 8);
-    }
-    int it = 0;
-    for (int id = id0; id < nheads; id += G, ++it) {
-        const int buf = it & 1;
-        const char* sK = smem + buf * V4_BUF;
-        float* sMg = (float*)(smem + 2 * V4_BUF + buf * V4_MG);
-        const int f = id >> 4, h = id & 15;
-        const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
-        // this wave's pieces of this head have landed (and its Q fragments, and its stores are out).  The BUILTIN form
-        // (0x0f70 = vmcnt(0)): hipcc's own wait insertion sees it and does not put a second vmcnt(0) in front of the first
-        // use of the Q fragments — which would sit behind the next head's DMA issue and drain it
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();                             // ... everyone's have, and everyone is done with the other buffer
-        if (it > 0 && wave == 0) {                   // merge the previous head's 257th query (its partials were complete at the barrier)
-            const float* pm = (const float*)(smem + 2 * V4_BUF + (buf ^ 1) * V4_MG);
-            const int pid = id - G;
-            float M = NEG_BIG;
-#pragma unroll
-            for (int w = 0; w < V4W; ++w) M = fmaxf(M, pm[w * VMERGE_F]);
-            float L = 0.f, O = 0.f;
-#pragma unroll
-            for (int w = 0; w < V4W; ++w) {
-                const float a = sm_exp2(pm[w * VMERGE_F] - M);
-                L = fmaf(pm[w * VMERGE_F + 1], a, L);
-                O = fmaf(pm[w * VMERGE_F + 4 + lane], a, O);
-            }
-            out[((size_t)(pid >> 4) * VN + (VN - 1)) * 1024 + (pid & 15) * 64 + lane] = f2h(O / L);
-        }
-        // ---- the next head's K / V / last-query piece: in flight under this WHOLE head (no ordinary load is pending here: the
-        //      Q fragments were waited for above, and the last query comes out of LDS)
-        if (id + G < nheads) stage(id + G, buf ^ 1);
-        // ---- first the 257th query's partial over this wave's keys (key tile `wave`; wave 0 also key tile 16), start to finish:
-        //      nothing of it stays in registers while the full tile runs (the kernel has exactly 128 registers per lane)
-        {
-            const char* sQ = sK + V4_KB + V4_VB + 7 * 128;           // row 7 of the piece = token 256, linear chunks
-            const bf16x8 ql[2] = {*(const bf16x8*)(sQ + g * 16), *(const bf16x8*)(sQ + 64 + g * 16)};
-            f32x4 sl[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t = j == 0 ? wave : VNT - 1;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (j == 0 || wave == 0) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                        acc = mfma16(kf, ql[kk], acc);
-                    }
-                }
-                sl[j] = acc * sc;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (wave != 0 || g != 0 || r != 0) sl[1][r] = NEG_BIG;     // tile 16 holds key 256 alone, and only wave 0 looks at it
-            float pm = NEG_BIG;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pm = fmaxf(pm, sl[j][r]);
-            pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
-            pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-            float pl = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = sm_exp2(sl[j][r] - pm);
-                    sl[j][r] = p;
-                    pl += p;
-                }
-            pl += __shfl_xor(pl, 16, 64);
-            pl += __shfl_xor(pl, 32, 64);
-            f32x4 po[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) po[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {   // k slots 0..3 <-> key tile `wave`; slots 4..7 carry zero weights (their V reads stay inside the image)
-                u32x4 pk;
-                pk[0] = pack_h2(sl[0][0], sl[0][1]);
-                pk[1] = pack_h2(sl[0][2], sl[0][3]);
-                pk[2] = 0u;
-                pk[3] = 0u;
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) po[dt] = mfma16(vt_frag(sK + voff[dt] + wave * 2048), pf, po[dt]);
-            }
-            if (wave == 0) {                         // key tile 16: rows 256.. (token 256 and its clamped copies, weights 0 past the first)
-                u32x4 pk;
-                pk[0] = pack_h2(sl[1][0], sl[1][1]);
-                pk[1] = pack_h2(sl[1][2], sl[1][3]);
-                pk[2] = 0u;
-                pk[3] = 0u;
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) po[dt] = mfma16(vt_frag(sK + voff[dt] + 16 * 2048), pf, po[dt]);
-            }
-            if (l15 == 0) {
-                float* mg = sMg + wave * VMERGE_F;
-                if (g == 0) { mg[0] = pm; mg[1] = pl; }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(mg + 4 + dt * 16 + 4 * g) = po[dt];
-            }
-        }
-        asm volatile("" ::: "memory");
-        // ---- QK^T of this wave's query tile (tile = wave)
-        f32x4 s[VNT];
-        {
-            const bf16x8 qf[2] = {qn[0], qn[1]};
-#pragma unroll
-            for (int t = 0; t < VNT; ++t) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
-                    acc = mfma16(kf, qf[kk], acc);
-                }
-                s[t] = acc * sc;
-                if ((t & 1) == 1) asm volatile("" ::: "memory");     // at most two key tiles of K fragments in flight (register budget)
-            }
-        }
-        // ---- softmax of the full tile; the probabilities are packed to the storage type as they are produced (34 instead of
-        //      68 registers live through the second product)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;       // keys 257..271 are padding
-        float m = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < VNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-        uint32_t pb[VNT][2];
-#pragma unroll
-        for (int t = 0; t < VNT; ++t) {
-            const float p0 = sm_exp2(s[t][0] - m), p1 = sm_exp2(s[t][1] - m), p2 = sm_exp2(s[t][2] - m), p3 = sm_exp2(s[t][3] - m);
-            l += (p0 + p1) + (p2 + p3);
-            pb[t][0] = pack_h2(p0, p1);
-            pb[t][1] = pack_h2(p2, p3);
-        }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        // ---- O^T += V^T P^T, V fragments by transpose reads
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < VNC; ++c) {
-            u32x4 pk;
-            pk[0] = pb[2 * c][0];
-            pk[1] = pb[2 * c][1];
-            pk[2] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][0] : 0u;
-            pk[3] = 2 * c + 1 < VNT ? pb[2 * c + 1 < VNT ? 2 * c + 1 : 0][1] : 0u;
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(vt_frag(sK + voff[dt] + c * 4096), pf, o[dt]);
-            asm volatile("" ::: "memory");
-            if (c == 4 && id + G < nheads) {         // this wave's Q fragments of the next head, into registers the probabilities have left
-                const int nid = id + G;
-                const uint16_t* nb = qkv + (size_t)(nid >> 4) * VN * VLD + (nid & 15) * 64;
-                qn[0] = *(const bf16x8*)(nb + (size_t)(wave * 16 + l15) * VLD + g * 8);
-                qn[1] = *(const bf16x8*)(nb + (size_t)(wave * 16 + l15) * VLD + 32 + g * 8);
-            }
-        }
-        store_tile_rows(out + ((size_t)f * VN + wave * 16 + l15) * 1024 + h * 64, o, 1.f / l, g);
-    }
-    __syncthreads();
-    if (wave == 0) {                                 // the last head's 257th query
-        const int lastit = it - 1, pid = id0 + lastit * G;
-        const float* pm = (const float*)(smem + 2 * V4_BUF + (lastit & 1) * V4_MG);
-        float M = NEG_BIG;
-#pragma unroll
-        for (int w = 0; w < V4W; ++w) M = fmaxf(M, pm[w * VMERGE_F]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int w = 0; w < V4W; ++w) {
-            const float a = sm_exp2(pm[w * VMERGE_F] - M);
-            L = fmaf(pm[w * VMERGE_F + 1], a, L);
-            O = fmaf(pm[w * VMERGE_F + 4 + lane], a, O);
-        }
-        out[((size_t)(pid >> 4) * VN + (VN - 1)) * 1024 + (pid & 15) * 64 + lane] = f2h(O / L);
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
 // grid = (heads, B, ceil(S/(16*LNW))), last query block first; LNW waves x 16 query rows.
 // ---------------------------------------------------------------------------------------------
-constexpr int LK_BYTES = 64 * 256;          // K tile: 64 keys x 128 d, 256-byte rows, chunk ^= row & 15
-constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row stride 144 B = 16*9
 
 // LNW waves x 16 query rows per workgroup: with 8 waves a K/V tile staged into LDS serves 128 queries (half the
 // redundant tile loads and transposes of the 64-query version) and a CU holds 16 waves.
@@ -526,185 +260,6 @@ constexpr int LVT_STRIDE = 72;              // V^T tile: [128 d][64 kv], row str
 #endif
 constexpr int LNW = VLY_LNW;
 
-__global__ void __launch_bounds__(LNW * 64) llama_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
-                                                         const uint16_t* __restrict__ vc, const uint8_t* __restrict__ key_valid,
-                                                         uint16_t* __restrict__ out, int S, int heads, int past,
-                                                         const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max) {
-    __shared__ __attribute__((aligned(16))) char smem[LK_BYTES + 128 * LVT_STRIDE * 2];
-    char* sK = smem;
-    uint16_t* sVt = (uint16_t*)(smem + LK_BYTES);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    [[maybe_unused]] const int hi16 = opaque_i32(16);          // see opaque_i32
-    // Longest-first dispatch: causal query blocks cost ~(qb + 1) key tiles each, so the grid is (heads, B, blocks) with
-    // the LAST query block in z = 0 — the heavy workgroups start first and the light ones fill the tail (c2: 2 / 4 / 6
-    // key tiles per block, 384 workgroups on 256 CUs: the makespan drops from ~light + heavy to the 6-tile bound).
-#ifndef VLY_ATTN_ORDER
-#define VLY_ATTN_ORDER 1      // 0: first query block first (A/B builds, tools/ab_lib.py)
-#endif
-    const int h = blockIdx.x, b = blockIdx.y, qb = VLY_ATTN_ORDER ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z;
-    const int Hq = heads * 128;
-    if (past_dev) past = min(*past_dev, ctx_max - S);
-    const int kv_len = past + S;
-
-    const int q = qb * (LNW * 16) + wave * 16 + l15;      // query row inside this call
-    const int qc = min(q, S - 1);
-    const int qpos = past + q;                            // absolute position: keys <= qpos are visible
-    const uint16_t* qp = qkv + ((size_t)b * S + qc) * 3 * Hq + h * 128;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 32 + g * 8);
-
-    const uint16_t* kbase = kc + ((size_t)b * heads + h) * ctx_max * 128;
-    const uint16_t* vbase = vc + ((size_t)b * heads + h) * ctx_max * 128;
-    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
-
-    const int q_last = min(qb * (LNW * 16) + LNW * 16 - 1, S - 1);
-    const int wave_qpos_max = past + min(qb * (LNW * 16) + wave * 16 + 15, S - 1);   // tiles beyond it are fully masked for this wave
-    const int kv_end = min(past + q_last + 1, kv_len);
-    const int ntiles = (kv_end + 63) >> 6;
-
-    const float sc = 0.08838834764831845f * LOG2E;        // 128^-0.5 * log2(e)
-    float m = NEG_BIG, l = 0.f;
-    f32x4 o[8];
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Register-staged K/V tiles (async-stage split): the global loads of tile t+1 are issued right
-    // before tile t's MFMAs and written to LDS after the next barrier, so HBM/L2 latency hides under
-    // compute instead of sitting between two barriers.
-    constexpr int NT = LNW * 64, KCH = 1024 / NT;           // K chunks per thread; V^T: thread <-> (key pair, 4096/NT d)
-    constexpr int VD = 4096 / NT;                           // d elements per thread (16 at 4 waves, 8 at 8 waves)
-    const int p_v = tid & 31, dg_v = tid >> 5;
-    u32x4 kreg[KCH], va0, va1, vb0, vb1;
-    bool okreg = false;
-    auto load_tile = [&](int kt) {
-        const int kv0 = kt * 64;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int s = i * NT + tid, row = s >> 4, c = s & 15;
-            kreg[i] = (kv0 + row < kv_len) ? *(const u32x4*)(kbase + (size_t)(kv0 + row) * 128 + c * 8) : z;
-        }
-        const int r0 = kv0 + 2 * p_v, r1 = r0 + 1;
-        va0 = va1 = vb0 = vb1 = z;
-        if (r0 < kv_len) {
-            const uint16_t* x = vbase + (size_t)r0 * 128 + dg_v * VD;
-            va0 = *(const u32x4*)x;
-            if (VD == 16) va1 = *(const u32x4*)(x + 8);
-        }
-        if (r1 < kv_len) {
-            const uint16_t* x = vbase + (size_t)r1 * 128 + dg_v * VD;
-            vb0 = *(const u32x4*)x;
-            if (VD == 16) vb1 = *(const u32x4*)(x + 8);
-        }
-        const int kvl = kv0 + lane;
-        okreg = kvl < kv_len && (!kvld || kvld[kvl] != 0);
-    };
-    if (ntiles > 0) load_tile(0);
-
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int kv0 = kt * 64;
-        __syncthreads();                                  // previous tile fully consumed
-        // ---- registers -> LDS: K row-major swizzled, V transposed ----------------------------------
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int s = i * NT + tid, row = s >> 4, c = s & 15;
-            *(u32x4*)(sK + row * 256 + ((c ^ (row & 15)) << 4)) = kreg[i];
-        }
-#pragma unroll
-        for (int dd = 0; dd < VD; ++dd) {
-            const uint32_t w = sel16(va0, va1, dd) | (sel16(vb0, vb1, dd) << 16);
-            *(uint32_t*)(sVt + (dg_v * VD + dd) * LVT_STRIDE + 2 * p_v) = w;
-        }
-        // key validity of this tile as a 64-bit wave mask (lane <-> key kv0 + lane)
-        const unsigned long long vmask = __ballot(okreg);
-        __syncthreads();
-        if (kt + 1 < ntiles) load_tile(kt + 1);           // in flight while this tile is multiplied
-        if (kv0 > wave_qpos_max) continue;                // every key of this tile is in this wave's future (wave-uniform)
-
-        // ---- S^T tile ---------------------------------------------------------------------------
-        f32x4 s[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 256 + (((kk * 4 + g) ^ l15) << 4));
-                acc = mfma16(kf, qf[kk], acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kl = t * 16 + 4 * g + r;
-                const bool vis = ((vmask >> kl) & 1ull) && (kv0 + kl <= qpos);
-                s[t][r] = vis ? acc[r] * sc : NEG_BIG;
-            }
-        }
-        // ---- online softmax ------------------------------------------------------------------------
-        float rm = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rm = fmaxf(rm, s[t][r]);
-        rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
-        rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
-        const float mn = fmaxf(m, rm);
-        const float alpha = sm_exp2(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = sm_exp2(s[t][r] - mn);
-                s[t][r] = p;
-                ps += p;
-            }
-        l = l * alpha + ps;                                // per-lane partial; the 4 g-lanes share alpha
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
-        // ---- O^T += V^T P^T ------------------------------------------------------------------------
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            u32x4 pk;
-            pk[0] = pack_h2(s[2 * c][0], s[2 * c][1]);
-            pk[1] = pack_h2(s[2 * c][2], s[2 * c][3]);
-            pk[2] = pack_h2(s[2 * c + 1][0], s[2 * c + 1][1]);
-            pk[3] = pack_h2(s[2 * c + 1][2], s[2 * c + 1][3]);
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const uint16_t* vp = sVt + (dt * 16 + l15) * LVT_STRIDE + 32 * c + 4 * g;
-                const u32x2 lo = *(const u32x2*)vp;
-                const u32x2 hi = *(const u32x2*)(vp + hi16);
-                u32x4 vv;
-                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = hi[0]; vv[3] = hi[1];
-                o[dt] = mfma16(__builtin_bit_cast(bf16x8, vv), pf, o[dt]);
-            }
-        }
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (q < S) {
-        const float inv = 1.f / l;
-        uint16_t* op = out + ((size_t)b * S + q) * Hq + h * 128 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            u32x2 pk;
-            pk[0] = pack_h2(o[dt][0] * inv, o[dt][1] * inv);
-            pk[1] = pack_h2(o[dt][2] * inv, o[dt][3] * inv);
-            *(u32x2*)(op + dt * 16) = pk;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Decode attention (S = 1): one workgroup per (head, batch), HBM-bound on the KV cache
-// (kv_len * 512 bytes per head).  Phase 1: thread <-> key, q.k over 128 d with 16-byte K loads, scores
-// to LDS; phase 2: block max / sum; phase 3: 16 threads share a V row (8 d each), 16 keys per pass,
-// fp32 partial sums reduced through LDS.
-// ---------------------------------------------------------------------------------------------
 // ---- round 3: the same attention with K / V tiles by LDS-DMA, V through ds_read_b64_tr_b16, two workgroups per CU ---------
 // llama_attn_kernel holds 160-222 registers (one 8-wave workgroup per CU; PMC: half of all wave cycles parked) and pays two
 // barriers per 64-key tile because its tiles pass through registers (K) and a register transpose (V).  Here a tile is 16 + 16
@@ -878,6 +433,12 @@ __global__ void __launch_bounds__(LNW * 64, 4) llama_attn2_kernel(const uint16_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode attention (S = 1): one workgroup per (head, batch), HBM-bound on the KV cache
+// (kv_len * 512 bytes per head).  Phase 1: thread <-> key, q.k over 128 d with 16-byte K loads, scores
+// to LDS; phase 2: block max / sum; phase 3: 16 threads share a V row (8 d each), 16 keys per pass,
+// fp32 partial sums reduced through LDS.
+// ---------------------------------------------------------------------------------------------
 constexpr int DEC_MAX_CTX = 8192;
 
 __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ kc,
@@ -1253,6 +814,10 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     }
 }
 
+// the two kernels that are NOT the default of their op (kept for A/B runs and as each other's bit-identity witness:
+// VLY_VIT_ATTN=4 -> vit_attn4_kernel, VLY_LLAMA_ATTN=1 -> llama_attn_kernel)
+#include "attention_ab.inc"
+
 }  // namespace
 
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
@@ -1293,7 +858,7 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
         return vly_check_launch("vly_llama_attention(decode)");
     }
     // llama_attn2_kernel (LDS-DMA tiles, two workgroups per CU: 59.3 -> 45.0 us per 13B layer at B = 8, S = 336; 77 -> 53 at S = 1024,
-    // profiles/r03/r03_llama_attn2.txt).  VLY_LLAMA_ATTN=1 keeps the register-staged llama_attn_kernel (A/B runs and its tests).
+    // profiles/history/r03/r03_llama_attn2.txt).  VLY_LLAMA_ATTN=1 keeps the register-staged llama_attn_kernel (A/B runs and its tests).
     static const int ver = getenv("VLY_LLAMA_ATTN") ? atoi(getenv("VLY_LLAMA_ATTN")) : 2;
     if (ver == 2 && (size_t)ctx_max * 256 < ((size_t)1 << 32)) {          // (per-head descriptors: no limit on the cache as a whole)
         hipLaunchKernelGGL(llama_attn2_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,

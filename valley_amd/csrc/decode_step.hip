@@ -4,13 +4,19 @@
 // Round 3's step was five launches per layer (norm+q|k|v GEMV, split attention, merge+o GEMV, norm+gate|up GEMV, down GEMV):
 // 118 us per 13B layer of which the weight stream itself is 92 us at the 6.9 TB/s the longest GEMV reaches — the rest is
 // five kernel boundaries (MI355X_MICROARCH "boundary": 1.2-1.9 us each) and, at every one of them, a drained memory pipe that
-// has to fill again.  Here ONE 16-wave workgroup per CU walks the five phases of every layer, separated by a grid barrier,
-// and the weight stream never stops: a workgroup is four 256-thread groups, each of which owns a strided sequence of weight
-// UNITS (a row pair, or one row of the K = I down projection) and keeps TWO units in flight in registers; the units of the
-// NEXT phase are requested before the barrier that ends the current one (they depend on nothing a barrier orders), so the
-// barrier's latency, the activation hand-off and the norm run under ~200 KB per CU of weights already in flight
-// (MI355X_MICROARCH "prefetch-credit": what a run-ahead loader saves per dependency edge).  The attention phase uses 160 of
-// the 1024 groups; every other group spends it fetching the o projection.
+// has to fill again.  Here ONE 8-wave workgroup per CU (256 registers per lane) walks the five phases of every layer,
+// separated by a grid barrier: a workgroup is two 256-thread groups, each of which owns a strided sequence of weight UNITS (a
+// row pair, or one row of the K = I down projection) and keeps NS = 3 units in flight in registers (7 x 16 bytes per thread
+// each: 172 KB per CU); the first units of the NEXT phase are requested in the last round of the current one (they depend on
+// nothing a barrier orders).
+//
+// MEASURED (13B, 256 tokens, profiles/r04/r04_decode_persistent_*): 198.7 tokens/s against the launches' 208-212 — NOT the
+// default (VALLEY_DECODE_PERSISTENT=1 selects it).  Its weight loops do stream at 6.9-7 TB/s (82 of 127 us per layer), but a
+// phase boundary inside the launch costs no less than a kernel boundary: workgroups arrive 3.5-8 us apart (static work split),
+// the barrier itself takes 1.5-2 us, the activation hand-off + norm 1.4-2.8 us, the store drain 1-2 us; and the requests
+// issued ahead of the barrier land before it ends, so they shorten the next loop instead of covering the gap
+// (tools/decode_phase_times.py prints the anatomy).  What it would take: dynamic unit claims against the arrival skew and an
+// LDS-DMA ring that keeps requesting across the barrier (MI355X_MICROARCH "engine-vs-launches").
 //
 // Arithmetic: per output element exactly that of the launches it replaces — the same chunk-to-thread mapping, the same wave
 // sums, the same fixed-order sum over four waves, norm_row_kernel's norm, decode_split_kernel's attention,
@@ -33,7 +39,7 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr int SPLITS = VLY_DECODE_SPLITS;
-constexpr int WG_THREADS = 512;          // two 256-thread groups, 256 registers per lane: FOUR units in flight per thread
+constexpr int WG_THREADS = 512;          // two 256-thread groups, 256 registers per lane
 constexpr int NGRP = WG_THREADS / 256;
 #ifndef VLY_DL_SLOTS
 #define VLY_DL_SLOTS 3

@@ -50,7 +50,7 @@ int vly_tile_group_height(int M, int N, int K, int tiles_m, int tiles_n, int BM,
     // (gm = 6), fc2 286 -> 276 us (gm = 8); q|k|v and out-proj flat; gm = 1 is the WORST choice for the Llama shapes
     // ... except when tiles_n divides the 8 XCDs: n-fastest then hands every XCD ONE column block of W for the whole launch
     // (workgroup i -> XCD i % 8), which stays in its 4 MiB L2 — fc2 32768x1024x4096 in the c3 bench: 1172 TF n-fastest,
-    // 1121 TF grouped (profiles/r02/r02_ab_tile_group.txt)
+    // 1121 TF grouped (profiles/history/r02/r02_ab_tile_group.txt)
     if (tiles_n <= 8 && 8 % tiles_n == 0 && !vly_tile_order_m_fast(M, N, K, tiles_m, tiles_n)) return 1;
     const double conc = 32.0 * wg_per_cu;
     int gm = (int)(sqrt(conc * BN / BM) + 0.5);
@@ -105,7 +105,7 @@ VLY_DEVICE void mma_ktile(f32x4 (&acc)[MI][NI], const char* pa, const char* pw, 
 // Chunk swizzle of the LDS stage rows, applied to the staging SOURCE address and to the fragment reads: chunk ^= row & 7,
 // conflict-free for the 16-row fragments of the 16x16x32 MFMA.
 
-// placement constants of the 4-wave loops (A/B of other placements: profiles/r02/r02_ab_4wave.txt)
+// placement constants of the 4-wave loops (A/B of other placements: profiles/history/r02/r02_ab_4wave.txt)
 constexpr int P8_BAR_GAP = 8;       // barrier A this many MFMAs (~140 clk, a ds_read round trip) after the last read of phase 1
 constexpr int P8_RD2_START = 1;     // phase 2: reads of the next tile's K step 0 after MFMA 1, 3, 5, ...
 constexpr int P8_RD2_STRIDE = 2;
@@ -854,7 +854,7 @@ VLY_DEVICE void acc_read_pairs(const f32x4& a, f32x2& even, f32x2& odd) {
 
 // ================= persistent 4-wave kernel: the PIPE 8 loop running THROUGH tile boundaries ==========================
 // One workgroup per CU walks tiles bid, bid + G, bid + 2G, ...  Measured on the one-tile-per-workgroup kernel
-// (profiles/r02/r02_ab_4wave.txt, "noepi"): without its epilogue the ViT fc1 GEMM (K = 1024: 16 K tiles per output tile)
+// (profiles/history/r02/r02_ab_4wave.txt, "noepi"): without its epilogue the ViT fc1 GEMM (K = 1024: 16 K tiles per output tile)
 // runs 213 instead of 292 us — the stores of one round, the workgroup turn-around and the first loads of the next round
 // are all exposed when every CU holds ONE workgroup (128 KB of LDS, 512 registers per wave).  Here
 //   * the LOAD cursor runs two K tiles ahead of the COMPUTE cursor across tile boundaries (it owns the per-lane offsets and
@@ -872,7 +872,7 @@ VLY_DEVICE void acc_read_pairs(const f32x4& a, f32x2& even, f32x2& odd) {
 // 492 units = 1.92 rounds of a third of a tile), the (slice, tile) units run FIRST, slice-major, one per workgroup and round,
 // then every workgroup walks its whole tiles as before.  Slices are UNIFORM on purpose: all workgroups of a round walk the
 // same K range in step, so tiles of one row / column still share their A / W panel in the XCD's L2 (contiguous stream-K
-// ranges — every workgroup at its own k — measured 1.1-1.8x SLOWER than no split at all: profiles/r03/r03_p4_streamk.jsonl).
+// ranges — every workgroup at its own k — measured 1.1-1.8x SLOWER than no split at all: profiles/history/r03/r03_p4_streamk.jsonl).
 // Slices 0 .. S-2 are CONTRIBUTORS: fp32 accumulators to the unit's slab, agent-scope release, flag.  The last slice OWNS the
 // tile: it waits for the S - 1 flags (their units ran in the same or an earlier round: no deadlock while the grid is
 // resident, spins are bounded) and its epilogue adds the slabs to every accumulator block it reads — the accumulators
@@ -1411,7 +1411,7 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
     const int tiles = tm * tn;
     // SK: slices per remainder tile — the S that packs S x rem8 units into the fewest rounds per slice (1 = no split), within
     // the slab capacity, at least two K tiles per slice, +6 % of a tile per extra slice for the hand-off chain and the shallower
-    // loop (measured: 7B gate|up on 192-row tiles 206 / 216 / 242 us at S = 2 / 4 / 8, profiles/r03/r03_p4_splitk_slices.jsonl)
+    // loop (measured: 7B gate|up on 192-row tiles 206 / 216 / 242 us at S = 2 / 4 / 8, profiles/history/r03/r03_p4_splitk_slices.jsonl)
     int sk_S = 1;
     if constexpr (SK) {
         const int rem = tiles % cus, rem8 = (rem + 7) & ~7, nk = K / BK;

@@ -137,7 +137,7 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
     bool four = false;
     if (split && MR <= 2 && N >= 8) {
         const int cus = cu_count();
-        // (measured, profiles/r03/r03_gemv_rows_per_wg.jsonl: 5120 x 13824 25.3 -> 23.9 us; 5120 x 5120 10.8 -> 10.9: short rows
+        // (measured, profiles/history/r03/r03_gemv_rows_per_wg.jsonl: 5120 x 13824 25.3 -> 23.9 us; 5120 x 5120 10.8 -> 10.9: short rows
         // gain nothing, so K >= 8192 as well)
         four = pin ? pin == 4 : K >= 8192 && balance((N + 3) / 4, cus * 5) > balance((N + 1) / 2, cus * 8) + 0.02f;
     }
@@ -177,7 +177,7 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
 // vly_rmsnorm + vly_gemv_bf16 — into LDS, and the GEMV loop reads x from LDS instead of re-fetching it through the vector
 // cache beside the weight stream.  Measured (13B decode, 256 tokens, same box, interleaved): 201.5 -> 207.0 tokens/s; three
 // structures of the prologue (five 256-thread workgroups per CU each normalising for itself, with and without a second
-// pair in flight, and this one) all land within 0.3 % of each other — profiles/r03/r03_decode_fuse_norm.txt.
+// pair in flight, and this one) all land within 0.3 % of each other — profiles/history/r03/r03_decode_fuse_norm.txt.
 // ---------------------------------------------------------------------------------------------
 template <int CH>
 struct PairRegs {
@@ -272,7 +272,10 @@ __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict
         }
     };
     PairRegs<CH> pa, pb;
-    const int first = ((int)blockIdx.x * 4 + grp) * 2, stride = gridDim.x * 4 * 2;
+    // pair p = cu + CUs * (grp + 4 t): a CU's four groups share its pairs round-robin, so every CU streams the same number of
+    // rows (round 3 gave group (cu, grp) the pairs 4 cu + grp + 4 CUs t: with 2560 pairs — the 13B o projection — the groups of
+    // CUs 0..127 made three trips, those of CUs 128..255 two, and half the chip sat out the last third of the launch)
+    const int first = (grp * (int)gridDim.x + (int)blockIdx.x) * 2, stride = gridDim.x * 4 * 2;
     if constexpr (PRO == 1) {
         // x = the merge of vly_decode_attention_split's partials (H = partials, ldh = heads): all 1024 threads, one or two
         // 4-wide units each — unit u is dims 4 (u & 31) .. + 3 of head u >> 5 — loads first, then the weights
@@ -371,7 +374,7 @@ __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict
     // trips are counted for the workgroup (group 0 owns the lowest pair index, so its count is the largest): every group
     // passes every barrier, pairs past N are loaded from W[0..7] and dropped
 #pragma unroll 1
-    for (int n0 = first, nb = (int)blockIdx.x * 8; nb < N; n0 += 2 * stride, nb += 2 * stride) {
+    for (int n0 = first, nb = (int)blockIdx.x * 2; nb < N; n0 += 2 * stride, nb += 2 * stride) {
         const int n1 = n0 + stride;
         load_pair(pb, n1);
         reduce_pair(pa, n0, red[0][grp]);

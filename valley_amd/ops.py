@@ -285,11 +285,11 @@ def gemm_mfma_qkv_rope(a, w, qkv, rope: "RopeKV", tile_hint=0):
 
 # Off by default: measured neutral twice — on the persistent 4-wave tiles (register epilogue: the rotation partner of a column is
 # in the same lane) q|k|v 304.8 us + rope_kv 27 us vs 327.3 us fused, c3 1652 -> 1656 frames/s; earlier on the LDS epilogue
-# (c3, same box, profiles/r02/r02_ab_rowsplit_rope.txt: q|k|v 355.7 us + rope_kv 27 us vs
+# (c3, same box, profiles/history/r02/r02_ab_rowsplit_rope.txt: q|k|v 355.7 us + rope_kv 27 us vs
 # 373.5 us fused, but the step moved 87.75 -> 88.22 ms, inside the noise) — the epilogue's 16 dependent cos / sin fetches
 # per thread cost what the removed pass over q|k|v saved.  Kept as a tested option (bit-identical to the unfused pair).
 # Round 3, behind the LDS-DMA attention kernel: c3 54.2 -> 53.9 ms of prefill with the fused form, twice in a row
-# (profiles/r03/r03_fuse_rope_again.txt) — small, but free.  "auto" (default) fuses exactly the shapes whose fused decision
+# (profiles/history/r03/r03_fuse_rope_again.txt) — small, but free.  "auto" (default) fuses exactly the shapes whose fused decision
 # ships in the tuned table (i.e. was measured: the 13B q|k|v at M = 2688); 1 = always (new shapes are tuned online), 0 = never.
 FUSE_ROPE = os.environ.get("VALLEY_FUSE_ROPE", "auto")
 
@@ -513,7 +513,7 @@ def row_split(M: int) -> int:
     with 4, 12 or 16 n-tiles the main launch is a whole number of rounds on 256 CUs) and the remaining F rows run as
     their own small launch right behind it.  Tall problems only; VALLEY_ROW_SPLIT=0 disables.
 
-    Measured at F = 128 (c3, profiles/r02/r02_ab_rowsplit_rope.txt): the main launches speed up — fc1 793 -> 899, fc2 990 -> 1158,
+    Measured at F = 128 (c3, profiles/history/r02/r02_ab_rowsplit_rope.txt): the main launches speed up — fc1 793 -> 899, fc2 990 -> 1158,
     out-proj 778 -> 897 TFLOP/s, q|k|v unchanged.  On the tile kernels the F-row remainder is one tile row's latency-bound
     K loop (14-17 us at K = 1024, 33 us at K = 4096: all of the gain); on vly_gemm_skinny_bf16 it costs 12 (fc1), 22 (fc2)
     and 9 us (out-proj), which nets a gain for all three — so vision_tower.layer_forward splits fc1, fc2 AND out-proj, and
@@ -521,7 +521,7 @@ def row_split(M: int) -> int:
     Round 3: with the persistent kernels the split pays from F = 32 frames on (M = 8224: fc1 81.9 -> 63.7 us, fc2 75.2 -> 65.6,
     out-proj 29.9 -> 25.0 per layer against 36 us of remainder kernels — which the side-stream schedule of
     vision_tower.layer_forward_2s takes off the critical path at these sizes: ViT 6.88 -> 6.62 ms at 32 frames, 12.24 -> 11.72 at
-    64; profiles/r03/r03_vit_two_stream.jsonl)."""
+    64; profiles/history/r03/r03_vit_two_stream.jsonl)."""
     if not ROW_SPLIT or GEMM_MODE != "tuned" or M < ROW_SPLIT_MIN or M % 4096 == 0:
         return M
     return M // 4096 * 4096

@@ -42,7 +42,7 @@ def _dev(t, device, dtype):
 
 VIT_CHUNK = int(os.environ.get("VALLEY_VIT_CHUNK", "256"))
 # Remainder rows of the row-split GEMMs on a side stream (layer_forward_2s): "auto" (default) below 32768 rows, where it
-# measured +2..5 % (profiles/r03/r03_vit_two_stream.jsonl); at 128+ frames it measured equal (the main stream's GEMMs leave
+# measured +2..5 % (profiles/history/r03/r03_vit_two_stream.jsonl); at 128+ frames it measured equal (the main stream's GEMMs leave
 # no registers for a co-resident kernel and its LayerNorm windows are short against 42 us of remainders), so the headline
 # configuration stays on one stream.  "1" / "0" force it on / off.
 TWO_STREAM = {"1": True, "0": False}.get(os.environ.get("VALLEY_VIT_TWO_STREAM", "auto"), None)
@@ -194,7 +194,7 @@ class HipCLIPVisionTower:
         # M = F*257 rows: the *_split forms cut a launch at a multiple of 4096 rows so that the main launch is a whole
         # number of workgroup rounds and hand the F-row remainder to the latency-optimised skinny kernel (ops.row_split;
         # q|k|v gains nothing from it: measured in round 2 and again in round 3 with the skinny remainder kernel — ViT 21.73 ->
-        # 22.13 ms per 128 frames with q|k|v split, profiles/r03/r03_vit_qkv_split.jsonl)
+        # 22.13 ms per 128 frames with q|k|v split, profiles/history/r03/r03_vit_qkv_split.jsonl)
         d2 = ws["delta2"] if ops.gemm2_split(ws["att"], L["w_o"], ws["delta"], ws["delta2"], L["b_o"]) == 2 else None
         ops.add_norm(h, ws["delta"], L["ln2_g"], L["ln2_b"], eps, out=ws["x"], delta2=d2)
         ops.gemm_split(ws["x"], L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU, out=ws["mlp"])
