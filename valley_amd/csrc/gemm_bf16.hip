@@ -42,7 +42,8 @@ int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n) {
 // VLY_TILE_GM=<n> overrides (A/B measurements).
 int vly_tile_group_height(int M, int N, int K, int tiles_m, int tiles_n, int BM, int BN, int wg_per_cu) {
     static const int forced = getenv("VLY_TILE_GM") ? atoi(getenv("VLY_TILE_GM")) : 0;
-    if (forced > 0) return forced < tiles_m ? forced : tiles_m;
+    static const int forced_max_m = getenv("VLY_TILE_GM_MAXM") ? atoi(getenv("VLY_TILE_GM_MAXM")) : 0x7fffffff;   // (only shapes up to M rows)
+    if (forced > 0 && M <= forced_max_m) return forced < tiles_m ? forced : tiles_m;
     static const bool grouped = !(getenv("VLY_TILE_GROUPED") && atoi(getenv("VLY_TILE_GROUPED")) == 0);
     if (!grouped) return vly_tile_order_m_fast(M, N, K, tiles_m, tiles_n) ? tiles_m : 1;      // round-1 behaviour
     // the near-square block also serves the shapes whose byte count prefers n-fastest (tall A, small W — the ViT GEMMs):
