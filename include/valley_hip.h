@@ -130,8 +130,9 @@ int vly_pack_weight_bf16(const void *W, void *packed, int N, int K, int ldw, voi
  *   tiles, one workgroup per CU) with its REMAINDER ROUND split along K — the tiles past the last whole round of CUs
  *   are cut into S equal K slices (S picked per shape so that S x remainder fills whole rounds), run first; the
  *   slices of a tile hand a running fp32 sum down a chain of slabs in `workspace`, the last one runs the epilogue.
- *   These two hints also take ldw = VLY_LDW_PACKED64.  Shipped for the 7B prefill shapes (M = 1312): gate|up 216.8 ->
- *   194 us, q|k|v 138.6 -> 125 us. */
+ *   These hints also take ldw = VLY_LDW_PACKED64.  Shipped for the 7B prefill shapes (M = 1312): gate|up 216.8 ->
+ *   194 us, q|k|v 138.6 -> 125 us.  tile_hint 297 (round 4): the same for the 256 x 256 tile (hint 197) — the owning slice adds
+ *   the chain's running sum to its accumulators with exact f32-input MFMAs before a plain epilogue. */
 int    vly_gemm_bf16_streamk(const void *A, const void *W, const float *bias, const float *residual, void *C,
                              int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                              int epilogue, int out_dtype, int tile_hint,

@@ -618,6 +618,10 @@ def test_gemm_packed_weights_bit_identical(tile):
 
 
 @pytest.mark.parametrize("M,N,K,epi,tile", [
+    (2688, 27648, 5120, 2, 297),      # 13B gate|up on 256-row tiles (round 4): 4 whole rounds + 164 tiles in three slices, summed on the matrix cores
+    (2816, 27648, 5120, 2, 297),      # configs[3]'s per-GPU shape of the same GEMM
+    (2688, 15360, 5120, 0, 297), (2688, 5120, 13824, 0, 297), (1312, 22016, 4096, 2, 297),
+    (771, 1000, 256, 1, 297), (1000, 3000, 640, 0, 297),
     (2688, 27648, 5120, 2, 298),      # 13B gate|up on 224-row tiles: 5 whole rounds + 16 tiles, eight slices each
     (2688, 15360, 5120, 0, 298),      # 13B q|k|v: 2 rounds + 208 tiles (no split pays: S = 1)
     (2688, 5120, 13824, 0, 298),      # 13B down: 240 tiles on 256 CUs, 216 K tiles per tile

@@ -893,6 +893,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                int tiles_m, int tiles_n, int gm, RopeArgs rp, float* __restrict__ slabs, unsigned* __restrict__ flags,
                unsigned epoch, int sk_S) {
     constexpr int WM = BM / 2, WN = BN / 2, NT = 256;
+    constexpr bool SKT = SK && BM != 256;       // the owner's epilogue adds slab terms (256-row tiles fold them into the accumulators instead)
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
     constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT, NS = PA + PW;
@@ -1118,6 +1119,47 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 }
                 __syncthreads();
                 nfol = 1;
+                if constexpr (BM == 256) {
+                    // 256-row tiles (round 4, hint 297): the chain's running sum goes INTO the accumulators, by the matrix cores —
+                    // D = I_k . P_k + C with the exact f32-input MFMA (v_mfma_f32_16x16x4_f32, 1.0 x p: one rounding, that of
+                    // acc + p) — so the owner's epilogue is the plain one.  With 256 accumulators per lane the epilogue had no 32
+                    // registers for the slab terms of a fragment row (hipcc spilled them behind vmcnt(0) waits: 3-8 % SLOWER than
+                    // no split, round 3); here the terms pass through registers the K loop's fragments have just left, four
+                    // dwords per block: lane (g, l15) needs P[4 k + g][l15], which the contributor's lane (k, l15) stored as
+                    // element g of its float4.  The accumulators are still only ever written by MFMAs.  256 x 32 cycles = 4 us per
+                    // owner tile, once per workgroup and launch.
+                    if (!contributor) {
+                        const char* prevb = (const char*)(slabs + (size_t)(cc.u - sk_rem8) * (BM * BN));
+                        float idk[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) idk[kk] = (l15 == 4 * kk + g) ? 1.f : 0.f;
+                        asm volatile("s_nop 1" : "+v"(idk[0]), "+v"(idk[1]), "+v"(idk[2]), "+v"(idk[3]));       // (VALU write -> MFMA operand)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            uint32_t lo = (uint32_t)((i * NI * NT + (tid & ~63) + l15) * 16 + g * 4);     // (opaque: see the stores below)
+                            asm volatile("" : "+v"(lo));
+#pragma unroll
+                            for (int jh = 0; jh < NI; jh += 4) {     // four blocks (16 loads) at a time
+                                float pv[4][4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int kk = 0; kk < 4; ++kk) pv[j][kk] = *(const float*)(prevb + lo + (jh + j) * (NT * 16) + kk * 256);
+                                // (asm with the accumulator block tied "+a": the builtin lets the allocator put the result in NEW
+                                // accumulation registers, and on the SwiGLU instantiation it then spills accumulators to scratch; k
+                                // outer, block inner: four independent accumulators between two MFMAs of one chain)
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[i][jh + j]) : "v"(idk[kk]), "v"(pv[j][kk]));
+                            }
+                        }
+                        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");      // the last MFMAs' results before any v_accvgpr_read of the epilogue
+                        nfol = 0;
+                    }
+                }
             }
             if (contributor) {
                 // publish the partial sums (lane-linear float4 image, fully coalesced); no epilogue.
@@ -1150,6 +1192,14 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 if (tid == 0) __hip_atomic_store(flags + cc.u, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 nfol = 0;
             }
+            if constexpr (BM == 256) {
+                // where the three paths (owner / owner after the add / contributor) meet, the accumulators ARE in the accumulation
+                // registers; say so (left alone, hipcc resolves the merge in VGPRs on the SwiGLU instantiation: 353 spills)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) asm volatile("" : "+a"(acc[i][j]));
+            }
         }
         // SK owners (nfol = 1): the chain's running sum for the blocks of the current fragment row sits in sk_ld[]; the epilogue
         // re-issues a block's load for row i + 1 as soon as it has consumed it (sk_next), so the reads of one row fly under
@@ -1166,7 +1216,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 if (j >= j0 && j < j0 + n) sk_ld[j] = *(const f32x4*)(sl + j * (NT * 16));
         };
         [[maybe_unused]] auto slab_term = [&](int, int j) { return nfol ? sk_ld[j] : f32x4{0.f, 0.f, 0.f, 0.f}; };
-        if constexpr (SK) sk_next(0, 0, NI);
+        if constexpr (SKT) sk_next(0, 0, NI);
         // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
         // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
         if (!(SK && contributor)) {
@@ -1250,13 +1300,13 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         f32x2 gt[4], up[4], e[4];
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            if constexpr (SK) {
+                            if constexpr (SKT) {
                                 const f32x4 v = acc_read(acc[i][4 * jq + jj]) + slab_term(i, 4 * jq + jj);
                                 gt[jj] = f32x2{v[0], v[2]};
                                 up[jj] = f32x2{v[1], v[3]};
                             } else acc_read_pairs(acc[i][4 * jq + jj], gt[jj], up[jj]);
                         }
-                        if constexpr (SK) sk_next(i + 1, 4 * jq, 4);
+                        if constexpr (SKT) sk_next(i + 1, 4 * jq, 4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) e[q] = gt[q] * -1.4426950408889634f;
 #pragma unroll
@@ -1286,7 +1336,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         // transcendental that consumes it (and back) the hardware wants a wait state, which independent
                         // work fills (one chain at a time cost 487 s_nop per tile)
                         f32x4 v0 = acc_read(acc[i][2 * jp]) + bv[2 * jp], v1 = acc_read(acc[i][2 * jp + 1]) + bv[2 * jp + 1];
-                        if constexpr (SK) {
+                        if constexpr (SKT) {
                             v0 += slab_term(i, 2 * jp);
                             v1 += slab_term(i, 2 * jp + 1);
                             sk_next(i + 1, 2 * jp, 2);
@@ -1338,7 +1388,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             for (int i = 0; i < MI; ++i) {
                 __builtin_amdgcn_sched_barrier(0);
                 [[maybe_unused]] f32x4 skc[NI];                      // (SK owners: this row's slab terms; the next row's loads leave now)
-                if constexpr (SK) {
+                if constexpr (SKT) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) skc[j] = slab_term(i, j);
                     sk_next(i + 1, 0, NI);
@@ -1352,7 +1402,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         for (int j = 0; j < NI; ++j)
                             if (ncol + j * 16 < N) {
                                 f32x4 v = acc_read(acc[i][j]) + bv[j] + *(const f32x4*)(rrow + j * 16);
-                                if constexpr (SK) v += skc[j];
+                                if constexpr (SKT) v += skc[j];
                                 *(f32x4*)(crow + j * 16) = v;
                             }
                     } else {
@@ -1360,7 +1410,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                         for (int j = 0; j < NI; ++j)
                             if (ncol + j * 16 < N) {
                                 f32x4 v = acc_read(acc[i][j]) + bv[j];
-                                if constexpr (SK) v += skc[j];
+                                if constexpr (SKT) v += skc[j];
                                 *(f32x4*)(crow + j * 16) = v;
                             }
                     }
@@ -1511,7 +1561,7 @@ static int pick_tile(int M, int N) {
     return c2x1 <= c128 ? 3 : 2;
 }
 
-// The split-K-remainder form of the persistent kernel, for vly_gemm_bf16_streamk (gemm_streamk.hip): tile 298 / 299 = 224 / 192
+// The split-K-remainder form of the persistent kernel, for vly_gemm_bf16_streamk (gemm_streamk.hip): tile 297 / 298 / 299 = 256 / 224 / 192
 // rows x 256 columns.  Returns 1 when the shape cannot take the persistent kernel's vector stores (the caller reports it).
 __attribute__((visibility("hidden"))) int valley_p4_streamk(int tile, const void* A, const void* W, const float* bias, const float* R,
                                                             void* C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epi,
@@ -1521,7 +1571,7 @@ __attribute__((visibility("hidden"))) int valley_p4_streamk(int tile, const void
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     cus = cus > 0 ? cus / 8 * 8 : 256;
-    const int bm = tile == 298 ? 224 : 192;
+    const int bm = tile == 297 ? 256 : tile == 298 ? 224 : 192;
     if (!ws || ws_bytes < FLAG_BYTES + (size_t)bm * 256 * 4) {
         vly_set_error("vly_gemm_bf16_streamk: workspace too small (%zu bytes)", ws_bytes);
         return -22;
@@ -1531,9 +1581,10 @@ __attribute__((visibility("hidden"))) int valley_p4_streamk(int tile, const void
     if (K < 128 || K % BK) { vly_set_error("vly_gemm_bf16_streamk: the persistent tiles need K >= 128"); return -22; }
     const P4SkArgs sk{(float*)((char*)ws + FLAG_BYTES), (unsigned*)ws, epoch, cap};
     int rc;
-    // (256-row tiles have no split-K form: with 256 accumulators per lane the owner's epilogue has no 32 registers for the
-    // chain's slab terms — hipcc spills 66-164 — and the kernel measured 3-8 % slower than the plain one on every shape)
-    if (tile == 298) rc = launch_p4<224, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
+    // (256-row tiles, hint 297, round 4: the owner folds the chain's sum into its accumulators with f32 MFMAs before a plain
+    // epilogue — with 256 accumulators per lane the epilogue has no 32 registers for slab terms; see the kernel)
+    if (tile == 297) rc = launch_p4<256, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
+    else if (tile == 298) rc = launch_p4<224, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
     else rc = launch_p4<192, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
     if (rc == 1) {
         vly_set_error("vly_gemm_bf16_streamk: tile %d needs 16-byte aligned rows of whole 8-column chunks and no residual for bf16 outputs", tile);

@@ -399,7 +399,7 @@ int pick_sk_tile(int M, int N, int K) {
 
 extern "C" size_t vly_gemm_streamk_workspace_bytes(void) {
     // worst case over the configurations: G x BM x BN fp32 slabs + flags
-    // (2 x: the persistent kernel's split-K remainder, hints 298 / 299, keeps one slab per contributor UNIT — up to S - 1 per
+    // (2 x: the persistent kernel's split-K remainder, hints 297 / 298 / 299, keeps one slab per contributor UNIT — up to S - 1 per
     // remainder tile; with less it settles for fewer slices)
     const size_t g1 = (size_t)num_cus();
     const size_t a = 2 * g1 * 256 * 256 * 4, b = 2 * g1 * 128 * 128 * 4;
@@ -413,8 +413,8 @@ extern "C" int vly_gemm_bf16_streamk(const void* A, const void* W, const float* 
                                      int out_dtype, int tile_hint, void* workspace, size_t workspace_bytes,
                                      unsigned epoch, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { vly_set_error("vly_gemm_bf16_streamk: empty problem"); return -22; }
-    const bool p4 = tile_hint == 298 || tile_hint == 299;   // the persistent 4-wave kernel with a stream-K pool (gemm_bf16.hip)
-    if (K % BK || lda % 8 || ldw % 8 || (ldw <= 0 && !(p4 && ldw == VLY_LDW_PACKED64)) /* row-major weights, or the block layout for 298 / 299 */ || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
+    const bool p4 = tile_hint >= 297 && tile_hint <= 299;   // the persistent 4-wave kernel with a stream-K pool (gemm_bf16.hip)
+    if (K % BK || lda % 8 || ldw % 8 || (ldw <= 0 && !(p4 && ldw == VLY_LDW_PACKED64)) /* row-major weights, or the block layout for 297 - 299 */ || N % 4 || ldc % 2 || (epilogue == VLY_EPI_SWIGLU && N % 8) ||
         ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || ((uintptr_t)workspace & 15) ||
         (residual && (ldr % 4 || ((uintptr_t)residual & 15))) || (bias && ((uintptr_t)bias & 15)) || epoch == 0) {
         vly_set_error("vly_gemm_bf16_streamk: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d ldc=%d ldr=%d",

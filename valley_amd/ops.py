@@ -86,8 +86,8 @@ def _w_args(w, tile_kernel: bool):
 
 def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra):
     _chk(a, runtime.HALF, "a", contiguous=False)
-    # the block-ordered copy serves the tile kernels and the persistent kernel's stream-K form (hints 298 / 299)
-    wt, ldw = _w_args(w, fn_name == "vly_gemm_bf16" or (fn_name == "vly_gemm_bf16_streamk" and extra[0] in (298, 299)))
+    # the block-ordered copy serves the tile kernels and the persistent kernel's stream-K form (hints 297 / 298 / 299)
+    wt, ldw = _w_args(w, fn_name == "vly_gemm_bf16" or (fn_name == "vly_gemm_bf16_streamk" and extra[0] in (297, 298, 299)))
     assert a.dim() == 2 and len(w.shape) == 2 and a.stride(1) == 1 and a.shape[1] == w.shape[1], (a.shape, w.shape)
     M, K = a.shape
     N = w.shape[0]
@@ -108,7 +108,7 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
     if rec is not None:
         sk = fn_name.endswith("streamk")
         tile = extra[0] or (L.vly_gemm_streamk_tile_for(M, N, K) if sk else L.vly_gemm_tile_for(M, N))
-        if sk and tile not in (298, 299):
+        if sk and tile not in (297, 298, 299):
             sk_loop = {0: "2, 0", 4: "2, 0", 5: "2, 1", 7: "3, 0", 8: "3, 1"}[tile % 100 // 10]
             tile %= 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -117,7 +117,7 @@ def _gemm_common(fn_name, a, w, bias, residual, epilogue, out_dtype, out, extra)
             out.stride(0), residual.stride(0) if residual is not None else 0, epilogue, od, *extra, _stream())
     if rec is not None:
         e1.record()
-        if sk and tile in (298, 299):
+        if sk and tile in (297, 298, 299):
             name = f"gemm_p4_kernel<{TILE_SPECIAL[tile - 100][0][3:]}, {epilogue}, {od}, true>"     # (the names rocprofv3 prints)
         elif sk:
             name = f"gemm_sk_kernel<{TILE_NAMES[tile]}, {epilogue}, {od}, {sk_loop}>"
@@ -419,7 +419,7 @@ def _flush_caches(device):
 
 
 CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94, 97, 98, 99, 197, 198, 199)] + \
-             [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186, 298, 299)]
+             [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186, 297, 298, 299)]
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 TUNE_FINALISTS = 4   # after TUNE_TRIALS calls per candidate the best few are re-timed to 3 x TUNE_TRIALS calls each
 _ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
