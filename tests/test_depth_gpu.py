@@ -106,3 +106,23 @@ def test_13b_decode_256_tokens_graph_vs_fp32_path():
     assert errs.mean() < 4e-2 and errs.max() < 8e-2
     assert confident == 0 or agree == confident
     assert c16.seq_len == S + N
+
+
+def test_7b_all_32_layers_vs_cpu_oracle():
+    """the two tests above are HIP (half storage) against HIP (fp32 mode).  This one is the production path against
+    the CPU ORACLE itself at full depth — Llama-2-7B shapes, all 32 decoder layers, configs[1]'s S = 328 — the run of
+    tools/full_depth_oracle.py (profiles/history/r03/r03_full_depth_oracle_7b_bf16.json: 3.81e-2 with bf16 storage, which is
+    what the oracle's own bf16-storage evaluation gives, 3.88e-2; the fp16 library is 8x closer).  ~15 s of host time for
+    the oracle's fp32 evaluation.  Reference arithmetic: hf LlamaModel.forward behind valley_model.py:281-330."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("full_depth_oracle", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                                     "full_depth_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows, secs, threads, half = mod.run(depths=(32,), rounded=False, threads=min(32, os.cpu_count() or 8))
+    r = rows[0]
+    print(f"7B x 32 layers vs CPU oracle ({half}): logits rel-L2 {r['hip_vs_fp32_logits']:.3e}, hidden {r['hip_vs_fp32_hidden']:.3e}, "
+          f"oracle {secs:.1f} s on {threads} threads")
+    bound = 4.5e-2 if half == torch.bfloat16 else 7e-3
+    assert r["hip_vs_fp32_logits"] < bound and r["hip_vs_fp32_hidden"] < bound

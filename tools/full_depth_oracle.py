@@ -24,7 +24,8 @@ def rel(a, b):
     return float((a - b).norm() / b.norm())
 
 
-def main():
+def run(depths=(2, 8, 16, 32), rounded=True, threads=None):
+    """-> (rows, oracle seconds, threads); tests/test_depth_gpu.py runs depth 32 without the rounded evaluation."""
     H, heads, I, L, eps, S, V = 4096, 32, 11008, 32, 1e-5, 328, 512
     half = getattr(runtime, "HALF", torch.bfloat16)
     d = torch.device("cuda:0")
@@ -43,11 +44,11 @@ def main():
     emb = (torch.randn((1, S, H), generator=torch.Generator().manual_seed(3)) * 0.5)
     cfg = O.LlamaCfg(hidden=H, heads=heads, intermediate=I, layers=L, vocab=V, eps=eps)
     lm = sd["lm_head.weight"].float()
-    threads = int(os.environ.get("VALLEY_ORACLE_THREADS", "32"))
+    threads = threads or int(os.environ.get("VALLEY_ORACLE_THREADS", "32"))
     torch.set_num_threads(threads)
     rows = []
     t_or = 0.0
-    for k in (2, 8, 16, 32):
+    for k in depths:
         cache = ll.new_cache(1, S)
         x = ll.forward(emb.to(d).view(S, H).clone(), 1, S, cache, n_layers=k)
         hip_h = x.float().cpu()
@@ -56,18 +57,25 @@ def main():
         with torch.no_grad():
             ref_h, _ = O.llama_forward(emb, sd, cfg, n_layers=k)
             ref_l = torch.nn.functional.linear(ref_h, lm)
-            with O.rounding():
-                rnd_h, _ = O.llama_forward(emb, sd, cfg, n_layers=k)
-                rnd_l = torch.nn.functional.linear(rnd_h, lm)
+            if rounded:
+                with O.rounding():
+                    rnd_h, _ = O.llama_forward(emb, sd, cfg, n_layers=k)
+                    rnd_l = torch.nn.functional.linear(rnd_h, lm)
         t_or += time.perf_counter() - t0
         rows.append({"layers": k,
                      "hip_vs_fp32_hidden": round(rel(hip_h, ref_h[0]), 5), "hip_vs_fp32_logits": round(rel(hip_l, ref_l[0]), 5),
-                     "rounded_oracle_vs_fp32_hidden": round(rel(rnd_h[0], ref_h[0]), 5),
-                     "rounded_oracle_vs_fp32_logits": round(rel(rnd_l[0], ref_l[0]), 5),
-                     "hip_vs_rounded_oracle_logits": round(rel(hip_l, rnd_l[0]), 5),
                      "logits_max_abs_hip_vs_fp32": round(float((hip_l - ref_l[0]).abs().max()), 4),
                      "logit_abs_max": round(float(ref_l.abs().max()), 3)})
+        if rounded:
+            rows[-1].update({"rounded_oracle_vs_fp32_hidden": round(rel(rnd_h[0], ref_h[0]), 5),
+                             "rounded_oracle_vs_fp32_logits": round(rel(rnd_l[0], ref_l[0]), 5),
+                             "hip_vs_rounded_oracle_logits": round(rel(hip_l, rnd_l[0]), 5)})
         print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
+    return rows, t_or, threads, half
+
+
+def main():
+    rows, t_or, threads, half = run()
     print(json.dumps({"what": "Llama-2-7B shapes, 32 layers, S = 328, B = 1: HIP path vs oracle fp32 vs oracle.rounding()",
                       "storage_dtype": str(half), "oracle_seconds": round(t_or, 1), "oracle_threads": threads, "depths": rows}))
 
