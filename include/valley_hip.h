@@ -275,15 +275,6 @@ int vly_decode_attention_split(const void *qkv_bf16, void *kcache_bf16, void *vc
                                int B, int heads, int past_len, const int32_t *past_len_dev, int past_len_dev_stride,
                                int ctx_max, void *stream);
 
-/* The same launch with ceil(prefetch_workgroups / (heads * B)) * heads * B more workgroups behind the attention's own, which
- *   read `prefetch_bytes` at `prefetch` (16-byte aligned; the weight the NEXT launch streams) and drop them: the attention
- *   moves a few MB and is all latency, HBM idles, and the 256 MB memory-side cache allocates on reads.  Same results. */
-int vly_decode_attention_split_pf(const void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
-                                  const float *sin_table, const uint8_t *key_valid, int key_valid_stride, float *partials,
-                                  int B, int heads, int past_len, const int32_t *past_len_dev, int past_len_dev_stride,
-                                  int ctx_max, const void *prefetch, size_t prefetch_bytes, int prefetch_workgroups,
-                                  void *stream);
-
 /* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
  *   serve/model_worker.py:380-387 (one-token forward). */
@@ -355,11 +346,6 @@ int vly_resize_h_u8(const uint8_t *in, const int32_t *bounds, const int32_t *tap
 int vly_resize_v_norm(const uint8_t *in, const int32_t *bounds, const int32_t *taps, const float *mean,
                       const float *stdv, void *out, int T, int H, int W, int x_off, int OS, int ksize,
                       int out_f32, void *stream);
-
-/* Read `bytes` of device memory at p (16-byte aligned) and drop the values: pulls a weight into the 256 MB memory-side cache
- * from a second stream while a latency-bound launch (the decode step's attention) leaves HBM idle.  Writes nothing.
- *   serve/model_worker.py:380-394 (the one-token forward this schedules around). */
-int vly_prefetch(const void *p, size_t bytes, int workgroups, void *stream);
 
 /* p[i] += delta for i < n (the device-side position counter of a captured decode step). */
 int vly_incr_i32(int32_t *p, int n, int delta, void *stream);

@@ -684,15 +684,7 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
                                                            const float* __restrict__ sin_t, const uint8_t* __restrict__ key_valid,
                                                            float* __restrict__ partials, int heads, int past,
                                                            const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max,
-                                                           int past_row_stride, const u32x4* __restrict__ pf, size_t pf_n16) {
-    if (blockIdx.z >= VLY_DECODE_SPLITS) {
-        // vly_decode_attention_split_pf: the workgroups behind the attention's own read a weight into the memory-side cache
-        // (this launch moves a few MB and is all latency; HBM is idle meanwhile)
-        const size_t wg = ((size_t)(blockIdx.z - VLY_DECODE_SPLITS) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const size_t nwg = (size_t)(gridDim.z - VLY_DECODE_SPLITS) * gridDim.y * gridDim.x;
-        vly_prefetch_units(pf, pf_n16, wg * 256 + threadIdx.x, nwg * 256);
-        return;
-    }
+                                                           int past_row_stride) {
     __shared__ float sc[256];
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ __attribute__((aligned(16))) float knew[128];
@@ -912,23 +904,10 @@ extern "C" int vly_decode_attention_rows(const void* qkv, void* kcache, void* vc
     return vly_check_launch("vly_decode_attention_rows");
 }
 
-extern "C" int vly_decode_attention_split_pf(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
-                                             const uint8_t* key_valid, int key_valid_stride, float* partials, int B, int heads,
-                                             int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
-                                             const void* prefetch, size_t prefetch_bytes, int prefetch_workgroups, void* stream);
-
 extern "C" int vly_decode_attention_split(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
                                           const uint8_t* key_valid, int key_valid_stride, float* partials, int B, int heads,
                                           int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
                                           void* stream) {
-    return vly_decode_attention_split_pf(qkv, kcache, vcache, cos_table, sin_table, key_valid, key_valid_stride, partials, B, heads,
-                                         past_len, past_len_dev, past_len_dev_stride, ctx_max, nullptr, 0, 0, stream);
-}
-
-extern "C" int vly_decode_attention_split_pf(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
-                                             const uint8_t* key_valid, int key_valid_stride, float* partials, int B, int heads,
-                                             int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
-                                             const void* prefetch, size_t prefetch_bytes, int prefetch_workgroups, void* stream) {
     if (B <= 0 || heads <= 0 || past_len < 0 || past_len + 1 > ctx_max || B > 65535 || heads > 65535 || ((uintptr_t)qkv & 15) ||
         ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) || !partials || ((uintptr_t)partials & 15) || !cos_table || !sin_table ||
         past_len_dev_stride < 0 || past_len_dev_stride > 1 || (past_len_dev_stride == 1 && !past_len_dev)) {
@@ -939,17 +918,8 @@ extern "C" int vly_decode_attention_split_pf(const void* qkv, void* kcache, void
         vly_set_error("vly_decode_attention_split: key_valid_stride %d too short", key_valid_stride);
         return -22;
     }
-    int zx = 0;                                              // extra grid planes of heads x B prefetching workgroups
-    if (prefetch && prefetch_bytes >= 16 && prefetch_workgroups > 0) {
-        if (((uintptr_t)prefetch & 15) || prefetch_workgroups > 4096) {
-            vly_set_error("vly_decode_attention_split_pf: prefetch pointer must be 16-byte aligned, <= 4096 workgroups");
-            return -22;
-        }
-        zx = (prefetch_workgroups + heads * B - 1) / (heads * B);
-    }
-    hipLaunchKernelGGL(decode_split_kernel, dim3(heads, B, VLY_DECODE_SPLITS + zx), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)qkv, (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, partials, heads,
-                       past_len, past_len_dev, key_valid_stride, ctx_max, past_len_dev_stride, (const u32x4*)prefetch,
-                       zx ? prefetch_bytes / 16 : (size_t)0);
+    hipLaunchKernelGGL(decode_split_kernel, dim3(heads, B, VLY_DECODE_SPLITS), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, partials, heads, past_len, past_len_dev,
+                       key_valid_stride, ctx_max, past_len_dev_stride);
     return vly_check_launch("vly_decode_attention_split");
 }

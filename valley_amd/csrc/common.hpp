@@ -151,23 +151,6 @@ VLY_DEVICE void bglds16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, CPOL);
 }
 
-// Read n16 16-byte units at p and drop them (weight prefetch into the memory-side cache): this lane takes units first, first +
-// stride, ...; eight loads in flight.
-VLY_DEVICE void vly_prefetch_units(const u32x4* __restrict__ p, size_t n16, size_t first, size_t stride) {
-    size_t i = first;
-    u32x4 v[8];
-    for (; i + 7 * stride < n16; i += 8 * stride) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(v[u]));
-    }
-    for (; i < n16; i += stride) {
-        v[0] = p[i];
-        asm volatile("" ::"v"(v[0]));
-    }
-}
-
 void vly_set_error(const char* fmt, ...);
 int vly_check_launch(const char* what);
 int vly_tile_order_m_fast(int M, int N, int K, int tiles_m, int tiles_n);

@@ -463,24 +463,3 @@ extern "C" int vly_gemv_attnmerge_bf16(const float* partials, const void* W, con
     if (M == 1) return launch_norm_mr<1, 1>(partials, nullptr, 0.f, W, bias, residual, C, M, N, K, heads, ldw, ldc, ldr, VLY_EPI_NONE, out_dtype, st, "vly_gemv_attnmerge_bf16");
     return launch_norm_mr<2, 1>(partials, nullptr, 0.f, W, bias, residual, C, M, N, K, heads, ldw, ldc, ldr, VLY_EPI_NONE, out_dtype, st, "vly_gemv_attnmerge_bf16");
 }
-
-// ---- weight prefetch into the memory-side cache (round 4) --------------------------------------------------------------
-// The decode step's attention launch moves 7 MB and takes ~12 us of pure latency while HBM idles; the 256 MB Infinity Cache
-// sits in front of HBM and allocates on reads.  This kernel reads `bytes` of a weight (16 bytes per lane, eight loads in
-// flight per lane, results dropped) on a second stream beside the attention launch, so that the o-proj GEMV that follows
-// streams its 52 MB (13B) from the cache instead of starting cold.  It writes nothing.
-namespace {
-__global__ void __launch_bounds__(256) prefetch_kernel(const u32x4* __restrict__ p, size_t n16) {
-    vly_prefetch_units(p, n16, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
-}
-}  // namespace
-
-extern "C" int vly_prefetch(const void* p, size_t bytes, int workgroups, void* stream) {
-    if (!p || ((uintptr_t)p & 15) || workgroups <= 0 || workgroups > 4096) {
-        vly_set_error("vly_prefetch: bad args (16-byte aligned pointer, 1..4096 workgroups)");
-        return -22;
-    }
-    if (bytes < 16) return 0;
-    hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, bytes / 16);
-    return vly_check_launch("vly_prefetch");
-}

@@ -30,12 +30,6 @@ SPLIT_ATTN = os.environ.get("VALLEY_DECODE_SPLIT_ATTN", "1") != "0"       # flas
 # activation hand-off and norm 1.4-2.8 us) costs no less than a kernel boundary (1.3 us + ramp), and requests issued before the
 # barrier land before it ends (DESIGN.md "decode: the persistent step").  Kept as an option: VALLEY_DECODE_PERSISTENT=1.
 PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "0") != "0"
-# round 4: while the attention launch of a layer runs (7 MB of K / V, ~12 us of latency, HBM idle) the o-proj weight is read into
-# the 256 MB memory-side cache: "o" = by extra workgroups of the attention launch (vly_decode_attention_split_pf), "side" = by
-# vly_prefetch on a second stream (fork / join in the captured graph), "0" = off
-PREFETCH = os.environ.get("VALLEY_DECODE_PREFETCH", "0")
-PREFETCH_WGS = int(os.environ.get("VALLEY_DECODE_PREFETCH_WGS", "96"))
-PREFETCH_MB = int(os.environ.get("VALLEY_DECODE_PREFETCH_MB", "1024"))
 
 class DecodeSession:
     def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True, per_row_positions: bool = False):
@@ -66,7 +60,6 @@ class DecodeSession:
             self.sync = torch.zeros((ops.DECODE_SYNC_WORDS,), dtype=torch.int32, device=d)
             self.table = None
             self._table_gen = None
-        self._side = torch.cuda.Stream(device=d) if PREFETCH == "side" else None
         self.use_graph = use_graph
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._gen = cache.generation
@@ -93,17 +86,8 @@ class DecodeSession:
                 ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
                 ops.gemv(self.x, L["w_qkv"], out=self.qkv)
             if split:                                            # every head over four workgroups; the o GEMV merges
-                if PREFETCH == "side":                           # a second stream beside the attention launch (fork / join)
-                    cur = torch.cuda.current_stream()
-                    self._side.wait_stream(cur)
-                    with torch.cuda.stream(self._side):
-                        ops.prefetch(L["w_o"], PREFETCH_WGS)
                 ops.decode_attention_split(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, self.partials,
-                                           past_dev=self.pos, per_row=self.per_row,
-                                           prefetch=L["w_o"] if PREFETCH == "o" else None, prefetch_bytes=PREFETCH_MB << 20,
-                                           prefetch_workgroups=PREFETCH_WGS)
-                if PREFETCH == "side":
-                    torch.cuda.current_stream().wait_stream(self._side)
+                                           past_dev=self.pos, per_row=self.per_row)
                 ops.gemv_attnmerge(self.partials, L["w_o"], residual=self.h, out=self.h)
             elif self.per_row:
                 ops.decode_attention_rows(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, self.pos, out=self.att)

@@ -45,11 +45,8 @@ _SIGS = {
     "vly_resize_h_u8": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_resize_v_norm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
-    "vly_prefetch": (c_int, [_P, c_size_t, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_decode_attention_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
-    "vly_decode_attention_split_pf": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_size_t,
-                                              c_int, _P]),
     "vly_gemv_attnmerge_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemv_rmsnorm_bf16": (c_int, [_P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_decode_layers_supported": (c_int, [c_int, c_int, c_int, c_int]),

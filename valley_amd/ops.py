@@ -928,11 +928,9 @@ def decode_partials(B: int, heads: int, device) -> torch.Tensor:
 
 def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                            key_valid: Optional[torch.Tensor], B: int, heads: int, past_len: int, partials: torch.Tensor,
-                           past_dev: Optional[torch.Tensor] = None, per_row: bool = False, prefetch=None,
-                           prefetch_bytes: Optional[int] = None, prefetch_workgroups: int = 96) -> torch.Tensor:
+                           past_dev: Optional[torch.Tensor] = None, per_row: bool = False) -> torch.Tensor:
     """vly_decode_attention_split: decode_attention (or decode_attention_rows with ``per_row``) with every head split over
-    DECODE_SPLITS workgroups; leaves the per-split (max, sum, P·V) in ``partials`` for gemv_attnmerge.  ``prefetch``: a weight
-    whose first ``prefetch_bytes`` extra workgroups of the launch read into the memory-side cache (vly_decode_attention_split_pf)."""
+    DECODE_SPLITS workgroups; leaves the per-split (max, sum, P·V) in ``partials`` for gemv_attnmerge."""
     _chk(qkv, runtime.HALF, "qkv")
     _chk(cos, torch.float32, "cos")
     _chk(sin, torch.float32, "sin")
@@ -950,18 +948,9 @@ def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torc
         _chk(key_valid, torch.uint8, "key_valid")
         assert key_valid.shape[0] == B and key_valid.shape[1] >= (ctx_max if past_dev is not None else past_len + 1)
         kv_stride = key_valid.stride(0)
-    if prefetch is not None:
-        t = prefetch.plain if isinstance(prefetch, PackedWeight) else prefetch
-        n = t.numel() * t.element_size()
-        rc = _lib.load().vly_decode_attention_split_pf(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(),
-                                                       sin.data_ptr(), _ptr(key_valid), kv_stride, partials.data_ptr(), B, heads,
-                                                       past_len, _ptr(past_dev), 1 if per_row else 0, ctx_max, t.data_ptr(),
-                                                       n if prefetch_bytes is None else min(n, prefetch_bytes),
-                                                       prefetch_workgroups, _stream())
-    else:
-        rc = _lib.load().vly_decode_attention_split(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(),
-                                                    sin.data_ptr(), _ptr(key_valid), kv_stride, partials.data_ptr(), B, heads,
-                                                    past_len, _ptr(past_dev), 1 if per_row else 0, ctx_max, _stream())
+    rc = _lib.load().vly_decode_attention_split(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                _ptr(key_valid), kv_stride, partials.data_ptr(), B, heads, past_len, _ptr(past_dev),
+                                                1 if per_row else 0, ctx_max, _stream())
     _lib.check(rc, "vly_decode_attention_split")
     return partials
 
@@ -1065,15 +1054,6 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     rc = _lib.load().vly_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream())
     _lib.check(rc, "vly_cast_f32_bf16")
     return y
-
-
-def prefetch(w, workgroups: int = 96, max_bytes: Optional[int] = None):
-    """vly_prefetch: read (the first ``max_bytes`` of) a weight into the memory-side cache — issue it on a side stream beside a
-    latency-bound launch."""
-    t = w.plain if isinstance(w, PackedWeight) else w       # the copy the GEMV streams
-    n = t.numel() * t.element_size()
-    rc = _lib.load().vly_prefetch(t.data_ptr(), n if max_bytes is None else min(n, max_bytes), workgroups, _stream())
-    _lib.check(rc, "vly_prefetch")
 
 
 def incr_i32(p: torch.Tensor, delta: int = 1):
