@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 #define VLY_ABI_VERSION 5   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
-                               vly_decode_attention_split, vly_gemv_attnmerge_bf16; 5: + vly_decode_layers(_supported) */
+                               vly_decode_attention_split, vly_gemv_attnmerge_bf16; 5: + vly_decode_layers(_supported),
+                               vly_decode_attention_merged */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -274,6 +275,16 @@ int vly_decode_attention_split(const void *qkv_bf16, void *kcache_bf16, void *vc
                                const float *sin_table, const uint8_t *key_valid, int key_valid_stride, float *partials,
                                int B, int heads, int past_len, const int32_t *past_len_dev, int past_len_dev_stride,
                                int ctx_max, void *stream);
+
+/* The same launch, with the merge done by the LAST of a head's VLY_DECODE_SPLITS workgroups to finish (round 4): it combines the
+ *   head's partials (the arithmetic of vly_gemv_attnmerge_bf16's prologue, in split order: bit-identical) and writes the
+ *   attention output out[B, heads*128] in the 16-bit storage type, which a plain vly_gemv_bf16 (the o projection) then reads.
+ *   arrivals: B * heads uint32 of device memory, zero before the first launch; every launch leaves them zero.  `partials` is
+ *   still the workspace [B][heads][VLY_DECODE_SPLITS][132].  (HF LlamaAttention.forward behind serve/model_worker.py:380-387.) */
+int vly_decode_attention_merged(const void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
+                                const float *sin_table, const uint8_t *key_valid, int key_valid_stride, float *partials,
+                                void *out_bf16, uint32_t *arrivals, int B, int heads, int past_len,
+                                const int32_t *past_len_dev, int past_len_dev_stride, int ctx_max, void *stream);
 
 /* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.

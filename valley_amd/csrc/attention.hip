@@ -673,6 +673,58 @@ __global__ void __launch_bounds__(512) decode_fused_kernel(const uint16_t* __res
 }
 
 // ---- decode attention split over the keys (flash-decoding) ----------------------------------------------------------------
+// ---- vly_decode_attention_merged: the merge of a head's split partials by the LAST of its workgroups to finish -------------
+// (round 4) vly_gemv_attnmerge_bf16 merges the partials in the o projection's prologue: every one of its 256 workgroups reads all
+// heads x splits x 132 floats and spends ~4 us before its first dot product — on a launch whose weights are 7 us of HBM time.
+// Here every split publishes its partial with write-through stores, drains them, and takes a ticket on the head's counter; the
+// one that draws the last ticket merges (the SAME arithmetic, in split order: bit-identical) and writes the head's 128 outputs
+// as 16-bit values, which the plain GEMV then reads like any activation.  No fence: write-through (sc1) stores + vmcnt(0) before
+// the ticket, sc1 loads after it (the hand-off of decode_step.hip).  The counter is back at zero when the launch ends.
+VLY_DEVICE void split_publish(float* p, float v, bool write_through) {
+    if (write_through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+VLY_DEVICE void split_merge_if_last(const float* __restrict__ partials, uint16_t* __restrict__ merged, unsigned* __restrict__ arrivals,
+                                    int heads, int h, int b, float* flag_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's partial has been written through
+    __syncthreads();
+    unsigned* ctr = arrivals + (size_t)b * heads + h;
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_lds[0] = t == VLY_DECODE_SPLITS - 1 ? 1.f : 0.f;
+        if (t == VLY_DECODE_SPLITS - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (flag_lds[0] == 0.f || threadIdx.x >= 32) return;
+    // 32 lanes x 4 dims: the unit arithmetic of gemv_norm_kernel<.., PRO = 1>, operation for operation
+    const float* hb = partials + ((size_t)b * heads + h) * (VLY_DECODE_SPLITS * 132);
+    float ms[VLY_DECODE_SPLITS], ls[VLY_DECODE_SPLITS];
+    float os[VLY_DECODE_SPLITS][4];
+#pragma unroll
+    for (int sp = 0; sp < VLY_DECODE_SPLITS; ++sp) {
+        ms[sp] = __hip_atomic_load(hb + sp * 132, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ls[sp] = __hip_atomic_load(hb + sp * 132 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            os[sp][r] = __hip_atomic_load(hb + sp * 132 + 4 + 4 * (int)threadIdx.x + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float mx = ms[0];
+#pragma unroll
+    for (int sp = 1; sp < VLY_DECODE_SPLITS; ++sp) mx = fmaxf(mx, ms[sp]);
+    float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sp = 0; sp < VLY_DECODE_SPLITS; ++sp) {
+        const float w = exp2f(ms[sp] - mx);
+        L = fmaf(ls[sp], w, L);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) O[r] = fmaf(os[sp][r], w, O[r]);
+    }
+    u32x2 pk;
+    pk[0] = pack_h2(O[0] / L, O[1] / L);
+    pk[1] = pack_h2(O[2] / L, O[3] / L);
+    *(u32x2*)(merged + ((size_t)b * heads + h) * 128 + 4 * threadIdx.x) = pk;
+}
+
 // decode_fused_kernel gives a head to ONE workgroup: at batch 1 that is `heads` (40) of 256 CUs, each pulling its head's
 // 2 x kv_len x 256 B of K and V through one CU's memory pipe (~10 us per layer at kv_len ~ 450 for 9 MB).  Here a head is
 // VLY_DECODE_SPLITS workgroups of 256 threads, each over a 64-aligned quarter of the keys; every workgroup rotates q itself,
@@ -684,7 +736,8 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
                                                            const float* __restrict__ sin_t, const uint8_t* __restrict__ key_valid,
                                                            float* __restrict__ partials, int heads, int past,
                                                            const int32_t* __restrict__ past_dev, int kv_stride, int ctx_max,
-                                                           int past_row_stride) {
+                                                           int past_row_stride, uint16_t* __restrict__ merged,
+                                                           unsigned* __restrict__ arrivals) {
     __shared__ float sc[256];
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ __attribute__((aligned(16))) float knew[128];
@@ -705,18 +758,37 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
     float* part = partials + (((size_t)b * heads + h) * VLY_DECODE_SPLITS + sp) * 132;
     if (lo >= hi) {                                           // an empty range (short contexts): the neutral element of the merge
-        if (tid < 132) part[tid] = tid == 0 ? NEG_BIG : 0.f;
+        if (tid < 132) split_publish(part + tid, tid == 0 ? NEG_BIG : 0.f, merged != nullptr);
+        if (merged) split_merge_if_last(partials, merged, arrivals, heads, h, b, sc);
         return;
     }
+    // Round 4: every global load of the first pass is requested up front, BRANCH-FREE (clamped addresses, values masked where
+    // they are used: behind exec-masked branches hipcc loses count of what is in flight and waits vmcnt(0)) and in the order of
+    // use — the rotation's few operands first, then the K row, the validity byte and the V chunks, which only depend on the
+    // position — so the rotation, its LDS hand-off and the barrier run under the K / V round trip.  Arithmetic unchanged.
+    const int t63 = tid & 63;
+    const float cs = cos_t[(size_t)pos * 64 + t63], sn = sin_t[(size_t)pos * 64 + t63];
+    const uint16_t q0r = qp[t63], q1r = qp[t63 + 64], k0r = qp[Hq + t63], k1r = qp[Hq + t63 + 64], vr = qp[2 * Hq + ((tid - 64) & 127)];
+    u32x4 vv[16], kk[16];
+    uint8_t kvalid = 1;
+    const int jmax = max(min(hi, pos) - 1, 0);                // last row this split may read (row 0 of the cache if there is none)
+    auto request = [&](int c0) {
+        const u32x4* kr = (const u32x4*)(kbase + (size_t)min(c0 + tid, jmax) * 128);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) kk[c] = kr[c];
+        if (kvld) kvalid = kvld[min(c0 + tid, hi - 1)];       // (uniform branch)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vv[u] = *(const u32x4*)(vbase + (size_t)min(c0 + (tid >> 4) + 16 * u, jmax) * 128 + 8 * (tid & 15));
+    };
+    request(lo);
     // ---- RoPE on q (every split), on k + append, v append (the owner): decode_fused_kernel's arithmetic
     if (tid < 64) {
-        const float cs = cos_t[(size_t)pos * 64 + tid], sn = sin_t[(size_t)pos * 64 + tid];
-        const float q0 = h2f(qp[tid]), q1 = h2f(qp[tid + 64]);
+        const float q0 = h2f(q0r), q1 = h2f(q1r);
         const float scale = 0.08838834764831845f * LOG2E;
         qs[tid] = h2f(f2h(rope_rot(q0, q1, cs, sn, -1.f))) * scale;
         qs[tid + 64] = h2f(f2h(rope_rot(q1, q0, cs, sn, 1.f))) * scale;
         if (owner) {
-            const float k0 = h2f(qp[Hq + tid]), k1 = h2f(qp[Hq + tid + 64]);
+            const float k0 = h2f(k0r), k1 = h2f(k1r);
             const uint16_t r0 = f2h(rope_rot(k0, k1, cs, sn, -1.f)), r1 = f2h(rope_rot(k1, k0, cs, sn, 1.f));
             knew[tid] = h2f(r0);
             knew[tid + 64] = h2f(r1);
@@ -725,9 +797,8 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
         }
     } else if (tid < 192 && owner) {
         const int d = tid - 64;
-        const uint16_t v = qp[2 * Hq + d];
-        vnew[d] = h2f(v);
-        vbase[(size_t)pos * 128 + d] = v;
+        vnew[d] = h2f(vr);
+        vbase[(size_t)pos * 128 + d] = vr;
     }
     __syncthreads();
 
@@ -738,21 +809,17 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     float m_run = NEG_BIG, l_run = 0.f;
 #pragma unroll 1
     for (int c0 = lo; c0 < hi; c0 += 256) {
-        u32x4 vv[16];
+        if (c0 != lo) request(c0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 16; ++u) {                          // rows past the range / the new position count as zero
             const int j = c0 + kg + 16 * u;
-            vv[u] = (j < hi && j < pos) ? *(const u32x4*)(vbase + (size_t)j * 128 + 8 * dc) : u32x4{0u, 0u, 0u, 0u};
+            if (!(j < hi && j < pos)) vv[u] = u32x4{0u, 0u, 0u, 0u};
         }
         const int jk = c0 + tid;
         float s = NEG_BIG;
-        if (jk < hi && (!kvld || kvld[jk])) {
+        if (jk < hi && kvalid) {
             float a = 0.f;
             if (jk < pos) {
-                const u32x4* kr = (const u32x4*)(kbase + (size_t)jk * 128);
-                u32x4 kk[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) kk[c] = kr[c];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const f32x4 q0 = *(const f32x4*)(qs + 8 * c), q1 = *(const f32x4*)(qs + 8 * c + 4);
@@ -808,10 +875,11 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
         float t = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) t += acc_s[k2][tid];
-        part[4 + tid] = t;
+        split_publish(part + 4 + tid, t, merged != nullptr);
     } else if (tid < 132) {
-        part[tid - 128] = tid == 128 ? m_run : tid == 129 ? l_run : 0.f;
+        split_publish(part + tid - 128, tid == 128 ? m_run : tid == 129 ? l_run : 0.f, merged != nullptr);
     }
+    if (merged) split_merge_if_last(partials, merged, arrivals, heads, h, b, sc);
 }
 
 // the two kernels that are NOT the default of their op (kept for A/B runs and as each other's bit-identity witness:
@@ -904,22 +972,47 @@ extern "C" int vly_decode_attention_rows(const void* qkv, void* kcache, void* vc
     return vly_check_launch("vly_decode_attention_rows");
 }
 
+static int decode_split_launch(const char* name, const void* qkv, void* kcache, void* vcache, const float* cos_table,
+                               const float* sin_table, const uint8_t* key_valid, int key_valid_stride, float* partials, int B,
+                               int heads, int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
+                               void* merged, unsigned* arrivals, void* stream);
+
 extern "C" int vly_decode_attention_split(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
                                           const uint8_t* key_valid, int key_valid_stride, float* partials, int B, int heads,
                                           int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
                                           void* stream) {
+    return decode_split_launch("vly_decode_attention_split", qkv, kcache, vcache, cos_table, sin_table, key_valid, key_valid_stride,
+                               partials, B, heads, past_len, past_len_dev, past_len_dev_stride, ctx_max, nullptr, nullptr, stream);
+}
+
+extern "C" int vly_decode_attention_merged(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
+                                           const uint8_t* key_valid, int key_valid_stride, float* partials, void* out,
+                                           uint32_t* arrivals, int B, int heads, int past_len, const int32_t* past_len_dev,
+                                           int past_len_dev_stride, int ctx_max, void* stream) {
+    if (!out || ((uintptr_t)out & 7) || !arrivals || ((uintptr_t)arrivals & 3)) {
+        vly_set_error("vly_decode_attention_merged: out (8-byte aligned) and arrivals (B * heads zeroed uint32) are required");
+        return -22;
+    }
+    return decode_split_launch("vly_decode_attention_merged", qkv, kcache, vcache, cos_table, sin_table, key_valid, key_valid_stride,
+                               partials, B, heads, past_len, past_len_dev, past_len_dev_stride, ctx_max, out, arrivals, stream);
+}
+
+static int decode_split_launch(const char* name, const void* qkv, void* kcache, void* vcache, const float* cos_table,
+                               const float* sin_table, const uint8_t* key_valid, int key_valid_stride, float* partials, int B,
+                               int heads, int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
+                               void* merged, unsigned* arrivals, void* stream) {
     if (B <= 0 || heads <= 0 || past_len < 0 || past_len + 1 > ctx_max || B > 65535 || heads > 65535 || ((uintptr_t)qkv & 15) ||
         ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15) || !partials || ((uintptr_t)partials & 15) || !cos_table || !sin_table ||
         past_len_dev_stride < 0 || past_len_dev_stride > 1 || (past_len_dev_stride == 1 && !past_len_dev)) {
-        vly_set_error("vly_decode_attention_split: bad args B=%d heads=%d past=%d ctx_max=%d", B, heads, past_len, ctx_max);
+        vly_set_error("%s: bad args B=%d heads=%d past=%d ctx_max=%d", name, B, heads, past_len, ctx_max);
         return -22;
     }
     if (key_valid && key_valid_stride < (past_len_dev ? ctx_max : past_len + 1)) {
-        vly_set_error("vly_decode_attention_split: key_valid_stride %d too short", key_valid_stride);
+        vly_set_error("%s: key_valid_stride %d too short", name, key_valid_stride);
         return -22;
     }
     hipLaunchKernelGGL(decode_split_kernel, dim3(heads, B, VLY_DECODE_SPLITS), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, partials, heads, past_len, past_len_dev,
-                       key_valid_stride, ctx_max, past_len_dev_stride);
-    return vly_check_launch("vly_decode_attention_split");
+                       key_valid_stride, ctx_max, past_len_dev_stride, (uint16_t*)merged, arrivals);
+    return vly_check_launch(name);
 }

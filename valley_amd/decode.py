@@ -30,6 +30,9 @@ SPLIT_ATTN = os.environ.get("VALLEY_DECODE_SPLIT_ATTN", "1") != "0"       # flas
 # activation hand-off and norm 1.4-2.8 us) costs no less than a kernel boundary (1.3 us + ramp), and requests issued before the
 # barrier land before it ends (DESIGN.md "decode: the persistent step").  Kept as an option: VALLEY_DECODE_PERSISTENT=1.
 PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "0") != "0"
+# round 4: where the split attention's partials are merged — "attn": by the last workgroup of a head inside the attention launch
+# (vly_decode_attention_merged; the o projection is then a plain GEMV), "oproj": in the o GEMV's prologue (round 3).  Same bits.
+MERGE_IN = os.environ.get("VALLEY_DECODE_MERGE", "attn")
 
 class DecodeSession:
     def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True, per_row_positions: bool = False):
@@ -49,6 +52,7 @@ class DecodeSession:
         self.qkv = torch.empty((B, 3 * llama.H), dtype=bf, device=d)
         self.att = torch.empty((B, llama.H), dtype=bf, device=d)
         self.partials = ops.decode_partials(B, llama.heads, d)
+        self.arrivals = torch.zeros((B * llama.heads,), dtype=torch.int32, device=d)     # tickets of vly_decode_attention_merged
         self.mlp = torch.empty((B, llama.I), dtype=bf, device=d)
         self.logits = torch.empty((B, llama.Vpad), dtype=torch.float32, device=d)
         # the persistent form takes the whole GPU (one workgroup per CU, all resident): shapes it supports, and only with the
@@ -86,9 +90,14 @@ class DecodeSession:
                 ops.rmsnorm(self.h, L["ln1"], ll.eps, out=self.x)
                 ops.gemv(self.x, L["w_qkv"], out=self.qkv)
             if split:                                            # every head over four workgroups; the o GEMV merges
-                ops.decode_attention_split(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, self.partials,
-                                           past_dev=self.pos, per_row=self.per_row)
-                ops.gemv_attnmerge(self.partials, L["w_o"], residual=self.h, out=self.h)
+                if MERGE_IN == "attn":
+                    ops.decode_attention_split(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0, self.partials,
+                                               past_dev=self.pos, per_row=self.per_row, out=self.att, arrivals=self.arrivals)
+                    ops.gemv(self.att, L["w_o"], residual=self.h, out=self.h)
+                else:
+                    ops.decode_attention_split(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, 0,
+                                               self.partials, past_dev=self.pos, per_row=self.per_row)
+                    ops.gemv_attnmerge(self.partials, L["w_o"], residual=self.h, out=self.h)
             elif self.per_row:
                 ops.decode_attention_rows(self.qkv, c.k[li], c.v[li], ll.cos, ll.sin, c.key_valid, B, ll.heads, self.pos, out=self.att)
             else:

@@ -928,9 +928,12 @@ def decode_partials(B: int, heads: int, device) -> torch.Tensor:
 
 def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                            key_valid: Optional[torch.Tensor], B: int, heads: int, past_len: int, partials: torch.Tensor,
-                           past_dev: Optional[torch.Tensor] = None, per_row: bool = False) -> torch.Tensor:
+                           past_dev: Optional[torch.Tensor] = None, per_row: bool = False, out: Optional[torch.Tensor] = None,
+                           arrivals: Optional[torch.Tensor] = None) -> torch.Tensor:
     """vly_decode_attention_split: decode_attention (or decode_attention_rows with ``per_row``) with every head split over
-    DECODE_SPLITS workgroups; leaves the per-split (max, sum, P·V) in ``partials`` for gemv_attnmerge."""
+    DECODE_SPLITS workgroups; leaves the per-split (max, sum, P·V) in ``partials`` for gemv_attnmerge.
+    With ``out`` (16-bit [B, heads*128]) and ``arrivals`` (int32 [B*heads], zero): vly_decode_attention_merged — the last
+    workgroup of a head merges, ``out`` is the attention output; returns ``out``."""
     _chk(qkv, runtime.HALF, "qkv")
     _chk(cos, torch.float32, "cos")
     _chk(sin, torch.float32, "sin")
@@ -948,6 +951,16 @@ def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torc
         _chk(key_valid, torch.uint8, "key_valid")
         assert key_valid.shape[0] == B and key_valid.shape[1] >= (ctx_max if past_dev is not None else past_len + 1)
         kv_stride = key_valid.stride(0)
+    if out is not None:
+        _chk(out, runtime.HALF, "out")
+        _chk(arrivals, torch.int32, "arrivals")
+        assert tuple(out.shape) == (B, heads * 128) and arrivals.numel() >= B * heads
+        rc = _lib.load().vly_decode_attention_merged(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(),
+                                                     sin.data_ptr(), _ptr(key_valid), kv_stride, partials.data_ptr(), out.data_ptr(),
+                                                     arrivals.data_ptr(), B, heads, past_len, _ptr(past_dev), 1 if per_row else 0,
+                                                     ctx_max, _stream())
+        _lib.check(rc, "vly_decode_attention_merged")
+        return out
     rc = _lib.load().vly_decode_attention_split(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                                                 _ptr(key_valid), kv_stride, partials.data_ptr(), B, heads, past_len, _ptr(past_dev),
                                                 1 if per_row else 0, ctx_max, _stream())
