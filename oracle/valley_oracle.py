@@ -349,7 +349,7 @@ def build_additive_mask(attention_mask: Optional[torch.Tensor], B: int, q_len: i
 
 
 def llama_attention_block(h: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
-                          past: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                          past: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, attn_out: Optional[list] = None):
     """hf:llama/modeling_llama.py:217-289 (LlamaAttention.forward, eager): q/k/v projections, RoPE, KV concat,
     softmax(QK^T * hd^-0.5 + mask) V in fp32, o_proj.  h [B,S,H] is the NORMED hidden state; p ends in 'self_attn.'."""
     B, S, H = h.shape
@@ -364,6 +364,8 @@ def llama_attention_block(h: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, 
         v = torch.cat([past[1], v], dim=2)
     s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5) + mask
     a = _q(torch.softmax(s, dim=-1, dtype=torch.float32))
+    if attn_out is not None:                                 # HF's ``output_attentions``: the probabilities [B, heads, S, kv_len]
+        attn_out.append(a)
     o = _q(torch.matmul(a, v).transpose(1, 2).reshape(B, S, H))
     out = F.linear(o, _tw(w, p + "o_proj.weight"))
     # prefill hands the projection to the residual add as a bf16 tensor; the <= 8-row decode step adds in the GEMV epilogue
@@ -379,10 +381,10 @@ def llama_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
 
 
 def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
-                past: Optional[Tuple[torch.Tensor, torch.Tensor]]):
+                past: Optional[Tuple[torch.Tensor, torch.Tensor]], attn_out: Optional[list] = None):
     """hf:llama/modeling_llama.py:292-332 (pre-norm decoder layer)."""
     h = _q(rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps))
-    o, kv = llama_attention_block(h, w, p + "self_attn.", cfg, cos, sin, mask, past)
+    o, kv = llama_attention_block(h, w, p + "self_attn.", cfg, cos, sin, mask, past, attn_out)
     x = x + o
     h = _q(rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps))
     return x + llama_mlp(h, w, p + "mlp."), kv
@@ -391,9 +393,10 @@ def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
 def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,
                   attention_mask: Optional[torch.Tensor] = None,
                   past: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None,
-                  n_layers: Optional[int] = None):
+                  n_layers: Optional[int] = None, attn_out: Optional[list] = None):
     """hf:llama/modeling_llama.py:372-417: positions = arange(S) + past_len (independent of the
-    padding mask), final RMSNorm.  Returns (hidden [B,S,H], new past)."""
+    padding mask), final RMSNorm.  Returns (hidden [B,S,H], new past).  ``attn_out`` (a list) receives every layer's
+    attention probabilities (HF's ``output_attentions``, valley_model.py:281,324-330)."""
     B, S, H = inputs_embeds.shape
     past_len = 0 if past is None else past[0][0].shape[2]
     pos = (torch.arange(S) + past_len)[None].expand(B, S)
@@ -403,7 +406,7 @@ def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,
     new_past = []
     L = cfg.layers if n_layers is None else n_layers
     for i in range(L):
-        x, kv = llama_layer(x, w, f"model.layers.{i}.", cfg, cos, sin, mask, None if past is None else past[i])
+        x, kv = llama_layer(x, w, f"model.layers.{i}.", cfg, cos, sin, mask, None if past is None else past[i], attn_out)
         new_past.append(kv)
     return _q(rms_norm(x, _t(w, "model.norm.weight"), cfg.eps)), new_past
 
@@ -413,7 +416,7 @@ def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,
 # --------------------------------------------------------------------------------------------
 def valley_forward(input_ids: torch.Tensor, images, w: Dict, vw: Dict, lcfg: LlamaCfg, vcfg: VisionCfg,
                    tok: TokenIds, attention_mask: Optional[torch.Tensor] = None, past=None,
-                   select_layer: int = -2, method: str = "mean", vprefix: str = ""):
+                   select_layer: int = -2, method: str = "mean", vprefix: str = "", attn_out: Optional[list] = None):
     """ValleyLlamaForCausalLM.forward (valley_model.py:272-330) without the loss.
     images: [B,T,3,H,W] tensor or list of [T_i,3,H,W] (valley_model.py:168-184)."""
     emb = F.embedding(input_ids, _tw(w, "model.embed_tokens.weight"))
@@ -434,7 +437,7 @@ def valley_forward(input_ids: torch.Tensor, images, w: Dict, vw: Dict, lcfg: Lla
             emb = splice_visual_tokens(input_ids, emb, [mm_project(f, w) for f in raw], tok, method, w, pooled=pooled)
         else:
             emb = splice_visual_tokens(input_ids, emb, [mm_project(f, w) for f in raw], tok, method, w)
-    hidden, new_past = llama_forward(emb, w, lcfg, attention_mask, past)
+    hidden, new_past = llama_forward(emb, w, lcfg, attention_mask, past, attn_out=attn_out)
     logits = F.linear(hidden, _tw(w, "lm_head.weight"))
     return logits, new_past, emb
 

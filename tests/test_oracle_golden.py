@@ -104,3 +104,28 @@ def test_greedy_decode_loop():
     toks, lasts = O.greedy_decode(torch.from_numpy(ids), img1, G.llama_state(), G.vision_state(), lcfg, vcfg, tok, 4)
     assert (toks.numpy() == g["tokens"]).all()
     assert maxabs(lasts.numpy(), g["last_logits"]) < 5e-5
+
+
+def test_attention_probabilities_vs_reference_fixture():
+    """``output_attentions=True`` (valley_model.py:281, 324-330 -> HF LlamaModel's all_self_attns, eager attention): the oracle's
+    per-layer softmax probabilities against the reference's own tuple (g11, tools/gen_goldens_r4.py) — B = 2, one row
+    left-padded; rows of padded queries are don't-care (HF leaves a uniform row there)."""
+    g = np.load(os.path.join(GOLD, "g11_attentions.npz"))
+    lcfg, vcfg, tok = cfgs()
+    T = G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224)
+    at = []
+    with torch.no_grad():
+        logits, _, _ = O.valley_forward(torch.from_numpy(ids), images, dict(G.llama_state()), G.vision_state(), lcfg, vcfg, tok,
+                                        attention_mask=torch.from_numpy(mask), attn_out=at)
+    assert len(at) == int(g["n"]) == lcfg.layers
+    v = mask.astype(bool)[:, ::4]                            # valid QUERY rows of the sub-sampled fixture
+    S = ids.shape[1]
+    for i, a in enumerate(at):
+        assert tuple(a.shape) == (2, lcfg.heads, S, S)
+        got, ref = a.numpy()[:, :, ::4], g[f"attn{i}"]
+        for b in range(2):
+            assert maxabs(got[b][:, v[b]], ref[b][:, v[b]]) < TOL, (i, b)
+            assert np.all(got[b][:, v[b]][..., ~mask.astype(bool)[b]] == 0)      # padded keys get exactly zero
+    assert maxabs(logits.numpy()[:, ::4][v], g["logits"][v]) < 5e-5

@@ -303,5 +303,36 @@ def test_output_hidden_states_vs_reference_fixture():
         assert maxabs(out.logits.cpu().numpy()[:, ::4][v], g["logits"][v]) < (TOL_FP32 if precision == "fp32" else 4.5e-2)
         assert same < (1e-5 if precision == "fp32" else 4.5e-2)       # the collecting pass flushes the residual per layer: rounding order only
         assert plain.hidden_states is None
-    with pytest.raises(NotImplementedError):
-        model(output_attentions=True, **kw)
+
+
+
+def test_output_attentions_vs_reference_fixture():
+    """``output_attentions=True`` (valley_model.py:281, 324-330 -> HF LlamaModel's all_self_attns, which HF's eager attention
+    fills with softmax(QK^T / sqrt(d) + mask)) against the reference's own tuple (g11, tools/gen_goldens_r4.py; the CPU oracle is
+    pinned to the same fixture in tests/test_oracle_golden.py): fp32 mode within 1e-4, the half-precision production path at
+    its storage tolerance; padded keys exactly zero, valid rows sum to one; logits unchanged by the flag."""
+    g = np.load(os.path.join(GOLD, "g11_attentions.npz"))
+    T = G.GCFG["T"]
+    ids, mask = G.golden_ids("main")
+    images = torch.from_numpy(G.golden_pixels(2 * T, "main")).view(2, T, 3, 224, 224).cuda()
+    S = ids.shape[1]
+    vq = mask.astype(bool)[:, ::4]
+    for precision, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        model = build_model("mean", precision)
+        kw = dict(input_ids=torch.from_numpy(ids).cuda(), images=images, attention_mask=torch.from_numpy(mask).cuda())
+        out = model(output_attentions=True, **kw)
+        assert len(out.attentions) == int(g["n"]) == G.GCFG["L"]
+        errs = []
+        for i, a in enumerate(out.attentions):
+            assert tuple(a.shape) == (2, G.GCFG["heads"], S, S)
+            got = a.float().cpu().numpy()
+            for b in range(2):
+                rows = got[b][:, ::4][:, vq[b]]
+                errs.append(maxabs(rows, g[f"attn{i}"][b][:, vq[b]]))
+                assert np.all(rows[..., ~mask.astype(bool)[b]] == 0)
+                assert np.abs(rows.sum(-1) - 1).max() < (1e-5 if precision == "fp32" else 2e-2)
+        plain = model(**kw)
+        same = maxabs(out.logits.cpu().numpy(), plain.logits.cpu().numpy())
+        print(f"{precision}: attention probabilities max-abs vs the reference's {['%.2e' % e for e in errs]}, logits with/without the flag differ by {same:.1e}")
+        assert max(errs) < tol
+        assert same < (1e-5 if precision == "fp32" else 4.5e-2) and plain.attentions is None

@@ -882,6 +882,63 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     if (merged) split_merge_if_last(partials, merged, arrivals, heads, h, b, sc);
 }
 
+// ---- vly_llama_attention_probs: HF's ``output_attentions`` (round 4) -------------------------------------------------------
+// The flash-style kernels above never hold a row of probabilities; a caller that asks for them (valley_model.py:281,324-330
+// forwards the flag to HF's eager attention, hf:llama/modeling_llama.py:191-213) gets them from this separate pass over the
+// ROTATED q (left in the q|k|v buffer by vly_rope_kv / the fused epilogue) and the K cache: one workgroup per (query, head,
+// sequence), scores in LDS, fp32 softmax, fp32 out.  Not a hot path: it re-reads the K rows once per query.
+template <typename T> VLY_DEVICE float probs_ld(const T* p);
+template <> VLY_DEVICE float probs_ld<uint16_t>(const uint16_t* p) { return h2f(*p); }
+template <> VLY_DEVICE float probs_ld<float>(const float* p) { return *p; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_probs_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
+                                                         const uint8_t* __restrict__ key_valid, float* __restrict__ out, int S,
+                                                         int heads, int past, int kv_stride, int ctx_max) {
+    extern __shared__ float pr_sc[];                       // kv_len scores / probabilities
+    __shared__ float qs[128];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int kv_len = past + S, vis = past + i + 1, Hq = heads * 128;
+    const T* q = qkv + ((size_t)b * S + i) * 3 * Hq + h * 128;
+    const T* kb = kc + ((size_t)b * heads + h) * ctx_max * 128;
+    const uint8_t* kvld = key_valid ? key_valid + (size_t)b * kv_stride : nullptr;
+    if (tid < 128) qs[tid] = probs_ld(q + tid) * (0.08838834764831845f * LOG2E);
+    __syncthreads();
+    float m = NEG_BIG;
+    for (int j = tid; j < kv_len; j += 256) {
+        float s = NEG_BIG;
+        if (j < vis && (!kvld || kvld[j])) {
+            const T* kr = kb + (size_t)j * 128;
+            float a = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 128; ++d) a = fmaf(probs_ld(kr + d), qs[d], a);
+            s = a;
+        }
+        pr_sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int j = tid; j < kv_len; j += 256) {
+        const float s = pr_sc[j];
+        const float p = s > 0.5f * NEG_BIG ? sm_exp2(s - m) : 0.f;
+        pr_sc[j] = p;
+        l += p;
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+    const float inv = l > 0.f ? 1.f / l : 0.f;               // a query with no visible key (left padding): a row of zeros
+    float* o = out + (((size_t)b * heads + h) * S + i) * kv_len;
+    for (int j = tid; j < kv_len; j += 256) o[j] = pr_sc[j] * inv;
+}
+
 // the two kernels that are NOT the default of their op (kept for A/B runs and as each other's bit-identity witness:
 // VLY_VIT_ATTN=4 -> vit_attn4_kernel, VLY_LLAMA_ATTN=1 -> llama_attn_kernel)
 #include "attention_ab.inc"
@@ -1015,4 +1072,29 @@ static int decode_split_launch(const char* name, const void* qkv, void* kcache, 
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, partials, heads, past_len, past_len_dev,
                        key_valid_stride, ctx_max, past_len_dev_stride, (uint16_t*)merged, arrivals);
     return vly_check_launch(name);
+}
+
+extern "C" int vly_llama_attention_probs(const void* qkv, const void* kcache, const uint8_t* key_valid, int key_valid_stride,
+                                         float* out, int B, int S, int heads, int past_len, int ctx_max, int inputs_f32,
+                                         void* stream) {
+    const int kv_len = past_len + S;
+    if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || kv_len > ctx_max || kv_len > 16384 || B > 65535 || heads > 65535 || !qkv ||
+        !kcache || !out) {
+        vly_set_error("vly_llama_attention_probs: bad args B=%d S=%d heads=%d past=%d ctx_max=%d (kv_len <= 16384)", B, S, heads,
+                      past_len, ctx_max);
+        return -22;
+    }
+    if (key_valid && key_valid_stride < kv_len) {
+        vly_set_error("vly_llama_attention_probs: key_valid_stride %d < kv_len %d", key_valid_stride, kv_len);
+        return -22;
+    }
+    const dim3 grid(S, heads, B), block(256);
+    const size_t lds = (size_t)kv_len * 4;
+    if (inputs_f32)
+        hipLaunchKernelGGL(attn_probs_kernel<float>, grid, block, lds, (hipStream_t)stream, (const float*)qkv, (const float*)kcache,
+                           key_valid, out, S, heads, past_len, key_valid_stride, ctx_max);
+    else
+        hipLaunchKernelGGL(attn_probs_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, (const uint16_t*)qkv,
+                           (const uint16_t*)kcache, key_valid, out, S, heads, past_len, key_valid_stride, ctx_max);
+    return vly_check_launch("vly_llama_attention_probs");
 }

@@ -186,11 +186,13 @@ class HipLlama:
         return ws
 
     def forward(self, h: torch.Tensor, B: int, S: int, cache: HipKVCache, n_layers: Optional[int] = None,
-                collect: Optional[list] = None) -> torch.Tensor:
+                collect: Optional[list] = None, attn: Optional[list] = None) -> torch.Tensor:
         """h fp32 [B*S, H] (modified in place) -> final-norm hidden bf16 [B*S, H].  Appends S
         positions to ``cache``; key validity comes from cache.key_valid.  ``collect`` (a list): HF's ``output_hidden_states``
         (hf:llama/modeling_llama.py LlamaModel.forward) — receives the embeddings, every decoder layer's output (fp32
-        copies of the residual stream) and, last, the final-norm output; costs one residual flush + copy per layer."""
+        copies of the residual stream) and, last, the final-norm output; costs one residual flush + copy per layer.
+        ``attn`` (a list): HF's ``output_attentions`` — receives every layer's probabilities, fp32 [B, heads, S, kv_len]
+        (ops.attention_probs: a separate pass per layer behind the RoPE launch; the attention kernels themselves are unchanged)."""
         if not self.loaded:
             raise RuntimeError("Llama engine has no weights")
         past = cache.seq_len
@@ -199,12 +201,12 @@ class HipLlama:
             raise ValueError("cache batch mismatch")
         ops.sk_check_polled(self.device)                   # a stream-K hand-off failure of an earlier call surfaces here
         with runtime.stream_lock():                        # launch sequences on one stream must not interleave
-            out = self._forward_locked(h, B, S, cache, past, n_layers, collect)
+            out = self._forward_locked(h, B, S, cache, past, n_layers, collect, attn)
             if S > 1:
                 ops.sk_poll_async(self.device)
             return out
 
-    def _forward_locked(self, h, B, S, cache, past, n_layers, collect=None):
+    def _forward_locked(self, h, B, S, cache, past, n_layers, collect=None, attn=None):
         M = B * S
         ws = self._workspace(M)
         kv = cache.key_valid                                # uint8 [B, ctx_max] or None (row stride = ctx_max)
@@ -221,7 +223,12 @@ class HipLlama:
                 ops.add_norm(h, ws["delta"], L["ln1"], None, self.eps, out=ws["x"], rms=True, delta2=d2)
             else:
                 ops.rmsnorm(h, L["ln1"], self.eps, out=ws["x"])
-            if S == 1:                                      # one-token step: RoPE + append + attention fused
+            if attn is not None:                            # output_attentions: the unfused sequence leaves the rotated q in qkv
+                ops.gemm(ws["x"], W["w_qkv"], out=ws["qkv"])
+                ops.rope_kv(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
+                ops.llama_attention(ws["qkv"], cache.k[li], cache.v[li], kv, B, S, self.heads, past, out=ws["att"])
+                attn.append(ops.attention_probs(ws["qkv"], cache.k[li], kv, B, S, self.heads, past))
+            elif S == 1:                                    # one-token step: RoPE + append + attention fused
                 ops.gemm(ws["x"], W["w_qkv"], out=ws["qkv"])
                 ops.decode_attention(ws["qkv"], cache.k[li], cache.v[li], self.cos, self.sin, kv, B, self.heads, past,
                                      out=ws["att"])

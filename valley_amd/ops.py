@@ -869,6 +869,26 @@ def llama_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
     return out
 
 
+def attention_probs(qkv: torch.Tensor, kcache: torch.Tensor, key_valid: Optional[torch.Tensor], B: int, S: int, heads: int,
+                    past_len: int) -> torch.Tensor:
+    """vly_llama_attention_probs: HF's ``output_attentions`` for one layer — fp32 [B, heads, S, past_len + S] from the rotated
+    q in ``qkv`` and the rotated K cache (16-bit storage type or fp32, by ``qkv.dtype``).  A separate pass, not a hot path."""
+    if qkv.dtype != torch.float32:
+        _chk(qkv, runtime.HALF, "qkv")
+    assert kcache.dtype == qkv.dtype and qkv.is_contiguous() and kcache.is_contiguous()
+    ctx_max = kcache.shape[2]
+    kv_stride = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        assert key_valid.shape[0] == B and key_valid.shape[1] >= past_len + S
+        kv_stride = key_valid.stride(0)
+    out = torch.empty((B, heads, S, past_len + S), dtype=torch.float32, device=qkv.device)
+    rc = _lib.load().vly_llama_attention_probs(qkv.data_ptr(), kcache.data_ptr(), _ptr(key_valid), kv_stride, out.data_ptr(), B, S,
+                                               heads, past_len, ctx_max, 1 if qkv.dtype == torch.float32 else 0, _stream())
+    _lib.check(rc, "vly_llama_attention_probs")
+    return out
+
+
 def decode_attention(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                      key_valid: Optional[torch.Tensor], B: int, heads: int, past_len: int, out=None,
                      past_dev: Optional[torch.Tensor] = None) -> torch.Tensor:

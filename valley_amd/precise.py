@@ -248,7 +248,7 @@ class PreciseLlama:
         return F32KVCache(self.L, batch, self.heads, ctx_max or self.max_positions, self.device)
 
     def forward(self, h: torch.Tensor, B: int, S: int, cache: F32KVCache, n_layers: Optional[int] = None,
-                collect: Optional[list] = None) -> torch.Tensor:
+                collect: Optional[list] = None, attn: Optional[list] = None) -> torch.Tensor:
         """h fp32 [B*S, H] (modified in place) -> final-norm hidden fp32 [B*S, H]; appends S positions to ``cache``;
         ``collect`` as in HipLlama.forward (HF's output_hidden_states)."""
         if not self.loaded:
@@ -268,6 +268,9 @@ class PreciseLlama:
                 qkv = F.gemm(F.norm(h, L["ln1"], None, self.eps), L["w_qkv"])
                 F.rope_kv(qkv, cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
                 att = F.llama_attention(qkv, cache.k[li], cache.v[li], cache.key_valid, B, S, self.heads, past)
+                if attn is not None:                        # output_attentions (as HipLlama.forward): rotated q, rotated K cache
+                    from . import ops as _ops
+                    attn.append(_ops.attention_probs(qkv, cache.k[li], cache.key_valid, B, S, self.heads, past))
                 F.gemm(att, L["w_o"], residual=h, out=h)
                 mid = F.gemm(F.norm(h, L["ln2"], None, self.eps), L["w_gu"], epilogue=ops.EPI_SWIGLU)
                 F.gemm(mid, L["w_down"], residual=h, out=h)

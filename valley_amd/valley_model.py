@@ -326,10 +326,6 @@ class ValleyLlamaModel:
                 visual_tokens: Optional[torch.Tensor] = None, frames_per_clip: Optional[Sequence[int]] = None):
         """valley_model.py:135-254.  ``visual_tokens``/``frames_per_clip`` let a caller that already
         encoded (e.g. the frame-DP path, valley_amd/parallel.py) skip the tower."""
-        if output_attentions:
-            # the flash-style kernels never materialise the [B, heads, S, S] probabilities (valley_model.py:281 forwards the
-            # flag to HF's eager attention, which does); no caller on the path sets it
-            raise NotImplementedError("output_attentions: attention probabilities are not materialised by the HIP path")
         if inputs_embeds is not None:
             h = inputs_embeds.to(self.device, torch.float32).reshape(-1, self.config.hidden_size).contiguous().clone()
             B, S = inputs_embeds.shape[:2]
@@ -357,9 +353,13 @@ class ValleyLlamaModel:
                 n = min(am.shape[1], cache.ctx_max)
                 cache.key_valid[:, :n] = am[:, :n].to(torch.uint8)
         states = [] if output_hidden_states else None      # valley_model.py:282,324-330 -> HF LlamaModel's all_hidden_states
-        x = self.llama.forward(h, B, S, cache, collect=states)
+        # valley_model.py:281,324-330 -> HF LlamaModel's all_self_attns: per layer [B, heads, S, kv_len] in the model dtype (HF's
+        # eager attention returns the fp32 softmax cast to the query dtype); a separate pass per layer (ops.attention_probs)
+        attns = [] if output_attentions else None
+        x = self.llama.forward(h, B, S, cache, collect=states, attn=attns)
         return BaseModelOutputWithPast(last_hidden_state=x.view(B, S, -1), past_key_values=cache if use_cache else None,
-                                       hidden_states=None if states is None else tuple(t.view(B, S, -1) for t in states))
+                                       hidden_states=None if states is None else tuple(t.view(B, S, -1) for t in states),
+                                       attentions=None if attns is None else tuple(a.to(self.wdtype) for a in attns))
 
     __call__ = forward
 
@@ -540,7 +540,8 @@ class ValleyLlamaForCausalLM:
         if return_dict is False:
             return (logits, out.past_key_values)
         return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=out.past_key_values,
-                                      hidden_states=getattr(out, "hidden_states", None), attentions=None)
+                                      hidden_states=getattr(out, "hidden_states", None),
+                                      attentions=getattr(out, "attentions", None))
 
     __call__ = forward
 
