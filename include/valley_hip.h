@@ -206,6 +206,14 @@ int vly_delta_attention(const void *q_bf16, const void *kv_bf16, void *out_bf16,
                         int nhead, void *stream);
 int vly_delta_finish(const float *delta_f32, const float *mean_f32, const float *feats_f32, void *out_bf16,
                      int B, int T, int H, void *stream);
+/* The same three with fp32 operands throughout (the fp32 "precise" mode, round 4: nothing rounded; GEMMs through vly_gemm_f32,
+ *   norms through vly_norm_f32).  x_last has no 16-bit twin here. */
+int vly_delta_prep_f32(const float *feats_f32, const float *pos_f32, float *x_all_f32, float *x_last_f32, float *mean_f32,
+                       int B, int T, int H, void *stream);
+int vly_delta_attention_f32(const float *q_f32, const float *kv_f32, float *out_f32, int nseq, int T, int H, int nhead,
+                            void *stream);
+int vly_delta_finish_f32(const float *delta_f32, const float *mean_f32, const float *feats_f32, float *out_f32, int B, int T,
+                         int H, void *stream);
 
 /* Token-embedding gather + visual-token splice -> fp32 residual stream:
  *   row_map int32 [R]: v >= 0 -> embed_table[v];  v < 0 -> visual[-v-1].

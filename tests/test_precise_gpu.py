@@ -172,7 +172,7 @@ def test_fp32_mode_tower_vs_reference_fixture():
         assert maxabs(h.cpu().numpy()[:, ::8, ::4], g[f"hs{i}"]) < 2e-4, i
 
 
-@pytest.mark.parametrize("method", ["mean", "max", "temporal_importance"])
+@pytest.mark.parametrize("method", ["mean", "max", "temporal_importance", "temporal_transformer"])
 def test_fp32_mode_logits_within_1e3_of_reference(method):
     """The north-star bound on the reference-captured fixtures: B = 2, left-padded, mixed text / visual tokens."""
     g = np.load(os.path.join(GOLD, f"g2_forward_{method}.npz"))

@@ -12,9 +12,24 @@
 
 namespace {
 
+// storage type of the GEMM operands these kernels write / read: the library's 16-bit type, or fp32 (the *_f32 entry points
+// of the fp32 "precise" mode, round 4: the same kernels with nothing rounded)
+VLY_DEVICE void st4(uint16_t* p, float4 x) {
+    u32x2 pk;
+    pk[0] = pack_h2(x.x, x.y);
+    pk[1] = pack_h2(x.z, x.w);
+    *(u32x2*)p = pk;
+}
+VLY_DEVICE void st4(float* p, float4 x) { *(float4*)p = x; }
+VLY_DEVICE float ld1(const uint16_t* p) { return h2f(*p); }
+VLY_DEVICE float ld1(const float* p) { return *p; }
+VLY_DEVICE void st1(uint16_t* p, float x) { *p = f2h(x); }
+VLY_DEVICE void st1(float* p, float x) { *p = x; }
+
 // thread per (clip b, patch p, 4 columns): walks the T frames once.
+template <typename ST>
 __global__ void __launch_bounds__(256) delta_prep_kernel(const float* __restrict__ feats, const float* __restrict__ pos,
-                                                         uint16_t* __restrict__ x_all, uint16_t* __restrict__ x_last16,
+                                                         ST* __restrict__ x_all, ST* __restrict__ x_last16,
                                                          float* __restrict__ x_last32, float* __restrict__ mean, int B, int T, int H) {
     const int hv = H >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -29,12 +44,9 @@ __global__ void __launch_bounds__(256) delta_prep_kernel(const float* __restrict
         const float4 q = ((const float4*)(pos + (size_t)t * H))[c];
         m.x += a.x; m.y += a.y; m.z += a.z; m.w += a.w;
         const float4 x = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
-        u32x2 pk;
-        pk[0] = pack_h2(x.x, x.y);
-        pk[1] = pack_h2(x.z, x.w);
-        *(u32x2*)(x_all + ((size_t)bp * T + t) * H + 4 * c) = pk;
+        st4(x_all + ((size_t)bp * T + t) * H + 4 * c, x);
         if (t == T - 1) {
-            *(u32x2*)(x_last16 + (size_t)bp * H + 4 * c) = pk;
+            if (x_last16) st4(x_last16 + (size_t)bp * H + 4 * c, x);
             ((float4*)(x_last32 + (size_t)bp * H))[c] = x;
         }
     }
@@ -44,9 +56,9 @@ __global__ void __launch_bounds__(256) delta_prep_kernel(const float* __restrict
 
 // one wave per (sequence, head): q [hd] against T keys, softmax over T, weighted sum of T values.
 // kv bf16 [nseq*T, 2H] (k | v), q bf16 [nseq, H], out bf16 [nseq, H].  hd = H/8 <= 1024, T <= 32.
-template <int EPL>                                              // elements per lane (hd <= 64*EPL)
-__global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kv,
-                                                         uint16_t* __restrict__ out, int nseq, int T, int H, int nhead) {
+template <int EPL, typename ST>                                  // elements per lane (hd <= 64*EPL)
+__global__ void __launch_bounds__(256) delta_attn_kernel(const ST* __restrict__ q, const ST* __restrict__ kv,
+                                                         ST* __restrict__ out, int nseq, int T, int H, int nhead) {
     const int lane = threadIdx.x & 63;
     const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= (long)nseq * nhead) return;
@@ -58,7 +70,7 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int d = lane + 64 * e;
-        qv[e] = d < hd ? h2f(q[(size_t)s * H + h * hd + d]) * scale : 0.f;
+        qv[e] = d < hd ? ld1(q + (size_t)s * H + h * hd + d) * scale : 0.f;
     }
     float sc[32];
     float mx = -1e30f;
@@ -66,12 +78,12 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
     for (int t = 0; t < 32; ++t) {
         sc[t] = -1e30f;
         if (t < T) {
-            const uint16_t* kr = kv + ((size_t)s * T + t) * 2 * H + h * hd;
+            const ST* kr = kv + ((size_t)s * T + t) * 2 * H + h * hd;
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int d = lane + 64 * e;
-                if (d < hd) a = fmaf(qv[e], h2f(kr[d]), a);
+                if (d < hd) a = fmaf(qv[e], ld1(kr + d), a);
             }
             a = wave_sum(a);
             sc[t] = a;
@@ -91,11 +103,11 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         if (t < T) {
-            const uint16_t* vr = kv + ((size_t)s * T + t) * 2 * H + H + h * hd;
+            const ST* vr = kv + ((size_t)s * T + t) * 2 * H + H + h * hd;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int d = lane + 64 * e;
-                if (d < hd) o[e] = fmaf(sc[t], h2f(vr[d]), o[e]);
+                if (d < hd) o[e] = fmaf(sc[t], ld1(vr + d), o[e]);
             }
         }
     }
@@ -103,13 +115,14 @@ __global__ void __launch_bounds__(256) delta_attn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int d = lane + 64 * e;
-        if (d < hd) out[(size_t)s * H + h * hd + d] = f2h(o[e] * inv);
+        if (d < hd) st1(out + (size_t)s * H + h * hd + d, o[e] * inv);
     }
 }
 
 // out bf16 [B, 256+T, H]: rows < 256 = delta + mean, rows >= 256 = CLS token of frame r-256.
+template <typename ST>
 __global__ void __launch_bounds__(256) delta_finish_kernel(const float* __restrict__ delta, const float* __restrict__ mean,
-                                                           const float* __restrict__ feats, uint16_t* __restrict__ out,
+                                                           const float* __restrict__ feats, ST* __restrict__ out,
                                                            int B, int T, int H) {
     const int hv = H >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -126,47 +139,76 @@ __global__ void __launch_bounds__(256) delta_finish_kernel(const float* __restri
     } else {
         o = ((const float4*)(feats + ((size_t)b * T + (r - 256)) * 257 * H))[c];
     }
-    u32x2 pk;
-    pk[0] = pack_h2(o.x, o.y);
-    pk[1] = pack_h2(o.z, o.w);
-    *(u32x2*)(out + ((size_t)b * (256 + T) + r) * H + 4 * c) = pk;
+    st4(out + ((size_t)b * (256 + T) + r) * H + 4 * c, o);
 }
 
 }  // namespace
 
-extern "C" int vly_delta_prep(const float* feats, const float* pos, void* x_all, void* x_last_bf16, float* x_last_f32,
-                              float* mean, int B, int T, int H, void* stream) {
-    if (B <= 0 || T <= 0 || H <= 0 || H % 4) { vly_set_error("vly_delta_prep: bad args B=%d T=%d H=%d", B, T, H); return -22; }
+template <typename ST>
+static int delta_prep_launch(const char* name, const float* feats, const float* pos, ST* x_all, ST* x_last, float* x_last_f32,
+                             float* mean, int B, int T, int H, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || H % 4) { vly_set_error("%s: bad args B=%d T=%d H=%d", name, B, T, H); return -22; }
     const long n = (long)B * 256 * (H / 4);
-    hipLaunchKernelGGL(delta_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feats, pos,
-                       (uint16_t*)x_all, (uint16_t*)x_last_bf16, x_last_f32, mean, B, T, H);
-    return vly_check_launch("vly_delta_prep");
+    hipLaunchKernelGGL(delta_prep_kernel<ST>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feats, pos,
+                       x_all, x_last, x_last_f32, mean, B, T, H);
+    return vly_check_launch(name);
 }
 
-extern "C" int vly_delta_attention(const void* q, const void* kv, void* out, int nseq, int T, int H, int nhead, void* stream) {
+extern "C" int vly_delta_prep(const float* feats, const float* pos, void* x_all, void* x_last_bf16, float* x_last_f32,
+                              float* mean, int B, int T, int H, void* stream) {
+    return delta_prep_launch("vly_delta_prep", feats, pos, (uint16_t*)x_all, (uint16_t*)x_last_bf16, x_last_f32, mean, B, T, H, stream);
+}
+
+extern "C" int vly_delta_prep_f32(const float* feats, const float* pos, float* x_all, float* x_last, float* mean, int B, int T,
+                                  int H, void* stream) {
+    return delta_prep_launch<float>("vly_delta_prep_f32", feats, pos, x_all, nullptr, x_last, mean, B, T, H, stream);
+}
+
+template <typename ST>
+static int delta_attention_launch(const char* name, const ST* q, const ST* kv, ST* out, int nseq, int T, int H, int nhead,
+                                  void* stream) {
     if (nseq <= 0 || T <= 0 || T > 32 || H <= 0 || nhead <= 0 || H % nhead || H / nhead > 1024) {
-        vly_set_error("vly_delta_attention: bad args nseq=%d T=%d H=%d nhead=%d (T <= 32, head_dim <= 1024)", nseq, T, H, nhead);
+        vly_set_error("%s: bad args nseq=%d T=%d H=%d nhead=%d (T <= 32, head_dim <= 1024)", name, nseq, T, H, nhead);
         return -22;
     }
     const long units = (long)nseq * nhead;
     dim3 grid((unsigned)((units + 3) / 4)), block(256);
     const int epl = (H / nhead + 63) / 64;
-#define VLY_DA(E) hipLaunchKernelGGL((delta_attn_kernel<E>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)q, \
-                                     (const uint16_t*)kv, (uint16_t*)out, nseq, T, H, nhead)
+#define VLY_DA(E) hipLaunchKernelGGL((delta_attn_kernel<E, ST>), grid, block, 0, (hipStream_t)stream, q, kv, out, nseq, T, H, nhead)
     if (epl <= 1) VLY_DA(1);
     else if (epl <= 4) VLY_DA(4);
     else if (epl <= 8) VLY_DA(8);
     else if (epl <= 10) VLY_DA(10);
     else VLY_DA(16);
 #undef VLY_DA
-    return vly_check_launch("vly_delta_attention");
+    return vly_check_launch(name);
+}
+
+extern "C" int vly_delta_attention(const void* q, const void* kv, void* out, int nseq, int T, int H, int nhead, void* stream) {
+    return delta_attention_launch("vly_delta_attention", (const uint16_t*)q, (const uint16_t*)kv, (uint16_t*)out, nseq, T, H, nhead,
+                                  stream);
+}
+
+extern "C" int vly_delta_attention_f32(const float* q, const float* kv, float* out, int nseq, int T, int H, int nhead, void* stream) {
+    return delta_attention_launch("vly_delta_attention_f32", q, kv, out, nseq, T, H, nhead, stream);
+}
+
+template <typename ST>
+static int delta_finish_launch(const char* name, const float* delta, const float* mean, const float* feats, ST* out, int B, int T,
+                               int H, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || H % 4) { vly_set_error("%s: bad args", name); return -22; }
+    const long n = (long)B * (256 + T) * (H / 4);
+    hipLaunchKernelGGL(delta_finish_kernel<ST>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, mean,
+                       feats, out, B, T, H);
+    return vly_check_launch(name);
 }
 
 extern "C" int vly_delta_finish(const float* delta, const float* mean, const float* feats, void* out, int B, int T, int H,
                                 void* stream) {
-    if (B <= 0 || T <= 0 || H <= 0 || H % 4) { vly_set_error("vly_delta_finish: bad args"); return -22; }
-    const long n = (long)B * (256 + T) * (H / 4);
-    hipLaunchKernelGGL(delta_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, mean,
-                       feats, (uint16_t*)out, B, T, H);
-    return vly_check_launch("vly_delta_finish");
+    return delta_finish_launch("vly_delta_finish", delta, mean, feats, (uint16_t*)out, B, T, H, stream);
+}
+
+extern "C" int vly_delta_finish_f32(const float* delta, const float* mean, const float* feats, float* out, int B, int T, int H,
+                                    void* stream) {
+    return delta_finish_launch("vly_delta_finish_f32", delta, mean, feats, out, B, T, H, stream);
 }

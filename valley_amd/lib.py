@@ -39,6 +39,9 @@ _SIGS = {
     "vly_delta_prep": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vly_delta_attention": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vly_delta_finish": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vly_delta_prep_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vly_delta_attention_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vly_delta_finish_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vly_embed_splice": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "vly_rope_kv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_llama_attention": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -126,3 +126,39 @@ def embed_splice(row_map: torch.Tensor, embed: torch.Tensor, visual: Optional[to
     rc = _lib.load().vly_embed_splice_f32(row_map.data_ptr(), embed.data_ptr(), _ptr(visual), out.data_ptr(), R, H, _stream())
     _lib.check(rc, "vly_embed_splice_f32")
     return out
+
+
+def delta_prep(feats: torch.Tensor, pos: torch.Tensor, B: int, T: int):
+    """vly_delta_prep_f32: projected feats fp32 [B*T*257, H] -> (x_all fp32 [B*256*T, H], x_last fp32, mean fp32 [B*256, H])."""
+    _chk(feats, F32, "feats")
+    _chk(pos, F32, "pos")
+    H, d = feats.shape[-1], feats.device
+    assert feats.numel() == B * T * 257 * H and pos.shape[0] >= T and pos.shape[1] == H
+    x_all = torch.empty((B * 256 * T, H), dtype=F32, device=d)
+    x_last = torch.empty((B * 256, H), dtype=F32, device=d)
+    mean = torch.empty((B * 256, H), dtype=F32, device=d)
+    rc = _lib.load().vly_delta_prep_f32(feats.data_ptr(), pos.data_ptr(), x_all.data_ptr(), x_last.data_ptr(), mean.data_ptr(), B, T, H,
+                                        _stream())
+    _lib.check(rc, "vly_delta_prep_f32")
+    return x_all, x_last, mean
+
+
+def delta_attention(q: torch.Tensor, kv: torch.Tensor, T: int, nhead: int) -> torch.Tensor:
+    _chk(q, F32, "q")
+    _chk(kv, F32, "kv")
+    nseq, H = q.shape
+    assert tuple(kv.shape) == (nseq * T, 2 * H)
+    out = torch.empty_like(q)
+    rc = _lib.load().vly_delta_attention_f32(q.data_ptr(), kv.data_ptr(), out.data_ptr(), nseq, T, H, nhead, _stream())
+    _lib.check(rc, "vly_delta_attention_f32")
+    return out
+
+
+def delta_finish(delta: torch.Tensor, mean: torch.Tensor, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    _chk(delta, F32, "delta")
+    _chk(mean, F32, "mean")
+    H = delta.shape[-1]
+    out = torch.empty((B, 256 + T, H), dtype=F32, device=delta.device)
+    rc = _lib.load().vly_delta_finish_f32(delta.data_ptr(), mean.data_ptr(), feats.data_ptr(), out.data_ptr(), B, T, H, _stream())
+    _lib.check(rc, "vly_delta_finish_f32")
+    return out

@@ -253,10 +253,14 @@ class ValleyLlamaModel:
     def _pool_precise(self, feats: torch.Tensor, Ts: List[int], method: str):
         """fp32 mode, in the REFERENCE's order for every variant: project all tokens (valley_model.py:190), then pool
         (:206-215) — no pool-before-project reordering, no bf16 anywhere.  Returns projected tokens fp32 [sum(256+T), H]."""
-        if method == "temporal_transformer":
-            raise NotImplementedError("the v3 temporal transformer has no fp32 mode (its attention kernel is bf16); use the bf16 path")
         proj = ops_f32.gemm(feats.view(-1, 1024), self.mm_projector.weight, self.mm_projector.bias)
         W = proj.shape[-1]
+        if method == "temporal_transformer":                 # round 4: the v3 encoder layer with fp32 operands throughout
+            outs, f0 = [], 0
+            for T in Ts:
+                outs.append(self._temporal_transformer_delta_f32(proj.view(-1, 257, W)[f0:f0 + T].reshape(-1, W), 1, T).view(-1, W))
+                f0 += T
+            return (outs[0] if len(outs) == 1 else torch.cat(outs, 0)), Ts
         mode = {"mean": ops.POOL_MEAN, "max": ops.POOL_MAX, "temporal_importance": ops.POOL_IMPORTANCE}[method]
         scores = None
         if method == "temporal_importance":
@@ -287,6 +291,23 @@ class ValleyLlamaModel:
         h2 = ops.gemm(f, de["w_2"], de["b_2"], residual=y32, out_dtype=torch.float32)
         _, delta = ops.layernorm(h2, de["n2_g"], de["n2_b"], 1e-5, want_f32=True)
         return ops.delta_finish(delta, mean, feats, B, T)
+
+    def _temporal_transformer_delta_f32(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """temporal_transformer_delta in the fp32 mode: the same sequence through vly_delta_*_f32 / vly_gemm_f32 / vly_norm_f32
+        (valley_model.py:123-133) -> fp32 [B, 256+T, H]."""
+        de = self.delta_encoder
+        if de is None:
+            raise RuntimeError("temporal_transformer pooling needs model.transformer_delta_encoder weights")
+        x_all, x32, mean = ops_f32.delta_prep(feats, de["pos"], B, T)
+        kv = ops_f32.gemm(x_all, de["w_kv"], de["b_kv"])
+        q = ops_f32.gemm(x32, de["w_q"], de["b_q"])
+        att = ops_f32.delta_attention(q, kv, T, 8)
+        h1 = ops_f32.gemm(att, de["w_o"], de["b_o"], residual=x32)
+        y = ops_f32.norm(h1, de["n1_g"], de["n1_b"], 1e-5)
+        f = ops_f32.gemm(y, de["w_1"], de["b_1"], epilogue=ops.EPI_RELU)
+        h2 = ops_f32.gemm(f, de["w_2"], de["b_2"], residual=y)
+        delta = ops_f32.norm(h2, de["n2_g"], de["n2_b"], 1e-5)
+        return ops_f32.delta_finish(delta, mean, feats, B, T)
 
     def project_pooled(self, pooled: torch.Tensor) -> torch.Tensor:
         """pooled bf16 [NV, 1024] -> visual tokens bf16 [NV, H] (mm_projector, valley_model.py:190)."""
@@ -480,7 +501,7 @@ class ValleyLlamaForCausalLM:
                 bias=_dev(sd["model.pooling_layer.bias"], self.device, torch.float32).reshape(-1))
         pfx = "model.transformer_delta_encoder.layers.0."
         if pfx + "self_attn.in_proj_weight" in sd:            # v3 temporal transformer (valley_model.py:45-52)
-            d, bf, f32 = self.device, runtime.HALF, torch.float32
+            d, bf, f32 = self.device, self.model.wdtype, torch.float32     # (fp32 mode: fp32 GEMM weights)
             H = self.config.hidden_size
             win, bin_ = _dev(sd[pfx + "self_attn.in_proj_weight"], d, bf), _dev(sd[pfx + "self_attn.in_proj_bias"], d, f32)
             self.model.delta_encoder = dict(
