@@ -38,6 +38,52 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(const uint16_t* _
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Whole groups of SK_UNROLL steps (every shape the ViT remainders have: kq = 256): no guards, so the 16 loads of a group
+    // leave back to back and the MFMAs count them down (round 4: with the guarded loop below hipcc peeled the wave-uniform
+    // `if`s into paths that wait vmcnt(0) behind one to three loads — 17.8 us for 128 x 1024 x 4096).  With four waves
+    // (256 threads, registers to spare) the NEXT group's loads leave before this group's MFMAs.
+    const int groups = (kq % (32 * SK_UNROLL) == 0) ? kq / (32 * SK_UNROLL) : 0;
+    if (groups > 0) {
+        bf16x8 fa0[SK_UNROLL], fa1[SK_UNROLL], fw0[SK_UNROLL], fw1[SK_UNROLL];
+        auto load_group = [&](bf16x8 (&xa0)[SK_UNROLL], bf16x8 (&xa1)[SK_UNROLL], bf16x8 (&xw0)[SK_UNROLL], bf16x8 (&xw1)[SK_UNROLL],
+                              int k) {
+#pragma unroll
+            for (int u = 0; u < SK_UNROLL; ++u) {
+                xw0[u] = *(const bf16x8*)(w0 + k + 32 * u);
+                xw1[u] = *(const bf16x8*)(w1 + k + 32 * u);
+                xa0[u] = *(const bf16x8*)(a0 + k + 32 * u);
+                xa1[u] = *(const bf16x8*)(a1 + k + 32 * u);
+            }
+        };
+        auto mfma_group = [&](const bf16x8 (&xa0)[SK_UNROLL], const bf16x8 (&xa1)[SK_UNROLL], const bf16x8 (&xw0)[SK_UNROLL],
+                              const bf16x8 (&xw1)[SK_UNROLL]) {
+#pragma unroll
+            for (int u = 0; u < SK_UNROLL; ++u) {
+                acc[0][0] = mfma16(xw0[u], xa0[u], acc[0][0]);
+                acc[0][1] = mfma16(xw1[u], xa0[u], acc[0][1]);
+                acc[1][0] = mfma16(xw0[u], xa1[u], acc[1][0]);
+                acc[1][1] = mfma16(xw1[u], xa1[u], acc[1][1]);
+            }
+        };
+        load_group(fa0, fa1, fw0, fw1, 0);
+        if constexpr (NWV == 4) {
+            bf16x8 ga0[SK_UNROLL], ga1[SK_UNROLL], gw0[SK_UNROLL], gw1[SK_UNROLL];
+#pragma unroll 1
+            for (int it = 0; it < groups; it += 2) {
+                if (it + 1 < groups) load_group(ga0, ga1, gw0, gw1, (it + 1) * 32 * SK_UNROLL);
+                mfma_group(fa0, fa1, fw0, fw1);
+                if (it + 1 >= groups) break;
+                if (it + 2 < groups) load_group(fa0, fa1, fw0, fw1, (it + 2) * 32 * SK_UNROLL);
+                mfma_group(ga0, ga1, gw0, gw1);
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < groups; ++it) {
+                mfma_group(fa0, fa1, fw0, fw1);
+                if (it + 1 < groups) load_group(fa0, fa1, fw0, fw1, (it + 1) * 32 * SK_UNROLL);
+            }
+        }
+    } else
     for (int k = 0; k < kq; k += 32 * SK_UNROLL) {
         bf16x8 fa0[SK_UNROLL], fa1[SK_UNROLL], fw0[SK_UNROLL], fw1[SK_UNROLL];
 #pragma unroll
