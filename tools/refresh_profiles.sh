@@ -32,4 +32,4 @@ d=json.loads([l for l in open('$O/bench_default.json') if l.startswith('{')][-1]
 print('c3', d['value'], d['ms_per_step'], d['stages']['vit_frac_of_bf16_peak'], d['stages']['prefill_frac_of_bf16_peak'], 'roofline', d['roofline']['frac'], d['roofline']['avg_launch_us'], d['roofline'].get('traffic_over_algorithmic'))
 for k,v in d.get('also',{}).items(): print(k, v.get('value'), v.get('ms_per_step'), v.get('error'))
 PY
-head -12 $O/c3_kernel_stats.csv; head -8 $O/decode_kernel_stats.csv
+head -12 $O/c3_kernel_stats.csv | cut -c1-140; head -8 $O/decode_kernel_stats.csv | cut -c1-140
