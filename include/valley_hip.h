@@ -257,7 +257,7 @@ int vly_llama_attention(const void *qkv_bf16, const void *kcache_bf16, const voi
 /* HF's ``output_attentions`` for one layer: the softmax probabilities of vly_llama_attention's problem,
  *   out fp32 [B, heads, S, kv_len = past_len + S] (zero where a key is masked; a query with no visible key gets a row of
  *   zeros).  qkv holds the ROTATED q in its first third (after vly_rope_kv / vly_gemm_bf16_qkv_rope), kcache the rotated K.
- *   inputs_f32 = 1: fp32 q|k|v rows and fp32 cache (the precise engines).  kv_len <= 16384.  A separate pass, not a hot path.
+ *   inputs_f32 = 1: fp32 q|k|v rows and fp32 cache (the precise engines).  kv_len <= 16000 (its scores live in LDS).  A separate pass, not a hot path.
  *   valley_model.py:281,324-330 -> hf:llama/modeling_llama.py:191-213 (eager attention returns attn_weights). */
 int vly_llama_attention_probs(const void *qkv, const void *kcache, const uint8_t *key_valid, int key_valid_stride,
                               float *out, int B, int S, int heads, int past_len, int ctx_max, int inputs_f32, void *stream);

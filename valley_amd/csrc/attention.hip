@@ -1078,9 +1078,9 @@ extern "C" int vly_llama_attention_probs(const void* qkv, const void* kcache, co
                                          float* out, int B, int S, int heads, int past_len, int ctx_max, int inputs_f32,
                                          void* stream) {
     const int kv_len = past_len + S;
-    if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || kv_len > ctx_max || kv_len > 16384 || B > 65535 || heads > 65535 || !qkv ||
+    if (B <= 0 || S <= 0 || heads <= 0 || past_len < 0 || kv_len > ctx_max || kv_len > 16000 || B > 65535 || heads > 65535 || !qkv ||
         !kcache || !out) {
-        vly_set_error("vly_llama_attention_probs: bad args B=%d S=%d heads=%d past=%d ctx_max=%d (kv_len <= 16384)", B, S, heads,
+        vly_set_error("vly_llama_attention_probs: bad args B=%d S=%d heads=%d past=%d ctx_max=%d (kv_len <= 16000)", B, S, heads,
                       past_len, ctx_max);
         return -22;
     }
