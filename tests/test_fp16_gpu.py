@@ -33,6 +33,17 @@ def test_fp16_library_passes_the_reference_fixture_tests():
     assert r.returncode == 0, tail
 
 
+def test_fp16_library_passes_the_round4_decode_and_attention_tests():
+    """The round-4 entry points on the fp16 build: the merged / persistent decode steps stay bit-identical to the launches they
+    replace, and ``output_attentions`` meets the reference fixture (the "bf16" arm of that test = the library's storage type)."""
+    r = _run(["-m", "pytest", "tests/test_decode_merge_gpu.py", "tests/test_decode_persistent_gpu.py", "tests/test_precise_gpu.py",
+              "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+              "-k", "13b-1-328 or 7b-2-200 or per_row or output_attentions or hidden_states or rejects"], "fp16", timeout=1200)
+    tail = r.stdout.decode(errors="replace")[-1500:]
+    print(tail)
+    assert r.returncode == 0, tail
+
+
 def test_fp16_is_closer_to_fp32_than_bf16():
     res = {}
     for prec in ("bf16", "fp16"):

@@ -90,6 +90,20 @@ VLY_DEVICE float vly_mul_add(float a, float b, float c) {       // a * b + c, tw
 #pragma clang fp contract(off)
     return a * b + c;
 }
+// Eight products of two packed 16-byte operands as a chain of eight fmas, low element first — the GEMVs' inner step.  With
+// contraction allowed, hipcc may fold two fmas on the halves of one fp16 register into ONE v_dot2_f32_f16 (other intermediate
+// rounding) in one kernel and not in another: round 4's persistent decode step then differed from the launches on the fp16
+// build only.  Pinned: explicit fmas, never re-associated.
+VLY_DEVICE float vly_dot8(const u32x4& w, const u32x4& a) {
+#pragma clang fp contract(off)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s = __builtin_fmaf(h_lo(w[i]), h_lo(a[i]), s);
+        s = __builtin_fmaf(h_hi(w[i]), h_hi(a[i]), s);
+    }
+    return s;
+}
 
 // Butterfly reductions over the 64 lanes: v (+)= v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 — every lane ends with the total, summed in
 // that fixed order.  __shfl_xor compiles to ds_bpermute (an LDS-crossbar round trip per step, ~12 issue slots + 6 lgkmcnt waits per

@@ -129,15 +129,7 @@ VLY_DEVICE int opaque_i32(int v) {
     return v;
 }
 
-VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {          // gemv_bf16.hip's, operation for operation
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s = fmaf(h_lo(w[i]), h_lo(a[i]), s);
-        s = fmaf(h_hi(w[i]), h_hi(a[i]), s);
-    }
-    return s;
-}
+VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) { return vly_dot8(w, a); }      // common.hpp: one definition for both files
 
 // ---- the weight stream ------------------------------------------------------------------------------------------------
 // A UNIT is NR weight rows (NR = 2: a row pair of q|k|v / o / gate|up — gate and up of one SwiGLU output; NR = 1: one row

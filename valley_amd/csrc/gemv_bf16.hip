@@ -8,15 +8,7 @@
 
 namespace {
 
-VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s = fmaf(h_lo(w[i]), h_lo(a[i]), s);
-        s = fmaf(h_hi(w[i]), h_hi(a[i]), s);
-    }
-    return s;
-}
+VLY_DEVICE float dot8(const u32x4& w, const u32x4& a) { return vly_dot8(w, a); }      // common.hpp: one definition for both files
 
 // KS = 1: every wave owns NR weight rows (short rows).  KS = 4 (K >= 2048, i.e. every decode projection): the
 // workgroup owns NR rows and its four waves split K, partial sums meet in LDS — four times the waves, hence
@@ -93,7 +85,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const uint16_t* __restrict__ 
                 v1 = x_sigmoid(v1, 1.702f);
             }
             if constexpr (EPI == VLY_EPI_SWIGLU) {
-                const float o = x_sigmoid(v0, 1.f) * v1;
+                float o = x_sigmoid(v0, 1.f) * v1;
+                // the product is an fp32 VALUE before it is stored: on the fp16 build hipcc otherwise folds multiply + conversion
+                // into v_fma_mixlo_f16 (one rounding of the exact product), a last bit away from what a consumer of the fp32
+                // value (vly_decode_layers' fp32 scratch) rounds to
+                asm volatile("" : "+v"(o));
                 const size_t off = (size_t)m * ldc + (n >> 1);
                 if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f2h(o);
                 else ((float*)Cv)[off] = o;
@@ -251,7 +247,11 @@ __global__ void __launch_bounds__(1024) gemv_norm_kernel(const float* __restrict
             for (int wv = 1; wv < 4; ++wv) { s0 += rd[(wv * MR + m) * 2]; s1 += rd[(wv * MR + m) * 2 + 1]; }
             float v0 = s0 + b0, v1 = s1 + b1;
             if constexpr (EPI == VLY_EPI_SWIGLU) {
-                const float o = x_sigmoid(v0, 1.f) * v1;
+                float o = x_sigmoid(v0, 1.f) * v1;
+                // the product is an fp32 VALUE before it is stored: on the fp16 build hipcc otherwise folds multiply + conversion
+                // into v_fma_mixlo_f16 (one rounding of the exact product), a last bit away from what a consumer of the fp32
+                // value (vly_decode_layers' fp32 scratch) rounds to
+                asm volatile("" : "+v"(o));
                 const size_t off = (size_t)m * ldc + (n0 >> 1);
                 if constexpr (OUT == VLY_OUT_BF16) ((uint16_t*)Cv)[off] = f2h(o);
                 else ((float*)Cv)[off] = o;
