@@ -579,6 +579,29 @@ def test_gemm_online_tuner_decides_and_stays_correct(monkeypatch, tmp_path):
     assert ops.sk_error_flag(dev()) == 0
 
 
+def test_gemm_without_online_trials_is_one_kernel_from_the_first_call(monkeypatch):
+    """VALLEY_TUNE_ONLINE=0 (round 4): a shape the table does not know takes the static whole-tile choice — no candidate
+    trials, nothing pending, and every call returns the SAME bits (in-place trials return valid results that differ by fp32
+    summation order between candidates)."""
+    from valley_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", "tuned")
+    monkeypatch.setattr(ops, "TUNE_ONLINE", False)
+    monkeypatch.setattr(ops, "_TUNED", {})
+    monkeypatch.setattr(ops, "_ONLINE", {})
+    M, N, K = 1312, 1024, 512
+    a = rnd((M, K), 11, dtype=torch.bfloat16).to(dev())
+    w = rnd((N, K), 12, 0.05, dtype=torch.bfloat16).to(dev())
+    bias = rnd((N,), 13, 0.5).to(dev())
+    ref = a.float() @ w.float().t() + bias
+    first = ops.gemm(a, w, bias, out_dtype=torch.float32).clone()
+    assert maxabs(first, ref) < 2e-4 * math.sqrt(K) + 1e-3
+    for _ in range(5):
+        assert torch.equal(ops.gemm(a, w, bias, out_dtype=torch.float32), first)
+    assert ops.tuning_pending() == 0 and not ops._TUNED
+    tiles = ops.gemm_mfma(a, w, bias, None, ops.EPI_NONE, torch.float32, None, 0)
+    assert torch.equal(tiles, first)                       # = the static heuristic's kernel
+
+
 @pytest.mark.parametrize("N,K", [(264, 128), (4096, 1024), (1000, 640)])
 def test_pack_weight_layout(N, K):
     """vly_pack_weight_bf16: [N,K] -> [K/64][ceil(N/64)][64][64], rows past N zero."""
