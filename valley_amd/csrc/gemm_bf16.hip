@@ -963,15 +963,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             voW[q] = (w_row_off(min(n0 + row, N - 1), ldw) + (uint32_t)((cp ^ (row & 7)) << 3)) * 2u;
         }
     };
-    if constexpr (!SK) {
-        // XCD phase skew (round 4 experiment, VLY_P4_XCD_SKEW_NS; `epoch` carries it for the whole-tile form): every workgroup
-        // of XCD x starts x * skew later.  The workgroups of ONE XCD stay in lockstep (they share A / W panels in its L2),
-        // but the eight XCDs reach their epilogues — a 4 MB store burst each — at different times, under the others' MFMAs.
-        if (epoch) {
-            const uint64_t t0 = wall_clock64(), wait = (uint64_t)(blockIdx.x & 7) * epoch / 10u;      // 100 MHz ticks
-            while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
-        }
-    }
     int lt = (int)blockIdx.x, lk = 0;                                // tile / K tile the load cursor points at
     [[maybe_unused]] P4Cursor sc;                                    // (SK: the same cursor as a segment walker)
     if constexpr (SK) {
@@ -1485,13 +1476,10 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
         if (pin > 0 && rem > 0 && (pin == 1 || ((pin - 1) * rem8 <= sk->slab_cap && nk / pin >= 2))) sk_S = pin;
     }
     dim3 grid(SK || tiles >= cus ? cus : tiles), block(256);           // SK: every CU takes its share of the units
-    static const unsigned skew_ns = [] { const char* e = getenv("VLY_P4_XCD_SKEW_NS"); return e ? (unsigned)atoi(e) : 0u; }();
-    static const int skew_maxk = [] { const char* e = getenv("VLY_P4_XCD_SKEW_MAXK"); return e ? atoi(e) : 1 << 30; }();
-    const unsigned skew = (!SK && tiles >= 2 * cus && K <= skew_maxk) ? skew_ns : 0u;
 #define VLY_P4_LAUNCH(E, O)                                                                                                  \
     hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O, SK>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, \
                        N, K, lda, ldw, ldc, ldr, tm, tn, gm, rope ? *rope : RopeArgs{}, sk ? sk->slabs : nullptr,                 \
-                       sk ? sk->flags : nullptr, sk ? sk->epoch : skew, sk_S)
+                       sk ? sk->flags : nullptr, sk ? sk->epoch : 0u, sk_S)
     if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_BF16);
     else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_P4_LAUNCH(VLY_EPI_NONE, VLY_OUT_F32);
     else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_P4_LAUNCH(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
