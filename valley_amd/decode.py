@@ -153,7 +153,12 @@ class DecodeSession:
 
     def check(self) -> None:
         """Raise if a workgroup of the persistent launch gave up at a grid barrier in the last step (it needs every CU: a kernel
-        of another stream was holding some).  Costs a device-to-host copy: callers check once per generation, tests per step."""
+        of another stream was holding some), or if the merged attention's ticket counters are not back at zero (a launch that
+        did not complete).  Costs a device-to-host copy: callers check once per generation, tests per step."""
+        if int(self.arrivals.abs().sum().item()) != 0:
+            self.arrivals.zero_()
+            raise RuntimeError("vly_decode_attention_merged: ticket counters not at zero after a step (an attention launch did "
+                               "not complete); the step's output is invalid")
         if self.persistent and int(self.sync[ops.DECODE_SYNC_ABORT].item()) != 0:
             self.sync.zero_()                                    # the barrier counters are inconsistent after an abort
             raise RuntimeError("vly_decode_layers: a grid barrier timed out (not every workgroup was resident); the step's "

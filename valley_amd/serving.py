@@ -91,6 +91,8 @@ def generate_video_stream(model, tokenizer, params: dict, video: Optional[torch.
             yield json.dumps(ret).encode() + b"\0"
         if stopped or cache.seq_len + 1 > cache.ctx_max:
             break
+    if sess is not None:
+        sess.check()                                         # the decode launches' ticket counters / abort word, once per request
 
 
 class ContinuousBatcher:
@@ -168,4 +170,6 @@ class ContinuousBatcher:
         return out
 
     def release(self, slot: int) -> None:
+        if self._captured and self.live[slot]:
+            self.sess.check()                                    # once per leaving request (the step's D2H read has synchronised already)
         self.live[slot] = False

@@ -645,6 +645,8 @@ class ValleyLlamaForCausalLM:
         ops.sk_poll_async(self.device)
         torch.cuda.current_stream().synchronize()            # the caller decodes the tokens next; a stream-K hand-off
         ops.sk_check_polled(self.device)                     # failure anywhere in this generation is reported here at the latest
+        if sess is not None:
+            sess.check()                                     # ticket counters / grid-barrier abort word of the decode launches
         return seq
 
     # -- tokenizer / prompt glue -----------------------------------------------------------------------
