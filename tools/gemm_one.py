@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run ONE GEMM shape a few times (for rocprofv3 --pmc runs): gemm_one.py M N K tile|sk|lib tile [epi] [reps] [packed]
+"""Run ONE GEMM shape a few times (for rocprofv3 --pmc runs): gemm_one.py M N K tile|sk|lib|skinny tile [epi] [reps] [packed]
 (packed = 1: the weight in the block-ordered copy the prefill engines read, ops.PackedWeight)"""
 import os
 import sys
@@ -22,7 +22,9 @@ if packed:
     w = ops.PackedWeight(w)
 fn = ops.gemm_mfma if kind == "tile" else ops.gemm_streamk
 for _ in range(reps):
-    if kind == "lib":          # the vendor library's kernel for the same problem (information only: its counters beside ours)
+    if kind == "skinny":
+        ops.gemm_skinny(a, w, None, epi, out)
+    elif kind == "lib":          # the vendor library's kernel for the same problem (information only: its counters beside ours)
         torch.mm(a, w.t(), out=out)
     else:
         fn(a, w, epilogue=epi, out=out, tile_hint=tile)
