@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from valley_amd.runtime import HALF  # the library's 16-bit storage type: bf16, or fp16 under VALLEY_PRECISION=fp16 (this process is bound by the environment)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -33,8 +35,8 @@ def maxabs(got, ref):
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (1028, 1024, 1024), (64, 512, 64), (513, 4096, 640)])
 def test_gemm_plain(M, N, K, tile):
     from valley_amd import ops
-    a = rnd((M, K), 1, dtype=torch.bfloat16)
-    w = rnd((N, K), 2, 0.05, dtype=torch.bfloat16)
+    a = rnd((M, K), 1, dtype=HALF)
+    w = rnd((N, K), 2, 0.05, dtype=HALF)
     ref = a.float() @ w.float().t()
     out = ops.gemm_mfma(a.to(dev()), w.to(dev()), out_dtype=torch.float32, tile_hint=tile)
     torch.cuda.synchronize()
@@ -48,8 +50,8 @@ def test_gemm_plain(M, N, K, tile):
 def test_gemm_epilogues(tile):
     from valley_amd import ops
     M, N, K = 771, 1024, 256
-    a = rnd((M, K), 3, dtype=torch.bfloat16)
-    w = rnd((N, K), 4, 0.05, dtype=torch.bfloat16)
+    a = rnd((M, K), 3, dtype=HALF)
+    w = rnd((N, K), 4, 0.05, dtype=HALF)
     bias = rnd((N,), 5, 0.5)
     res = rnd((M, N), 6)
     base = a.float() @ w.float().t() + bias
@@ -77,8 +79,8 @@ def test_gemm_ragged_columns_through_lds_epilogue(tile):
     from valley_amd import ops
     M, K = 333, 192
     for N, epi in ((260, ops.EPI_NONE), (520, ops.EPI_SWIGLU), (132, ops.EPI_QUICK_GELU)):
-        a = rnd((M, K), 61, dtype=torch.bfloat16).to(dev())
-        w = rnd((N, K), 62, 0.05, dtype=torch.bfloat16).to(dev())
+        a = rnd((M, K), 61, dtype=HALF).to(dev())
+        w = rnd((N, K), 62, 0.05, dtype=HALF).to(dev())
         base = a.float() @ w.float().t()
         if epi == ops.EPI_SWIGLU:
             ref = torch.nn.functional.silu(base[:, 0::2]) * base[:, 1::2]
@@ -87,12 +89,12 @@ def test_gemm_ragged_columns_through_lds_epilogue(tile):
         else:
             ref = base
         No = ref.shape[1]
-        out = torch.full((M, No + 12), 7.0, dtype=torch.bfloat16, device=dev())         # guard columns
+        out = torch.full((M, No + 12), 7.0, dtype=HALF, device=dev())         # guard columns
         assert (No + 12) % 8 == 0 and No % 8 == 4
         ops.gemm_mfma(a, w, epilogue=epi, out=out[:, :No], tile_hint=tile)              # ldc % 8 == 0: 16-byte aligned rows
         assert relerr(out[:, :No], ref) < 4e-3
         assert float((out[:, No:].float() - 7.0).abs().max()) == 0.0                   # nothing written past N
-        out2 = torch.full((M, No + 2), 7.0, dtype=torch.bfloat16, device=dev())         # ldc % 8 != 0: fragment-store path
+        out2 = torch.full((M, No + 2), 7.0, dtype=HALF, device=dev())         # ldc % 8 != 0: fragment-store path
         ops.gemm_mfma(a, w, epilogue=epi, out=out2[:, :No], tile_hint=tile)
         assert torch.equal(out2[:, :No], out[:, :No])
         assert float((out2[:, No:].float() - 7.0).abs().max()) == 0.0
@@ -103,9 +105,9 @@ def test_gemm_strided_a_and_asymmetric():
     transposed fragments that symmetric data would hide."""
     from valley_amd import ops
     d = dev()
-    big = rnd((200, 512), 7, dtype=torch.bfloat16).to(d)
+    big = rnd((200, 512), 7, dtype=HALF).to(d)
     a = big[:, 128:384]
-    w = torch.zeros((128, 256), dtype=torch.bfloat16)
+    w = torch.zeros((128, 256), dtype=HALF)
     w[3, 17] = 1.0
     w[100, 255] = 2.0
     out = ops.gemm_mfma(a, w.to(d), out_dtype=torch.float32)
@@ -118,8 +120,8 @@ def test_gemv(M):
     from valley_amd import ops
     N, K = 1000, 1024
     d = dev()
-    a = rnd((M, K), 8, dtype=torch.bfloat16)
-    w = rnd((N, K), 9, 0.05, dtype=torch.bfloat16)
+    a = rnd((M, K), 8, dtype=HALF)
+    w = rnd((N, K), 9, 0.05, dtype=HALF)
     bias = rnd((N,), 10, 0.5)
     res = rnd((M, N), 11)
     base = a.float() @ w.float().t()
@@ -138,7 +140,7 @@ def test_gemv_rmsnorm_is_bit_identical_to_the_pair(M, N, K):
     d = dev()
     h = (rnd((M, K), 31, 1.5) + 0.1).to(d)
     g = (rnd((K,), 32, 0.1) + 1.0).to(d)
-    w = rnd((N, K), 33, 0.03, dtype=torch.bfloat16).to(d)
+    w = rnd((N, K), 33, 0.03, dtype=HALF).to(d)
     bias = rnd((N,), 34, 0.5).to(d)
     res = rnd((M, N), 35).to(d)
     x = ops.rmsnorm(h, g, 1e-6)
@@ -148,7 +150,7 @@ def test_gemv_rmsnorm_is_bit_identical_to_the_pair(M, N, K):
         fused = ops.gemv_rmsnorm(h, g, 1e-6, w, **kw)
         assert torch.equal(pair, fused), kw
     hf = h.float().cpu()
-    xr = (g.cpu() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6))).to(torch.bfloat16).float()
+    xr = (g.cpu() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6))).to(HALF).float()
     ref = xr @ w.float().cpu().t()
     assert relerr(ops.gemv_rmsnorm(h, g, 1e-6, w, out_dtype=torch.float32), ref) < 3e-3
     assert not ops.gemv_rmsnorm_ok(3, K) and not ops.gemv_rmsnorm_ok(1, 1024)
@@ -167,7 +169,7 @@ def test_norms(D):
     y16, y32 = ops.layernorm(x.to(d), g.to(d), b.to(d), 1e-5, want_f32=True)
     ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
     assert maxabs(y32, ref) < 2e-5
-    assert maxabs(y16, ref.to(torch.bfloat16)) <= 0.04   # at most one bf16 ulp at |x| < 8
+    assert maxabs(y16, ref.to(HALF)) <= 0.04   # at most one bf16 ulp at |x| < 8
     y = ops.rmsnorm(x.to(d), g.to(d), 1e-6)
     ref = g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
     assert relerr(y, ref) < 3e-3
@@ -177,13 +179,13 @@ def test_patchify_matches_conv():
     from valley_amd import ops
     d = dev()
     F = 3
-    img = rnd((F, 3, 224, 224), 15, dtype=torch.bfloat16)
-    wt = rnd((1024, 3, 14, 14), 16, 0.02, dtype=torch.bfloat16)
+    img = rnd((F, 3, 224, 224), 15, dtype=HALF)
+    wt = rnd((1024, 3, 14, 14), 16, 0.02, dtype=HALF)
     cols = ops.patchify(img.to(d))
     ref_cols = torch.nn.functional.unfold(img.float(), kernel_size=14, stride=14).transpose(1, 2).reshape(F * 256, 588)
     assert maxabs(cols[:, :588], ref_cols) == 0.0
     assert float(cols[:, 588:].float().abs().max()) == 0.0
-    wpad = torch.zeros((1024, 640), dtype=torch.bfloat16)
+    wpad = torch.zeros((1024, 640), dtype=HALF)
     wpad[:, :588] = wt.reshape(1024, 588)
     out = ops.gemm_mfma(cols, wpad.to(d), out_dtype=torch.float32)
     ref = torch.nn.functional.conv2d(img.float(), wt.float(), stride=14).flatten(2).transpose(1, 2).reshape(F * 256, 1024)
@@ -207,7 +209,7 @@ def test_vit_attention():
     from valley_amd import ops
     d = dev()
     F = 3
-    qkv = rnd((F * 257, 3072), 22, 1.0, dtype=torch.bfloat16)
+    qkv = rnd((F * 257, 3072), 22, 1.0, dtype=HALF)
     qkv[5, :64] *= 6.0            # one spiky query row
     out = ops.vit_attention(qkv.to(d), F)
     x = qkv.float().view(F, 257, 3, 16, 64)
@@ -257,7 +259,7 @@ def test_pool_tokens(mode):
     out = ops.pool_tokens(f.to(d).view(-1, W), B, T, mode)
     pooled = f[:, :, 1:].mean(1) if mode == 0 else f[:, :, 1:].max(1)[0]
     ref = torch.cat([pooled, f[:, :, 0]], dim=1)
-    assert maxabs(out, ref.to(torch.bfloat16)) <= 0.02
+    assert maxabs(out, ref.to(HALF)) <= 0.02
     assert relerr(out, ref) < 3e-3
 
 
@@ -265,8 +267,8 @@ def test_embed_splice():
     from valley_amd import ops
     d = dev()
     V, H, NV = 50, 256, 7
-    emb = rnd((V, H), 24, dtype=torch.bfloat16)
-    vis = rnd((NV, H), 25, dtype=torch.bfloat16)
+    emb = rnd((V, H), 24, dtype=HALF)
+    vis = rnd((NV, H), 25, dtype=HALF)
     rmap = torch.tensor([0, 49, -1, -7, 3, -2, 10], dtype=torch.int32)
     out = ops.embed_splice(rmap.to(d), emb.to(d), vis.to(d))
     ref = torch.stack([emb[v].float() if v >= 0 else vis[-v - 1].float() for v in rmap.tolist()])
@@ -300,12 +302,12 @@ def test_rope_kv_and_llama_attention(B, S, past, heads, pad):
     Hq = heads * 128
     ctx_max = 512
     cos, sin = _rope_tables(ctx_max)
-    kc = torch.zeros((B, heads, ctx_max, 128), dtype=torch.bfloat16)
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=HALF)
     vc = torch.zeros_like(kc)
     if past:
-        kc[:, :, :past] = rnd((B, heads, past, 128), 30, dtype=torch.bfloat16)
-        vc[:, :, :past] = rnd((B, heads, past, 128), 31, dtype=torch.bfloat16)
-    qkv = rnd((B * S, 3 * Hq), 32, dtype=torch.bfloat16)
+        kc[:, :, :past] = rnd((B, heads, past, 128), 30, dtype=HALF)
+        vc[:, :, :past] = rnd((B, heads, past, 128), 31, dtype=HALF)
+    qkv = rnd((B * S, 3 * Hq), 32, dtype=HALF)
     kcd, vcd, qd = kc.to(d), vc.to(d), qkv.to(d).clone()
     ops.rope_kv(qd, kcd, vcd, cos.to(d), sin.to(d), B, S, heads, past)
     # reference rope
@@ -318,8 +320,8 @@ def test_rope_kv_and_llama_attention(B, S, past, heads, pad):
         return torch.cat([-t[..., 64:], t[..., :64]], -1)
     qr = x[:, :, 0] * c + rot(x[:, :, 0]) * sn
     kr = x[:, :, 1] * c + rot(x[:, :, 1]) * sn
-    assert maxabs(qd.view(B, S, 3, heads, 128)[:, :, 0], qr.to(torch.bfloat16)) <= 0.04
-    assert maxabs(kcd[:, :, past:past + S], kr.transpose(1, 2).to(torch.bfloat16)) <= 0.04
+    assert maxabs(qd.view(B, S, 3, heads, 128)[:, :, 0], qr.to(HALF)) <= 0.04
+    assert maxabs(kcd[:, :, past:past + S], kr.transpose(1, 2).to(HALF)) <= 0.04
     assert maxabs(vcd[:, :, past:past + S], x[:, :, 2].transpose(1, 2)) == 0.0
     assert float(kcd[:, :, past + S:].float().abs().max()) == 0.0
 
@@ -350,12 +352,12 @@ def test_decode_attention_fused_equals_rope_then_attention(B, past, heads, pad, 
     Hq = heads * 128
     cos, sin = _rope_tables(ctx_max)
     cos, sin = cos.to(d), sin.to(d)
-    kc = torch.zeros((B, heads, ctx_max, 128), dtype=torch.bfloat16)
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=HALF)
     vc = torch.zeros_like(kc)
     if past:
-        kc[:, :, :past] = rnd((B, heads, past, 128), 30, dtype=torch.bfloat16)
-        vc[:, :, :past] = rnd((B, heads, past, 128), 31, dtype=torch.bfloat16)
-    qkv = rnd((B, 3 * Hq), 32, dtype=torch.bfloat16).to(d)
+        kc[:, :, :past] = rnd((B, heads, past, 128), 30, dtype=HALF)
+        vc[:, :, :past] = rnd((B, heads, past, 128), 31, dtype=HALF)
+    qkv = rnd((B, 3 * Hq), 32, dtype=HALF).to(d)
     valid = None
     if pad:
         valid = torch.ones((B, past + 1), dtype=torch.uint8)
@@ -390,14 +392,14 @@ def test_decode_attention_split_and_merge(B, past, pad, ctx_max, per_row):
     cos, sin = _rope_tables(ctx_max)
     cos, sin = cos.to(d), sin.to(d)
     pasts = [past, max(past - 130, 0)][:B] if per_row else [past] * B
-    kc = torch.zeros((B, heads, ctx_max, 128), dtype=torch.bfloat16)
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=HALF)
     vc = torch.zeros_like(kc)
     for b in range(B):
         if pasts[b]:
-            kc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 30 + b, dtype=torch.bfloat16)
-            vc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 40 + b, dtype=torch.bfloat16)
-    qkv = rnd((B, 3 * Hq), 32, dtype=torch.bfloat16).to(d)
-    w = rnd((N, Hq), 33, 0.05, dtype=torch.bfloat16).to(d)
+            kc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 30 + b, dtype=HALF)
+            vc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 40 + b, dtype=HALF)
+    qkv = rnd((B, 3 * Hq), 32, dtype=HALF).to(d)
+    w = rnd((N, Hq), 33, 0.05, dtype=HALF).to(d)
     res = rnd((B, N), 34).to(d)
     valid = None
     if pad or per_row:
@@ -418,7 +420,7 @@ def test_decode_attention_split_and_merge(B, past, pad, ctx_max, per_row):
     assert torch.equal(k1, k2) and torch.equal(v1, v2)
     assert relerr(got - res, want - res) < 4e-3 and maxabs(got, want) < 2e-2, (relerr(got - res, want - res), maxabs(got, want))
     # the merged attention output itself, through an identity-like projection: rows of W = unit vectors
-    eye = torch.zeros((256, Hq), dtype=torch.bfloat16)
+    eye = torch.zeros((256, Hq), dtype=HALF)
     eye[torch.arange(256), torch.arange(256) * 8] = 1.0
     m_att = ops.gemv_attnmerge(parts, eye.to(d), out_dtype=torch.float32)
     assert maxabs(m_att, att[:, ::8][:, :256].float()) <= 2e-2
@@ -436,10 +438,10 @@ def test_gemm_splitk2_and_add2_rmsnorm(M, N, K, tile):
     """vly_gemm_bf16_splitk2: the two bf16 partials are the two K halves (each checked on its own), and
     vly_add2_rmsnorm consumes them like vly_add_rmsnorm consumes their sum."""
     from valley_amd import ops
-    a = rnd((M, K), 71, dtype=torch.bfloat16).to(dev())
-    w = rnd((N, K), 72, 0.05, dtype=torch.bfloat16).to(dev())
+    a = rnd((M, K), 71, dtype=HALF).to(dev())
+    w = rnd((N, K), 72, 0.05, dtype=HALF).to(dev())
     bias = rnd((N,), 73, 0.3).to(dev())
-    o0 = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+    o0 = torch.empty((M, N), dtype=HALF, device=dev())
     o1 = torch.empty_like(o0)
     ops.gemm_mfma_splitk2(a, w, bias, o0, o1, tile)
     h0 = (K // 64) // 2 * 64
@@ -513,7 +515,7 @@ def test_add_norm(D, rms):
     d = dev()
     M = 333
     h = rnd((M, D), 60, 2.0)
-    delta = rnd((M, D), 61, 0.5, dtype=torch.bfloat16)
+    delta = rnd((M, D), 61, 0.5, dtype=HALF)
     g = rnd((D,), 62, 0.1) + 1.0
     b = rnd((D,), 63, 0.1)
     hd = h.to(d).clone()
@@ -543,7 +545,7 @@ def test_preprocess_frames_gpu_vs_oracle(shape):
     got = preprocess_frames_gpu(torch.from_numpy(frames).to(dev()), out_dtype=torch.float32)
     assert maxabs(got, ref) < 2e-6
     got16 = preprocess_frames_gpu(torch.from_numpy(frames).to(dev()))
-    assert maxabs(got16, ref.to(torch.bfloat16)) <= 0.016
+    assert maxabs(got16, ref.to(HALF)) <= 0.016
 
 
 def test_gemm_online_tuner_decides_and_stays_correct(monkeypatch, tmp_path):
@@ -556,8 +558,8 @@ def test_gemm_online_tuner_decides_and_stays_correct(monkeypatch, tmp_path):
     monkeypatch.setattr(ops, "_TUNED", {})
     monkeypatch.setattr(ops, "_ONLINE", {})
     M, N, K = 1312, 1024, 512
-    a = rnd((M, K), 11, dtype=torch.bfloat16).to(dev())
-    w = rnd((N, K), 12, 0.05, dtype=torch.bfloat16).to(dev())
+    a = rnd((M, K), 11, dtype=HALF).to(dev())
+    w = rnd((N, K), 12, 0.05, dtype=HALF).to(dev())
     bias = rnd((N,), 13, 0.5).to(dev())
     ref = a.float() @ w.float().t() + bias
     calls = 0
@@ -589,8 +591,8 @@ def test_gemm_without_online_trials_is_one_kernel_from_the_first_call(monkeypatc
     monkeypatch.setattr(ops, "_TUNED", {})
     monkeypatch.setattr(ops, "_ONLINE", {})
     M, N, K = 1312, 1024, 512
-    a = rnd((M, K), 11, dtype=torch.bfloat16).to(dev())
-    w = rnd((N, K), 12, 0.05, dtype=torch.bfloat16).to(dev())
+    a = rnd((M, K), 11, dtype=HALF).to(dev())
+    w = rnd((N, K), 12, 0.05, dtype=HALF).to(dev())
     bias = rnd((N,), 13, 0.5).to(dev())
     ref = a.float() @ w.float().t() + bias
     first = ops.gemm(a, w, bias, out_dtype=torch.float32).clone()
@@ -606,10 +608,10 @@ def test_gemm_without_online_trials_is_one_kernel_from_the_first_call(monkeypatc
 def test_pack_weight_layout(N, K):
     """vly_pack_weight_bf16: [N,K] -> [K/64][ceil(N/64)][64][64], rows past N zero."""
     from valley_amd import ops
-    w = rnd((N, K), 81, dtype=torch.bfloat16).to(dev())
+    w = rnd((N, K), 81, dtype=HALF).to(dev())
     pw = ops.PackedWeight(w)
     nb = (N + 63) // 64
-    ref = torch.zeros((nb * 64, K), dtype=torch.bfloat16, device=dev())
+    ref = torch.zeros((nb * 64, K), dtype=HALF, device=dev())
     ref[:N] = w
     ref = ref.view(nb, 64, K // 64, 64).permute(2, 0, 1, 3).contiguous()
     assert tuple(pw.blocks.shape) == (K // 64, nb, 64, 64) and torch.equal(pw.blocks, ref)
@@ -622,8 +624,8 @@ def test_gemm_packed_weights_bit_identical(tile):
     bits as with the row-major weights (ragged N included), through every epilogue; so does the split-K pair."""
     from valley_amd import ops
     M, N, K = 771, 1000, 256
-    a = rnd((M, K), 82, dtype=torch.bfloat16).to(dev())
-    w = rnd((N, K), 83, 0.05, dtype=torch.bfloat16).to(dev())
+    a = rnd((M, K), 82, dtype=HALF).to(dev())
+    w = rnd((N, K), 83, 0.05, dtype=HALF).to(dev())
     bias = rnd((N,), 84, 0.5).to(dev())
     res = rnd((M, N), 85).to(dev())
     pw = ops.PackedWeight(w)
@@ -631,7 +633,7 @@ def test_gemm_packed_weights_bit_identical(tile):
                dict(epilogue=ops.EPI_SWIGLU)):
         assert torch.equal(ops.gemm_mfma(a, pw, tile_hint=tile, **kw), ops.gemm_mfma(a, w, tile_hint=tile, **kw)), kw
     if tile in (0, 2, 6, 7, 8, 76, 84, 86):
-        o = [torch.empty((M, N), dtype=torch.bfloat16, device=dev()) for _ in range(4)]
+        o = [torch.empty((M, N), dtype=HALF, device=dev()) for _ in range(4)]
         ops.gemm_mfma_splitk2(a, pw, bias, o[0], o[1], tile)
         ops.gemm_mfma_splitk2(a, w, bias, o[2], o[3], tile)
         assert torch.equal(o[0], o[2]) and torch.equal(o[1], o[3])
@@ -660,8 +662,8 @@ def test_gemm_p4_streamk(M, N, K, epi, tile):
     is; fp32 outputs with bias + residual, the packed weight copy (bit-identical), and no hand-off failure."""
     from valley_amd import ops
     d = dev()
-    a = rnd((M, K), 91, dtype=torch.bfloat16).to(d)
-    w = rnd((N, K), 92, 0.03, dtype=torch.bfloat16).to(d)
+    a = rnd((M, K), 91, dtype=HALF).to(d)
+    w = rnd((N, K), 92, 0.03, dtype=HALF).to(d)
     bias = rnd((N,), 93, 0.5).to(d) if epi != ops.EPI_SWIGLU else None
     want = ops.gemm_mfma(a, w, bias, epilogue=epi, tile_hint=tile - 100)
     got = ops.gemm_streamk(a, w, bias, epilogue=epi, tile_hint=tile)
@@ -683,8 +685,8 @@ def test_gemm_p4_streamk(M, N, K, epi, tile):
 def test_gemm_packed_rejects_half_tile_loops():
     from valley_amd import ops
     from valley_amd.lib import ValleyHipError
-    a = rnd((256, 128), 86, dtype=torch.bfloat16).to(dev())
-    pw = ops.PackedWeight(rnd((256, 128), 87, dtype=torch.bfloat16).to(dev()))
+    a = rnd((256, 128), 86, dtype=HALF).to(dev())
+    pw = ops.PackedWeight(rnd((256, 128), 87, dtype=HALF).to(dev()))
     for t in (11, 33):
         with pytest.raises(ValleyHipError):
             ops.gemm_mfma(a, pw, tile_hint=t)
@@ -707,7 +709,7 @@ def test_g6_rmsnorm_eps_and_layernorm_vs_hf():
     for eps in (1e-5, 1e-6):
         ref = torch.from_numpy(g[f"rmsnorm_eps{eps:g}"])
         y = ops.rmsnorm(x, wn, eps)
-        assert maxabs(y, ref.to(torch.bfloat16)) <= float(ref.abs().max()) / 128 + 1e-6               # one bf16 ulp at the largest value
+        assert maxabs(y, ref.to(HALF)) <= float(ref.abs().max()) / 128 + 1e-6               # one bf16 ulp at the largest value
         assert relerr(y, ref) < 3e-3
     # the two eps settings differ by less than a bf16 ulp here, so also check the statistic itself on a tiny-norm row
     tiny = (x[:1] * 1e-3).contiguous()
@@ -732,21 +734,21 @@ def test_g6_rope_positions_vs_hf():
     q = torch.from_numpy(op_input("rope.q", (1, heads, 4, 128)))
     k = torch.from_numpy(op_input("rope.k", (1, heads, 4, 128)))
     for i, pos in enumerate(OPS["rope_positions"]):
-        qkv = torch.zeros((1, 3 * heads * 128), dtype=torch.bfloat16)
-        qkv[0, :heads * 128] = q[0, :, i].reshape(-1).to(torch.bfloat16)
-        qkv[0, heads * 128:2 * heads * 128] = k[0, :, i].reshape(-1).to(torch.bfloat16)
+        qkv = torch.zeros((1, 3 * heads * 128), dtype=HALF)
+        qkv[0, :heads * 128] = q[0, :, i].reshape(-1).to(HALF)
+        qkv[0, heads * 128:2 * heads * 128] = k[0, :, i].reshape(-1).to(HALF)
         qd = qkv.to(d)
-        kc = torch.zeros((1, heads, 2048, 128), dtype=torch.bfloat16, device=d)
+        kc = torch.zeros((1, heads, 2048, 128), dtype=HALF, device=d)
         vc = torch.zeros_like(kc)
         ops.rope_kv(qd, kc, vc, cos.to(d), sin.to(d), 1, 1, heads, pos)
         # HF rotated the fp32 q; the kernel rotates the bf16-rounded q: compare against the rotation of the rounded input
-        qb, kb = q[0, :, i].to(torch.bfloat16).float(), k[0, :, i].to(torch.bfloat16).float()
+        qb, kb = q[0, :, i].to(HALF).float(), k[0, :, i].to(HALF).float()
         c = torch.from_numpy(g["rope_cos"])[0, i]
         s = torch.from_numpy(g["rope_sin"])[0, i]
         rot = lambda t: torch.cat([-t[..., 64:], t[..., :64]], -1)  # noqa: E731
         want_q, want_k = qb * c + rot(qb) * s, kb * c + rot(kb) * s
-        assert maxabs(qd.view(3, heads, 128)[0], want_q.to(torch.bfloat16)) <= 0.032, pos
-        assert maxabs(kc[0, :, pos], want_k.to(torch.bfloat16)) <= 0.032, pos
+        assert maxabs(qd.view(3, heads, 128)[0], want_q.to(HALF)) <= 0.032, pos
+        assert maxabs(kc[0, :, pos], want_k.to(HALF)) <= 0.032, pos
         # and the HF fixture itself (fp32 input) within the input rounding
         assert maxabs(qd.view(3, heads, 128)[0], torch.from_numpy(g["rope_q"])[0, :, i]) < 0.04, pos
 
@@ -760,7 +762,7 @@ def test_g6_llama_attention_block_and_mlp_vs_hf():
     from valley_amd.llama import HipLlama
     g, d, o = _g6(), dev(), OPS
     H, heads, B, S = o["H"], o["heads"], 2, o["S"]
-    bf = torch.bfloat16
+    bf = HALF
     W = {n: torch.from_numpy(op_weights(f"att.{n}", (H, H), 0.05)).to(d, bf) for n in ("q_proj", "k_proj", "v_proj", "o_proj")}
     x = torch.from_numpy(op_input("att.h", (B, S, H))).view(B * S, H).to(d, bf)
     qkv = ops.gemm_mfma(x, torch.cat([W["q_proj"], W["k_proj"], W["v_proj"]], 0).contiguous())
@@ -795,7 +797,7 @@ def test_g6_clip_mlp_and_attention_vs_hf():
     from tests.golden_r2_cfg import OPS, op_input, op_weights
     from valley_amd import ops
     g, d, o = _g6(), dev(), OPS
-    bf = torch.bfloat16
+    bf = HALF
     tw = lambda n, shp, std=0.03: torch.from_numpy(op_weights(n, shp, std)).to(d)  # noqa: E731
     x = torch.cat([torch.from_numpy(op_input("cmlp.x", (9, 1024))), torch.zeros(7, 1024)], 0).to(d, bf)
     mid = ops.gemm_mfma(x, tw("cmlp.fc1.w", (o["VI"], 1024)).to(bf), tw("cmlp.fc1.b", (o["VI"],), 0.1), epilogue=ops.EPI_QUICK_GELU)
@@ -821,24 +823,24 @@ def test_gemm_skinny(M, N, K, epi):
     wider buffer, as the remainder rows are); the transpose detector."""
     from valley_amd import ops
     d = dev()
-    big = rnd((M + 3, K + 64), 91, dtype=torch.bfloat16).to(d)
+    big = rnd((M + 3, K + 64), 91, dtype=HALF).to(d)
     a = big[3:, 64:]                                                     # row stride K + 64, 16-byte aligned start
-    w = rnd((N, K), 92, 0.05, dtype=torch.bfloat16).to(d)
+    w = rnd((N, K), 92, 0.05, dtype=HALF).to(d)
     bias = rnd((N,), 93, 0.5).to(d)
     base = a.float() @ w.float().t() + bias
     ref = base * torch.sigmoid(1.702 * base) if epi == 1 else base.clamp_min(0) if epi == 3 else base
-    out = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device=d)
+    out = torch.full((M + 2, N), 7.0, dtype=HALF, device=d)
     ops.gemm_skinny(a, w, bias, epilogue=epi, out=out[:M])
     assert relerr(out[:M], ref) < 4e-3
     assert float((out[M:].float() - 7.0).abs().max()) == 0.0              # nothing written past M
     assert relerr(out[:M], ops.gemm_mfma(a, w, bias, epilogue=epi)) < 3e-3   # same math as the tile kernel (summation order only)
-    w1 = torch.zeros((N, K), dtype=torch.bfloat16, device=d)
+    w1 = torch.zeros((N, K), dtype=HALF, device=d)
     w1[5, K - 3] = 1.0
     o1 = ops.gemm_skinny(a, w1)
     assert maxabs(o1[:, 5], a[:, K - 3]) == 0.0 and float(o1[:, :5].float().abs().max()) == 0.0
     from valley_amd.lib import ValleyHipError
     with pytest.raises(ValleyHipError):
-        ops.gemm_skinny(rnd((300, K), 1, dtype=torch.bfloat16).to(d), w)     # M > 256 is not this kernel's job
+        ops.gemm_skinny(rnd((300, K), 1, dtype=HALF).to(d), w)     # M > 256 is not this kernel's job
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 8, 9, 51, 53, 54, 55, 73, 74, 83, 84, 93, 94, 97, 98, 99, 197, 198, 199])
@@ -850,16 +852,16 @@ def test_gemm_qkv_rope_fused_bit_identical(tile, B, S, heads, past):
     from valley_amd import ops
     d = dev()
     H, K, ctx = heads * 128, 256, 512
-    a = rnd((B * S, K), 101, dtype=torch.bfloat16).to(d)
-    w = rnd((3 * H, K), 102, 0.05, dtype=torch.bfloat16).to(d)
+    a = rnd((B * S, K), 101, dtype=HALF).to(d)
+    w = rnd((3 * H, K), 102, 0.05, dtype=HALF).to(d)
     cos, sin = _rope_tables(ctx)
     cos, sin = cos.to(d), sin.to(d)
-    seedk = rnd((B, heads, ctx, 128), 103, dtype=torch.bfloat16).to(d)
+    seedk = rnd((B, heads, ctx, 128), 103, dtype=HALF).to(d)
     k0, v0 = seedk.clone(), (seedk * 0.5).clone()
     ref = ops.gemm_mfma(a, w, tile_hint=tile)
     ops.rope_kv(ref, k0, v0, cos, sin, B, S, heads, past)
     for wt in (w, ops.PackedWeight(w)):
-        qkv = torch.full((B * S, 3 * H), 7.0, dtype=torch.bfloat16, device=d)
+        qkv = torch.full((B * S, 3 * H), 7.0, dtype=HALF, device=d)
         k1, v1 = seedk.clone(), (seedk * 0.5).clone()
         ops.gemm_mfma_qkv_rope(a, wt, qkv, ops.RopeKV(k1, v1, cos, sin, B, S, heads, past), tile)
         assert torch.equal(qkv[:, :H], ref[:, :H])
@@ -872,12 +874,12 @@ def test_gemm_qkv_rope_rejects_narrow_tiles_and_falls_back():
     from valley_amd.lib import ValleyHipError
     d = dev()
     B, S, heads, K = 1, 64, 2, 128
-    a = rnd((B * S, K), 104, dtype=torch.bfloat16).to(d)
-    w = rnd((3 * heads * 128, K), 105, 0.05, dtype=torch.bfloat16).to(d)
+    a = rnd((B * S, K), 104, dtype=HALF).to(d)
+    w = rnd((3 * heads * 128, K), 105, 0.05, dtype=HALF).to(d)
     cos, sin = (t.to(d) for t in _rope_tables(128))
-    kc = torch.zeros((B, heads, 128, 128), dtype=torch.bfloat16, device=d)
+    kc = torch.zeros((B, heads, 128, 128), dtype=HALF, device=d)
     rope = ops.RopeKV(kc, torch.zeros_like(kc), cos, sin, B, S, heads, 0)
-    qkv = torch.empty((B * S, 3 * heads * 128), dtype=torch.bfloat16, device=d)
+    qkv = torch.empty((B * S, 3 * heads * 128), dtype=HALF, device=d)
     for t in (6, 7, 76, 86):                               # 192-column tiles cannot hold a head's two halves
         with pytest.raises(ValleyHipError):
             ops.gemm_mfma_qkv_rope(a, w, qkv, rope, t)
@@ -896,8 +898,8 @@ def test_gemm_persistent_many_tiles_bit_identical_to_tile9(tile):
     from valley_amd import ops
     d = dev()
     M, N, K = 4100, 4360, 320                                   # 17 x 18 tiles of 256 x 256 = 306 > 256 workgroups
-    a = rnd((M, K), 201, dtype=torch.bfloat16).to(d)
-    w = rnd((N, K), 202, 0.05, dtype=torch.bfloat16).to(d)
+    a = rnd((M, K), 201, dtype=HALF).to(d)
+    w = rnd((N, K), 202, 0.05, dtype=HALF).to(d)
     bias = rnd((N,), 203, 0.5).to(d)
     res = rnd((M, N), 204).to(d)
     for wt in (w, ops.PackedWeight(w)):
@@ -907,6 +909,6 @@ def test_gemm_persistent_many_tiles_bit_identical_to_tile9(tile):
             ref = ops.gemm_mfma(a, wt, tile_hint=9, **kw)
             assert torch.equal(got, ref), (tile, sorted(kw))
     # an output view whose rows are not 16-byte aligned falls back to the one-tile-per-workgroup kernel: same values
-    out = torch.full((M, N + 2), 7.0, dtype=torch.bfloat16, device=d)
+    out = torch.full((M, N + 2), 7.0, dtype=HALF, device=d)
     ops.gemm_mfma(a, w, bias, out=out[:, :N], tile_hint=tile)
     assert torch.equal(out[:, :N], ops.gemm_mfma(a, w, bias, tile_hint=9)) and float((out[:, N:].float() - 7.0).abs().max()) == 0.0

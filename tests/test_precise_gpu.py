@@ -252,6 +252,9 @@ def test_bf16_path_vs_same_dtype_oracle(method):
     """The production bf16 path vs oracle.rounding() (bf16 rounding at the pipeline's storage points): what remains is fp32
     summation order and the online-softmax form.  Also prints the distance of both to the fp32 reference fixture."""
     from oracle import valley_oracle as O
+    from valley_amd import runtime
+    if runtime.HALF != torch.bfloat16:
+        pytest.skip("oracle.rounding() emulates bf16 storage; this process is bound to the fp16 library")
     g = np.load(os.path.join(GOLD, f"g2_forward_{method}.npz"))
     model = build_model(method, precision="bf16")
     c, T = G.GCFG, G.GCFG["T"]

@@ -21,6 +21,8 @@ import numpy as np
 import pytest
 import torch
 
+from valley_amd.runtime import HALF  # the library's 16-bit storage type: bf16, or fp16 under VALLEY_PRECISION=fp16 (this process is bound by the environment)
+
 pytestmark = pytest.mark.gpu
 
 SHAPES = {"7b": dict(H=4096, heads=32, I=11008, eps=1e-5, S=328), "13b": dict(H=5120, heads=40, I=13824, eps=1e-6, S=336)}
@@ -93,7 +95,7 @@ def test_llama_layers_vs_oracle(name, mode, monkeypatch):
             ref_l = torch.nn.functional.linear(ref_h, lm)
             with O.rounding():
                 same_h, _ = O.llama_forward(torch.from_numpy(emb), sd, cfg, torch.from_numpy(mask))
-                same_l = torch.nn.functional.linear(same_h, lm.to(torch.bfloat16).float())
+                same_l = torch.nn.functional.linear(same_h, lm.to(HALF).float())
         _ORACLE[name] = (ref_h, ref_l, past, rel(same_h.numpy()[v], ref_h.numpy()[v]), rel(same_l.numpy()[v], ref_l.numpy()[v]))
     ref_h, ref_l, past, sh, sl = _ORACLE[name]
     rh, rl, ml = rel(got_h[v], ref_h.numpy()[v]), rel(got_l[v], ref_l.numpy()[v]), maxabs(got_l[v], ref_l.numpy()[v])
@@ -113,7 +115,7 @@ def test_llama_layers_vs_oracle(name, mode, monkeypatch):
     with torch.no_grad():
         e1 = torch.from_numpy(sd["model.embed_tokens.weight"])[tok][:, None]
         # the device embedding table is bf16: feed the oracle the same rounded rows (the table is a weight, not arithmetic)
-        e1 = e1.to(torch.bfloat16).float()
+        e1 = e1.to(HALF).float()
         m1 = torch.cat([torch.from_numpy(mask), torch.ones((B, 1), dtype=torch.long)], 1)
         h1, _ = O.llama_forward(e1, sd, cfg, m1, past=past)
         ref_d = torch.nn.functional.linear(h1, torch.from_numpy(sd["lm_head.weight"]))[:, 0].numpy()
@@ -174,8 +176,8 @@ def test_gemm_hot_shapes_vs_fp32(M, N, K, epi, has_bias, label, monkeypatch):
     from valley_amd import ops
     d = torch.device("cuda:0")
     g = torch.Generator(device=d).manual_seed(M + N + K)
-    a = torch.randn((M, K), generator=g, device=d).to(torch.bfloat16)
-    w = (torch.randn((N, K), generator=g, device=d) * 0.05).to(torch.bfloat16)
+    a = torch.randn((M, K), generator=g, device=d).to(HALF)
+    w = (torch.randn((N, K), generator=g, device=d) * 0.05).to(HALF)
     # transpose detector: one hot row / column pair (symmetric random data would hide a swapped fragment)
     a[M - 3, :] = 0
     a[M - 3, K - 5] = 2.0
@@ -202,7 +204,7 @@ def test_gemm_hot_shapes_vs_fp32(M, N, K, epi, has_bias, label, monkeypatch):
         if ops.tuning_pending() == 0:
             break
     if epi == 0 and N in (1024, 4096, 5120):                      # the projections that feed a residual add
-        o0 = torch.empty((M, N), dtype=torch.bfloat16, device=d)
+        o0 = torch.empty((M, N), dtype=HALF, device=d)
         o1 = torch.empty_like(o0)
         for _ in range(300):
             n = ops.gemm2(a, wp, o0, o1, bias)
@@ -322,13 +324,13 @@ def test_c4_replicated_prefill_64_sequences_vs_oracle(monkeypatch):
     assert ops.sk_error_flag("cuda:0") == 0
     # the attention call of that step on the > 4 GB cache: LDS-DMA kernel (default) == register-staged kernel (bit-identical)
     import os, subprocess, sys
-    qkv = (torch.randn((B * S, 3 * H), device="cuda") * 0.5).to(torch.bfloat16)
+    qkv = (torch.randn((B * S, 3 * H), device="cuda") * 0.5).to(HALF)
     a2 = ops.llama_attention(qkv, cache.k[1], cache.v[1], cache.key_valid, B, S, ll.heads, 0)
     torch.cuda.synchronize()
-    code = ("import torch,sys; sys.path.insert(0, %r); from valley_amd import ops; "
+    code = ("import torch,sys; sys.path.insert(0, %r); from valley_amd import ops; from valley_amd.runtime import HALF; "
             "B,S,H,CTX=64,352,5120,6656; torch.manual_seed(3); "
-            "k=(torch.randn((B,40,CTX,128),device='cuda')*0.5).to(torch.bfloat16); v=(torch.randn((B,40,CTX,128),device='cuda')*0.5).to(torch.bfloat16); "
-            "q=(torch.randn((B*S,3*H),device='cuda')*0.5).to(torch.bfloat16); kv=torch.ones((B,CTX),dtype=torch.uint8,device='cuda'); kv[5,:17]=0; "
+            "k=(torch.randn((B,40,CTX,128),device='cuda')*0.5).to(HALF); v=(torch.randn((B,40,CTX,128),device='cuda')*0.5).to(HALF); "
+            "q=(torch.randn((B*S,3*H),device='cuda')*0.5).to(HALF); kv=torch.ones((B,CTX),dtype=torch.uint8,device='cuda'); kv[5,:17]=0; "
             "o=ops.llama_attention(q,k,v,kv,B,S,40,0); torch.cuda.synchronize(); print('SUM', float(o.float().abs().sum()), float(o.float()[-1].sum()))"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = []
@@ -437,7 +439,7 @@ def test_vit_two_stream_remainder_schedule_is_bit_identical(monkeypatch):
     tower = vm.build_vision_tower(None)
     tower.init_random(seed=3, layers=4)
     g = torch.Generator(device="cuda").manual_seed(8)
-    frames = torch.randn((32, 3, 224, 224), generator=g, device="cuda").to(torch.bfloat16)
+    frames = torch.randn((32, 3, 224, 224), generator=g, device="cuda").to(HALF)
     assert ops.row_split(32 * 257) == 8192
     before = set(ops._ONLINE)                                  # shapes other tests of this process left undecided do not recur here
     for it in range(400):                                      # let the online tuner settle on this tower's shapes

@@ -7,6 +7,8 @@ import math
 import pytest
 import torch
 
+from valley_amd.runtime import HALF  # the library's 16-bit storage type: bf16, or fp16 under VALLEY_PRECISION=fp16 (this process is bound by the environment)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -24,8 +26,8 @@ SHAPES = [(1312, 4096, 4096), (1312, 12288, 4096), (8224, 1024, 1024), (8224, 30
 def test_streamk_matches_tile_kernel(M, N, K, tile):
     from valley_amd import ops
     d = torch.device("cuda:0")
-    a = rnd((M, K), 1, dtype=torch.bfloat16).to(d)
-    w = rnd((N, K), 2, 0.05, dtype=torch.bfloat16).to(d)
+    a = rnd((M, K), 1, dtype=HALF).to(d)
+    w = rnd((N, K), 2, 0.05, dtype=HALF).to(d)
     ref = ops.gemm_mfma(a, w, out_dtype=torch.float32)
     for rep in range(3):                                   # workspace reuse across epochs
         out = ops.gemm_streamk(a, w, out_dtype=torch.float32, tile_hint=tile)
@@ -39,8 +41,8 @@ def test_streamk_epilogues(tile):
     from valley_amd import ops
     d = torch.device("cuda:0")
     M, N, K = 1312, 2048, 1024
-    a = rnd((M, K), 3, dtype=torch.bfloat16).to(d)
-    w = rnd((N, K), 4, 0.05, dtype=torch.bfloat16).to(d)
+    a = rnd((M, K), 3, dtype=HALF).to(d)
+    w = rnd((N, K), 4, 0.05, dtype=HALF).to(d)
     bias = rnd((N,), 5, 0.5).to(d)
     res = rnd((M, N), 6).to(d)
     h = res.clone()
@@ -62,8 +64,8 @@ def test_streamk_stress_many_launches():
     d = torch.device("cuda:0")
     mats = {}
     for (M, N, K) in SHAPES[:5]:
-        a = rnd((M, K), M, dtype=torch.bfloat16).to(d)
-        w = rnd((N, K), N, 0.05, dtype=torch.bfloat16).to(d)
+        a = rnd((M, K), M, dtype=HALF).to(d)
+        w = rnd((N, K), N, 0.05, dtype=HALF).to(d)
         mats[(M, N, K)] = (a, w, ops.gemm_mfma(a, w, out_dtype=torch.float32))
     for rep in range(20):
         for (M, N, K), (a, w, ref) in mats.items():

@@ -9,15 +9,15 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from valley_amd import ops  # noqa: E402
+from valley_amd import ops, runtime  # noqa: E402
 
 
 def main():
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     d = torch.device("cuda:0")
     g = torch.Generator(device=d).manual_seed(5)
-    qkvs = [(torch.randn((F * 257, 3072), generator=g, device=d) * 1.5).to(torch.bfloat16) for _ in range(3)]
-    out = torch.empty((F * 257, 1024), dtype=torch.bfloat16, device=d)
+    qkvs = [(torch.randn((F * 257, 3072), generator=g, device=d) * 1.5).to(runtime.HALF) for _ in range(3)]
+    out = torch.empty((F * 257, 1024), dtype=runtime.HALF, device=d)
     ops.vit_attention(qkvs[0], F, out=out)
     torch.cuda.synchronize()
     # fp32 reference over every frame (in slabs of 8: the fp32 scores of 128 frames would be 0.5 GB)
