@@ -76,7 +76,7 @@ print("bound", runtime.half_bound(), runtime.HALF)
 try:
     runtime.request_half(torch.float16, ".half()")
 except ValueError as e:
-    print("raised", "a loaded library" in str(e))
+    print("raised", "lib.load(libvalley_hip.so)" in str(e))     # the loader names itself as what bound the type
 runtime.request_half(torch.bfloat16, "same")                    # the bound type: no-op
 runtime.request_half(torch.float32, "not a 16-bit request")     # ignored here
 print("done")
@@ -114,3 +114,36 @@ runtime.request_half(torch.bfloat16, "someone")
 print("bound", cli.entry_dtype())
 """)
     assert "open torch.float16" in out and "bound torch.bfloat16" in out
+
+
+def test_cli_entry_dtype_keeps_the_fp32_validation_mode():
+    """with VALLEY_PRECISION=fp32 the entry points must hand from_pretrained torch.float32 — a 16-bit dtype would let
+    apply_torch_dtype overwrite config.valley_precision with "bf16" and silently build the bf16 engines."""
+    out = _child("""
+import torch
+from valley_amd import cli, runtime, valley_model as vm
+print("entry", cli.entry_dtype())
+cfg = vm.ValleyConfig(vocab_size=8, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=1)
+vm.apply_torch_dtype(cfg, cli.entry_dtype(), "test")
+print("precision", cfg.valley_precision, runtime.PRECISION)
+""", env={"VALLEY_PRECISION": "fp32"})
+    assert "entry torch.float32" in out and "precision fp32 fp32" in out
+
+
+def test_engine_constructors_bind_the_storage_type():
+    """whatever allocates the first 16-bit tensor fixes the storage type — a later request for the other one raises
+    instead of leaving mixed-dtype engines behind."""
+    out = _child("""
+import torch
+from valley_amd import runtime
+from valley_amd.vision_tower import HipCLIPVisionTower
+print("open", runtime.half_bound())
+HipCLIPVisionTower(device="cpu")
+print("bound", runtime.half_bound())
+try:
+    runtime.request_half(torch.float16, "late caller")
+    print("no error")
+except ValueError as e:
+    print("raised", "HipCLIPVisionTower" in str(e))
+""")
+    assert "open False" in out and "bound True" in out and "raised True" in out

@@ -1,0 +1,17 @@
+"""Round 5 host-side checks (no GPU).
+
+The persistent GEMM's rolled instantiations own the accumulation registers BY NAME (valley_amd/csrc/gemm_bf16.hip, "accumulators by
+name"): the compiler must never touch a0..a255 in them.  tools/agpr_audit.py reads the ISA hipcc emits and fails on any accumulation
+register named outside an inline-asm block, on scratch and on spills; this test runs it on the fast build (the persistent tiles only)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_named_accumulators_are_never_touched_by_the_compiler():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "agpr_audit.py"), "-DVLY_FEW_TILES"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "12 kernels with accumulators by name audited, 0 findings" in r.stdout, r.stdout[-2000:]

@@ -86,6 +86,8 @@ def run(names, shapes, reps=40):
             if os.environ.get("AB_NOCHECK") == "1":                        # timing experiments with deliberately broken variants
                 continue
             assert err < 2e-3, (names[arms[ai][0]], arms[ai][1], sh, err)
+            if os.environ.get("AB_BITEXACT") == "1":                       # same summation order: the same bits
+                assert torch.equal(outs[ai], outs[0]), (names[arms[ai][0]], arms[ai][1], sh, "not bit-identical")
         ncall = 0
         for r in range(reps + 3):
             order = list(range(len(arms)))

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Per-kernel VGPR / scratch / LDS report for one HIP source: kernel_resources.py valley_amd/csrc/x.hip [filter]"""
+"""Per-kernel VGPR / scratch / LDS report for one HIP source: kernel_resources.py valley_amd/csrc/x.hip [filter [-Dflags ...]]"""
 import re
 import subprocess
 import sys
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
+extra = sys.argv[3:]                                        # further compiler flags (-DVLY_...)
 out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", "/dev/null",
-                      "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+                      "-Rpass-analysis=kernel-resource-usage", *extra], capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
@@ -27,5 +28,5 @@ for line in out.splitlines():
         rows[cur][k.strip()] = v.strip()
 for k, v in sorted(rows.items()):
     if flt in k:
-        print(f"{k:60s} vgpr={v.get('VGPRs'):>4} agpr={v.get('AGPRs'):>4} scratch={v.get('ScratchSize [bytes/lane]'):>4} "
+        print(f"{k:60s} vgpr={v.get('VGPRs'):>4} agpr={v.get('AGPRs'):>4} scratch={v.get('ScratchSize [bytes/lane]'):>4} spill={v.get('VGPRs Spill'):>3} "
               f"lds={v.get('LDS Size [bytes/block]'):>7} occ={v.get('Occupancy [waves/SIMD]')}")

@@ -43,7 +43,10 @@ GREEDY = {"do_sample": False, "temperature": 0.2, "max_new_tokens": 1024}
 def entry_dtype():
     """The dtype the reference's entry points pass to ``from_pretrained`` is ``torch.float16`` (run_valley.py:39,
     run_valley_llamma_v2.py / run_valley_conv.py alike): the same here — it selects libvalley_hip_f16.so — unless
-    VALLEY_PRECISION or an earlier model already bound this process to a storage type, which then wins."""
+    VALLEY_PRECISION or an earlier model already bound this process to a storage type, which then wins
+    (VALLEY_PRECISION=fp32 gives torch.float32: the fp32 validation mode survives the entry points)."""
+    if runtime.PRECISION == "fp32":                          # the validation engines (valley_amd/precise.py): never narrowed by an entry point
+        return torch.float32
     return runtime.HALF if runtime.half_bound() else torch.float16
 
 

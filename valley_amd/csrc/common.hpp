@@ -129,17 +129,34 @@ VLY_DEVICE float wave_reduce(float v, OP op) {
     v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xb1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
     return v;
 }
-VLY_DEVICE float wave_sum(float v) {
-    return wave_reduce(v, [](float a, float b) { return a + b; });
-}
-VLY_DEVICE float wave_max(float v) {
-    return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
-}
-// the __shfl_xor forms (tests/c_abi and A/B builds: -DVLY_SHFL_REDUCE=1 restores them everywhere)
+// the __shfl_xor forms (tests/c_abi and A/B builds: -DVLY_SHFL_REDUCE=1 restores them everywhere — same partners, same order of
+// additions, so a build with the switch is the bit-identity witness of the DPP forms)
+#ifndef VLY_SHFL_REDUCE
+#define VLY_SHFL_REDUCE 0
+#endif
 VLY_DEVICE float wave_sum_shfl(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+VLY_DEVICE float wave_max_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+VLY_DEVICE float wave_sum(float v) {
+#if VLY_SHFL_REDUCE
+    return wave_sum_shfl(v);
+#else
+    return wave_reduce(v, [](float a, float b) { return a + b; });
+#endif
+}
+VLY_DEVICE float wave_max(float v) {
+#if VLY_SHFL_REDUCE
+    return wave_max_shfl(v);
+#else
+    return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
+#endif
 }
 
 // async global -> LDS copy of 16 bytes per lane; LDS destination = wave-uniform base + lane*16

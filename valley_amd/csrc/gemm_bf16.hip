@@ -111,6 +111,32 @@ constexpr int P8_BAR_GAP = 8;       // barrier A this many MFMAs (~140 clk, a ds
 constexpr int P8_RD2_START = 1;     // phase 2: reads of the next tile's K step 0 after MFMA 1, 3, 5, ...
 constexpr int P8_RD2_STRIDE = 2;
 constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MFMAs before its buffer_load
+// the persistent kernel's tile boundary (round 5; DESIGN.md §4 "the tile boundary"):
+//   VLY_P4_ZEROFREE  the first K step of a tile is issued with C = 0 — no 256 v_accvgpr_write per tile (+2.0..2.2 % on the K = 1024
+//                    shapes, profiles/r05/r05_boundary_ab_1.txt)
+//   VLY_P4_ROLL      the ROLLING epilogue: the finished tile's epilogue runs row by row INSIDE the next tile's first K tile (implies
+//                    ZEROFREE) — see `boundary` in gemm_p4_kernel
+//   VLY_P4_DROPSTORE diagnostic: every store of the bf16 epilogue is issued out of range (dropped by the hardware)
+// (measured and removed: waiting for the loads in flight BEFORE the epilogue's first store so that the next K tile's counted wait
+//  does not also wait for the stores' acknowledgements — -0.7 .. +0.9 %, noise: the stores throttle the epilogue at their ISSUE)
+#ifndef VLY_P4_ROLL
+#define VLY_P4_ROLL 1
+#endif
+#ifndef VLY_P4_ROLL_MASK
+#define VLY_P4_ROLL_MASK 0x09       // bit e: epilogue e (VLY_EPI_*) takes the rolled boundary (plain + ReLU); the others keep their epilogue phase
+#endif                              // (still with the accumulators by name and the zero-free first K step)
+#ifndef VLY_P4_LIT
+#define VLY_P4_LIT 1                // 0: accumulators as C++ values everywhere (the round-4 kernel)
+#endif
+#ifndef VLY_P4_ZEROFREE
+#define VLY_P4_ZEROFREE 1
+#endif
+#ifndef VLY_P4_DROPSTORE
+#define VLY_P4_DROPSTORE 0
+#endif
+#ifndef VLY_P4_TIMING
+#define VLY_P4_TIMING 0
+#endif
 
 // One phase of the 4-wave loop (PIPE 8): the MI x NI MFMAs of one 32-wide K step on fragments that are already in
 // registers, with up to three lists of other instructions (the NI + MI fragment reads of the NEXT step — W fragments
@@ -119,8 +145,61 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 // does: ISA of the first version had nine ds_reads + lgkmcnt(0) ahead of the first MFMA of each phase).  One wave per
 // SIMD: nothing else hides a gap in this wave's MFMA stream.
 // f1(k), k < N1, goes after MFMA number S1 + k * D1 (row-major over the MI x NI MFMAs); f2 / f3 likewise
-template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, int N4, int S4, int D4, typename F1,
-          typename F2, typename F3, typename F4, typename ACC>
+// D = A . B + 0 into the accumulator block `c` (asm: the builtin with a zero C makes hipcc treat the block as a new value and move the
+// accumulators out of the accumulation registers; tied "+a", the block stays where the previous tile's MFMAs left it)
+VLY_DEVICE void mfma16_zero(f32x4& c, const bf16x8& a, const bf16x8& b) {
+#if VLY_FP16
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+VLY_DEVICE void mfma16_acc(f32x4& c, const bf16x8& a, const bf16x8& b) {      // D = A . B + C, same pinning
+#if VLY_FP16
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+// ---- accumulators by NAME (round 5, the rolled kernels).  Block b of a wave's tile IS a[4b : 4b + 3]: every MFMA and every read of
+// the accumulators is an asm statement that spells the registers out (the block number is an immediate operand, printed into the
+// register range), and no C++ value ever holds an accumulator.  hipcc allocates the accumulation registers only because of the one
+// clobber list at the top of the kernel (VLY_ALL_AGPRS) and — having no value of its own there, and no free accumulation register
+// to spill into — never emits a v_accvgpr_* of its own; tools/isa_blocks.py --agpr-audit checks exactly that after every build.
+// Why: as loop-carried C++ values (which the rolling epilogue needs: a block is re-used by the next tile the moment it is read) the
+// 256 accumulators put the allocator at exactly 256 of 256 registers, and every copy it inserts at a merge point or in front of a
+// tied asm operand is a spill (what three forms of pinning still left: 86 .. 446 spilled registers).
+// Wait states are ours now (nothing inside or around an asm statement is padded): an MFMA's D is read (v_accvgpr_read, or the next
+// K step's MFMA taking it as C) no sooner than a fragment row = 8 MFMAs later everywhere below, far beyond the 12 states an
+// 8-pass MFMA needs; the MFMA operands come from ds_read (waited for by explicit lgkmcnt waits), never from a VALU write.
+#if VLY_FP16
+#define VLY_MFMA16_NAME "v_mfma_f32_16x16x32_f16"
+#else
+#define VLY_MFMA16_NAME "v_mfma_f32_16x16x32_bf16"
+#endif
+VLY_DEVICE void mfma16_lit(int blk, const bf16x8& a, const bf16x8& b) {          // a[4 blk ..] += A . B   (blk: constant after unrolling)
+    asm volatile(VLY_MFMA16_NAME " a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(4 * blk), "i"(4 * blk + 3));
+}
+VLY_DEVICE void mfma16_lit_zero(int blk, const bf16x8& a, const bf16x8& b) {     // a[4 blk ..]  = A . B
+    asm volatile(VLY_MFMA16_NAME " a[%2:%3], %0, %1, 0" ::"v"(a), "v"(b), "i"(4 * blk), "i"(4 * blk + 3));
+}
+VLY_DEVICE f32x4 acc_read_lit(int blk) {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
+                 : "i"(4 * blk), "i"(4 * blk + 1), "i"(4 * blk + 2), "i"(4 * blk + 3));
+    return v;
+}
+#define VLY_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define VLY_ALL_AGPRS                                                                                                                  \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", VLY_A8(1), VLY_A8(2), VLY_A8(3), VLY_A8(4), VLY_A8(5), VLY_A8(6), VLY_A8(7), \
+        VLY_A8(8), VLY_A8(9), VLY_A8(10), VLY_A8(11), VLY_A8(12), VLY_A8(13), VLY_A8(14), VLY_A8(15), VLY_A8(16), VLY_A8(17), VLY_A8(18),   \
+        VLY_A8(19), VLY_A8(20), VLY_A8(21), VLY_A8(22), VLY_A8(23), VLY_A8(24), "a250", "a251", "a252", "a253", "a254", "a255"
+
+// MODE: 0 = builtin accumulate into acc[][], 1 = asm with C = 0 and the block tied "+a" (ZEROFREE without ROLL), 2 / 3 = accumulators by
+// name: accumulate / C = 0
+template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, int N4, int S4, int D4, int MODE = 0,
+          typename F1, typename F2, typename F3, typename F4, typename ACC>
 VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3, F4&& f4) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -130,7 +209,10 @@ VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[N
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            if constexpr (MODE == 3) mfma16_lit_zero(i * NI + j, wf[j], af[i]);
+            else if constexpr (MODE == 2) mfma16_lit(i * NI + j, wf[j], af[i]);
+            else if constexpr (MODE == 1) mfma16_zero(acc[i][j], wf[j], af[i]);
+            else acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
             const int t = i * NI + j;
             if (N1 > 0 && t >= S1 && (t - S1) % D1 == 0 && (t - S1) / D1 < N1) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -171,11 +253,11 @@ VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[N
 }
 template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3, typename ACC>
 VLY_DEVICE void phase_4w3(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3) {
-    phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, N3, S3, D3, 0, 0, 1>(acc, af, wf, f1, f2, f3, [](int) {});
+    phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, N3, S3, D3, 0, 0, 1, 0>(acc, af, wf, f1, f2, f3, [](int) {});
 }
 template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, typename F1, typename F2, typename ACC>
 VLY_DEVICE void phase_4w(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2) {
-    phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, 0, 0, 1, 0, 0, 1>(acc, af, wf, f1, f2, [](int) {}, [](int) {});
+    phase_4w4<MI, NI, N1, S1, D1, N2, S2, D2, 0, 0, 1, 0, 0, 1, 0>(acc, af, wf, f1, f2, [](int) {}, [](int) {});
 }
 
 // arguments of the VLY_EPI_QKV_ROPE epilogue (kernel argument by value; unused by every other instantiation)
@@ -904,6 +986,19 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     constexpr int GL2_START = GL1_START + N1 * GL_STRIDE - T;
     static_assert(GL1_START < T && GL_STRIDE >= 1 && N2 >= 0 && GL2_START + (N2 - 1) * GL_STRIDE < T, "piece schedule");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+#if VLY_P4_TIMING
+    // anatomy builds (tools/p4_boundary_times.py): wave 0 of the first workgroups stamps s_memtime at the seams of every tile into LDS
+    // (a global store would join the vmcnt queue the loop counts on) and copies them out at the end; `slabs` carries the buffer
+    __shared__ unsigned long long tstamp[64];
+    int tsn = 0;
+#define VLY_STAMP()                                                                            \
+    do {                                                                                       \
+        if (!SK && threadIdx.x == 0 && tsn < 64) tstamp[tsn] = __builtin_readcyclecounter();  \
+        ++tsn;                                                                                 \
+    } while (0)
+#else
+#define VLY_STAMP() do {} while (0)
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1056,48 +1151,381 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsC =
         __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (uint32_t)M * (uint32_t)ldc * (OUT == VLY_OUT_BF16 ? 2u : 4u), 0x00020000);
     int buf = 0;                                                     // buffer of the K tile being computed
-    for (;;) {
-        const bool wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
-        // (clearing the accumulators = 256 v_accvgpr_write per tile.  Tried in round 3: a peeled first K step with C = 0 as the
-        // MFMA's inline constant — builtin or asm with an "=a" result — makes hipcc keep the accumulators in arch VGPRs inside
-        // the K loop and spill 213 registers; not shipped.)
-        f32x4 acc[MI][NI];
+    // (clearing the accumulators = 256 v_accvgpr_write per tile.  Round 3: a peeled first K step with C = 0 as the MFMA's inline
+    // constant — builtin or asm with an "=a" result — makes hipcc keep the accumulators in arch VGPRs inside the K loop and spill
+    // 213 registers.  Round 5 (VLY_P4_ZEROFREE): the accumulators are ONE set of values carried through the persistent loop,
+    // cleared once per launch, and the first K step of a tile is the asm MFMA with C = 0 and its block tied "+a" — to the
+    // compiler an accumulation like any other.)
+    constexpr bool LIT = VLY_P4_LIT != 0 && !SK && OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE;     // the accumulators by name (mfma16_lit)
+    constexpr bool ROLL = VLY_P4_ROLL != 0 && LIT && ((VLY_P4_ROLL_MASK >> EPI) & 1) != 0;
+    constexpr int NST_ = EPI == VLY_EPI_SWIGLU ? NI / 4 : NI / 2;    // 16-byte stores per fragment row of the bf16 epilogue
+    static_assert(!ROLL || N1 + MI * NST_ <= 63, "vmcnt is a 6-bit count");
+    constexpr bool ZF = false;                                       // (the tied-operand form of the zero-free first step: spills since the lambdas moved; see LIT)
+    if constexpr (LIT) asm volatile("" ::: VLY_ALL_AGPRS);           // the kernel owns a0 .. a255
+    f32x4 acc[MI][NI];
+    if constexpr (ZF) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto ktile = [&]() {                                         // one K tile = two phases
-            const char* cur = smem + buf * STAGE;
-            const char* nxt = smem + (buf ^ 1) * STAGE;
-            // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
-            __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago
-            if (wave_live)
-                phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE>(
-                    acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
-            else {
-                __builtin_amdgcn_s_barrier();
+    }
+    auto pin_acc = [&]() {        // "the accumulators ARE in the accumulation registers": at every merge point of the loop-carried
+#pragma unroll                    // values (left alone, hipcc resolves the loop's phis in arch VGPRs and spills ~210 registers)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int q = 0; q < N1; ++q) piece(buf, q);
-            }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
+            for (int j = 0; j < NI; ++j) asm volatile("" : "+a"(acc[i][j]));
+    };
+    bool wave_live = false;                                          // this wave's slab of the tile being computed lies inside the problem
+    // first_c: the first K tile of a tile.  relaxed (ROLL): the first K tile after a boundary — the stream of vector-memory operations
+    // is then [pieces of the K tile this barrier publishes] [the epilogue's stores] [N1 pieces], and vmcnt retires loads AND stores in
+    // issue order (tools/probes/vmcnt_store_order.hip: 0 violations in 16.8 M trials), so "all but the N1 + stores youngest" waits for
+    // the pieces and for none of the stores: their drain (~10 k clk for the 32 MB every CU bursts at once) gets two more K tiles.
+    auto ktile = [&](auto first_c, bool relaxed = false) {       // one K tile = two phases
+        constexpr bool FIRST = decltype(first_c)::value;
+        const char* cur = smem + buf * STAGE;
+        const char* nxt = smem + (buf ^ 1) * STAGE;
+        // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago
+        if (wave_live)
+            phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE, LIT ? (FIRST ? 3 : 2) : (FIRST && ZF ? 1 : 0)>(
+                acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
+        else {
             __builtin_amdgcn_s_barrier();
-            if (wave_live)
-                phase_4w4<MI, NI, MI + NI, P8_RD2_START, P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE, 0, 0, 1, N2, GL2_START - P4_M0_LEAD, GL_STRIDE>(
-                    acc, a1, w1, rd_step0(nxt), [&](int q) { piece_ld(N1 + q); }, [](int) {}, [&](int q) { piece_m0(buf, N1 + q); });
-            else {
 #pragma unroll
-                for (int q = 0; q < N2; ++q) piece(buf, N1 + q);
+            for (int q = 0; q < N1; ++q) piece(buf, q);
+        }
+        if (ROLL && relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1 + MI * NST_) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave_live)
+            phase_4w4<MI, NI, MI + NI, P8_RD2_START, P8_RD2_STRIDE, N2, GL2_START, GL_STRIDE, 0, 0, 1, N2, GL2_START - P4_M0_LEAD, GL_STRIDE, LIT ? 2 : 0>(
+                acc, a1, w1, rd_step0(nxt), [&](int q) { piece_ld(N1 + q); }, [](int) {}, [&](int q) { piece_m0(buf, N1 + q); });
+        else {
+#pragma unroll
+            for (int q = 0; q < N2; ++q) piece(buf, N1 + q);
+        }
+        advance_load();
+        buf ^= 1;
+    };
+    [[maybe_unused]] int nfol = 0;                                   // SK owner: its epilogue adds the slabs of workgroups (x, j + 1 .. j + nfol)
+    [[maybe_unused]] bool contributor = false;
+    // SK owners (nfol = 1): the chain's running sum for the blocks of the current fragment row sits in sk_ld[]; the epilogue
+    // re-issues a block's load for row i + 1 as soon as it has consumed it (sk_next), so the reads of one row fly under
+    // the arithmetic of the row before.  (First version: one dependent load per block at its point of use = 128 exposed
+    // round trips per tile, +93 us on the 13B gate|up; second: two followers x a whole row ahead = 96 registers, spilled.)
+    [[maybe_unused]] f32x4 sk_ld[NI];
+    [[maybe_unused]] auto sk_next = [&](int i, int j0, int n) {  // loads of blocks j0 .. j0 + n - 1 of fragment row i
+        if (nfol == 0 || i >= MI) return;
+        uint32_t lo = (uint32_t)((i * NI * NT + tid) * 16);      // (opaque: see the contributor's stores)
+        asm volatile("" : "+v"(lo));
+        const char* sl = (const char*)(slabs + (size_t)(cc.u - sk_rem8) * (BM * BN)) + lo;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (j >= j0 && j < j0 + n) sk_ld[j] = *(const f32x4*)(sl + j * (NT * 16));
+    };
+    [[maybe_unused]] auto slab_term = [&](int, int j) { return nfol ? sk_ld[j] : f32x4{0.f, 0.f, 0.f, 0.f}; };
+    // ---- the bf16 epilogue as (setup, row) so that the rolling boundary can weave its rows into the next tile's first K tile
+    constexpr int NST = EPI == VLY_EPI_SWIGLU ? NI / 4 : NI / 2;                    // 16-byte stores per fragment row
+    [[maybe_unused]] const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
+    [[maybe_unused]] uint32_t vo[NST];                           // byte offset of this lane's store s in fragment row i (advanced per row)
+    [[maybe_unused]] const uint32_t rstep = (uint32_t)ldc * 32u; // 16 rows further down
+    [[maybe_unused]] f32x4 bv[NI];                               // the bias of this lane's 4 columns per block: once per tile
+    [[maybe_unused]] u32x4 held[NST];                            // a row's packed outputs, when their stores are deferred (boundary row 0)
+    [[maybe_unused]] auto epi_setup = [&](int em0, int en0) {    // (em0, en0): origin of the tile being written
+        if constexpr (OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE) {
+            {
+                const uint32_t rowb = (uint32_t)(em0 + wm0 + l15) * (uint32_t)ldc * 2u;
+#pragma unroll
+                for (int s = 0; s < NST; ++s) {
+                    const int n = EPI == VLY_EPI_SWIGLU ? ((en0 + wn0) >> 1) + (4 * s + g) * 8
+                                                        : en0 + wn0 + (2 * s + (g & 1)) * 16 + (g & 2) * 4;
+                    vo[s] = rowb + (n + 8 <= No && !VLY_P4_DROPSTORE ? (uint32_t)n * 2u : 0x80000000u);
+                }
             }
+            if constexpr (EPI != VLY_EPI_SWIGLU) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = en0 + wn0 + j * 16 + g * 4;
+                    bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (bias) bv[j] = *(const f32x4*)(bias + min(n, N - 4));           // uniform branch, clamped (dropped at the store)
+                }
+            }
+        }
+    };
+    // hook(k), k = 0 .. 2 NI - 1: sixteen evenly spread points of a row at which the rolling boundary issues ONE MFMA of the next
+    // tile each (an MFMA occupies the matrix core for ~16 clk and the wave's issue for one slot: placed between ~12 VALU
+    // instructions it runs entirely in their shadow; sixteen back to back would block the wave's issue for 240 clk)
+    [[maybe_unused]] auto epi_row = [&](int i, auto&& hook, auto defer_c) {    // fragment row i of the finished tile: read, activate, pack, store
+        constexpr bool DEFER = decltype(defer_c)::value;         // keep the row's 16-byte pieces in held[] (epi_flush stores them)
+        if constexpr (OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE) {
+            if constexpr (EPI == VLY_EPI_SWIGLU) {
+#pragma unroll
+                for (int jq = 0; jq < NI / 4; ++jq) {
+                    // gate = even columns, up = odd columns (row-interleaved weights); the four blocks of one 16-byte store go
+                    // through every step of x_sigmoid2(gate, 1) * up together (see the quick_gelu branch)
+                    f32x2 gt[4], up[4], e[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if constexpr (SKT) {
+                            const f32x4 v = acc_read(acc[i][4 * jq + jj]) + slab_term(i, 4 * jq + jj);
+                            gt[jj] = f32x2{v[0], v[2]};
+                            up[jj] = f32x2{v[1], v[3]};
+                        } else if constexpr (LIT) {
+                            const f32x4 v = acc_read_lit(i * NI + 4 * jq + jj);
+                            gt[jj] = f32x2{v[0], v[2]};
+                            up[jj] = f32x2{v[1], v[3]};
+                        } else acc_read_pairs(acc[i][4 * jq + jj], gt[jj], up[jj]);
+                    }
+                    if constexpr (SKT) sk_next(i + 1, 4 * jq, 4);
+                    hook(8 * jq + 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e[q] = gt[q] * -1.4426950408889634f;
+                    hook(8 * jq + 1);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
+                    hook(8 * jq + 2);
+#pragma unroll
+                    for (int q = 2; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
+                    hook(8 * jq + 3);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e[q] += 1.f;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
+                    hook(8 * jq + 4);
+#pragma unroll
+                    for (int q = 2; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
+                    hook(8 * jq + 5);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gt[q] *= e[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gt[q] *= up[q];
+                    hook(8 * jq + 6);
+                    uint32_t d[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) d[jj] = pack_h2(gt[jj][0], gt[jj][1]);
+                    const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                    const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+                    const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+                    const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+                    if constexpr (DEFER) held[jq] = u32x4{q0[0], q1[0], q0[1], q1[1]};
+                    else {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{q0[0], q1[0], q0[1], q1[1]}, rsC, vo[jq], 0, 0);
+                        vo[jq] += rstep;
+                    }
+                    hook(8 * jq + 7);
+                }
+            } else {
+#pragma unroll
+                for (int jp = 0; jp < NI / 2; ++jp) {
+                    // the four register pairs of two blocks go through every step TOGETHER: between a packed op and the
+                    // transcendental that consumes it (and back) the hardware wants a wait state, which independent
+                    // work fills (one chain at a time cost 487 s_nop per tile)
+                    f32x4 v0, v1;
+                    if constexpr (LIT) {
+                        v0 = acc_read_lit(i * NI + 2 * jp) + bv[2 * jp];
+                        v1 = acc_read_lit(i * NI + 2 * jp + 1) + bv[2 * jp + 1];
+                    } else {
+                        v0 = acc_read(acc[i][2 * jp]) + bv[2 * jp];
+                        v1 = acc_read(acc[i][2 * jp + 1]) + bv[2 * jp + 1];
+                    }
+                    if constexpr (SKT) {
+                        v0 += slab_term(i, 2 * jp);
+                        v1 += slab_term(i, 2 * jp + 1);
+                        sk_next(i + 1, 2 * jp, 2);
+                    }
+                    f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
+                    hook(4 * jp + 0);
+                    if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+                        constexpr float c = -1.4426950408889634f * 1.702f;           // x_sigmoid2's arithmetic, step by step
+                        f32x2 e[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = x[q] * c;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
+                        hook(4 * jp + 1);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] += 1.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
+                        hook(4 * jp + 2);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] *= e[q];
+                    } else {
+                        hook(4 * jp + 1);
+                    }
+                    if constexpr (EPI == VLY_EPI_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = f32x2{fmaxf(x[q][0], 0.f), fmaxf(x[q][1], 0.f)};
+                    }
+                    u32x2 pk[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        pk[jj][0] = pack_h2(x[2 * jj][0], x[2 * jj][1]);
+                        pk[jj][1] = pack_h2(x[2 * jj + 1][0], x[2 * jj + 1][1]);
+                    }
+                    if constexpr (EPI != VLY_EPI_QUICK_GELU) hook(4 * jp + 2);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    if constexpr (DEFER) held[jp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    else {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsC, vo[jp], 0, 0);
+                        vo[jp] += rstep;
+                    }
+                    hook(4 * jp + 3);
+                }
+            }
+        }
+    };
+    [[maybe_unused]] auto epi_flush = [&]() {                    // the deferred row's stores
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            __builtin_amdgcn_raw_buffer_store_b128(held[q], rsC, vo[q], 0, 0);
+            vo[q] += rstep;
+        }
+    };
+    // ---- ROLL: the tile boundary = the NEXT tile's first K tile, computed fragment row by fragment row, with the FINISHED tile's
+    // epilogue woven in.  What an epilogue costs (profiles/r05/r05_boundary_ab_1.txt, r05_store_burst.txt): the memory system takes a
+    // 32 MB burst of stores (every CU's 128 KB at once) at ~6 TB/s = 5.4 us whatever the lane -> address pattern, so a plain epilogue is
+    // bound by the ISSUE of its 32 stores per wave (~5.4 k clk, the wave stalled in the store queue), an activation epilogue by its
+    // VALU (~10 k clk, stores hidden behind it); either way the matrix cores idle.  The accumulators cannot be double-buffered (256
+    // of 512 registers), but a block is free the moment the epilogue has READ it: row r of the epilogue (8 blocks read, activated,
+    // packed, stored) is followed by row r of the next tile's K tile 0 — 8 MFMAs with C = 0 into the blocks just read, then the 8
+    // of K step 1 — so the tile's first 128 MFMAs execute in the shadow of the stores' issue stalls / the activation's VALU.
+    // Per block the order of accumulation is unchanged (K step 0, then 1): results are bit-identical to the phase order.
+    // Buffers and counters: the step-0 fragments of the new tile's K tile 0 were read by the last regular phase (they are kept across
+    // the boundary now); its step-1 fragments are read first thing, then barrier A releases that buffer and the 16 pieces of K tile 2
+    // are spread over the rows as in a regular K tile.  Every wave waits for its own pieces of K tile 1 (vmcnt(0)) BEFORE its first
+    // store — no store is ever older than a load someone still waits for — and barrier A publishes them: no barrier B in here.  The
+    // next K tile's step-0 fragments are re-read row by row (A) and behind the last row's K step 0 (W).
+    [[maybe_unused]] auto boundary = [&](int em0, int en0) {
+        if constexpr (ROLL) {
+            // (a wave whose slab of the NEW tile lies outside the problem computes this one K tile anyway: its accumulators are never
+            // stored — the descriptor drops them — and a branch per row would be eight 256-register merge points for the allocator)
+            const char* cur = smem + buf * STAGE;                // K tile 0 of the new tile
+            const char* nxt = smem + (buf ^ 1) * STAGE;          // its K tile 1
+            constexpr int SLOTS = 2 * NI;                        // MFMAs per fragment row
+            static_assert(NS <= SLOTS, "one piece per hook point of row 0");
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // step-0 fragments (read by the last phase) have landed
+            {
+                auto r1 = rd_step1(cur);
+#pragma unroll
+                for (int k = 0; k < MI + NI; ++k) r1(k);
+            }
+            if (!wave_live) {                                    // this wave sat the finished tile out (its slab lay outside the problem):
+                auto r0c = rd_step0(cur);                        // the dead branch of the last phase did not read the new tile's first fragments
+#pragma unroll
+                for (int k = 0; k < MI + NI; ++k) r0c(k);
+            }
+            epi_setup(em0, en0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of K tile 1, and the bias
+            if constexpr (EPI != VLY_EPI_SWIGLU) {               // (hipcc's own wait for the bias loads lands HERE, not behind the pieces below)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bv[j]));
+            }
+            bar_a(0);                                            // everyone has read K tile 0 and waited for its pieces of K tile 1
+            auto r0n = rd_step0(nxt);
+            // MFMA number 16 rr + t of the boundary (row rr: t < 8 K step 0 with C = 0, t >= 8 K step 1) and what hangs behind it: the
+            // reload of a0[rr] once the row's K step 0 is through, and behind the LAST row's K step 1 the reload of w0
+            auto emit = [&](int rr, int t) {
+                const int j = t % NI;
+                __builtin_amdgcn_sched_barrier(0);
+                if (t < NI) mfma16_lit_zero(rr * NI + j, w0[j], a0[rr]);
+                else mfma16_lit(rr * NI + j, w1[j], a1[rr]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == NI) {                                   // a0[rr] was last used by this row's K step 0
+                    r0n(NI + rr);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (rr == MI - 1 && t >= NI) {                   // last row: w0[j] is free once its K step 0 is through
+                    r0n(t - NI);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // row 0 carries the NS pieces of K tile 2 at its hook points and keeps its stores back until they are all issued: no store
+            // of this tile is older than a piece the next K tile's counted wait waits for (ktile, `relaxed`)
+            epi_row(0, [&](int k) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    if (q * SLOTS / NS == k) piece(buf, q);      // SLOTS = 16 hook points, NS = 14 .. 16 pieces
+                __builtin_amdgcn_sched_barrier(0);
+            }, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            epi_flush();
+            // epilogue row r carries the MFMAs of row r - 1 (whose blocks it has read) at its sixteen hook points
+#pragma unroll
+            for (int r = 1; r < MI; ++r) {
+                __builtin_amdgcn_sched_barrier(0);
+                epi_row(r, [&](int k) { emit(r - 1, k); }, std::false_type{});
+            }
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) emit(MI - 1, t);
+            __builtin_amdgcn_sched_barrier(0);
             advance_load();
             buf ^= 1;
-        };
-        [[maybe_unused]] int nfol = 0;                                   // SK owner: its epilogue adds the slabs of workgroups (x, j + 1 .. j + nfol)
-        [[maybe_unused]] bool contributor = false;
+        }
+    };
+    if constexpr (ROLL) {
+        // ---- the rolled schedule: first K tile of the first tile, then { K tiles 1 .. nk - 1 ; boundary = epilogue + next tile's K tile 0 }
+        // per tile, and the last tile's epilogue on its own.  One loop, one back edge, the accumulators written by asm MFMAs only.
+        wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
+        VLY_STAMP();
+        ktile(std::true_type{});
+        bool after_boundary = false;
+        for (;;) {
+            VLY_STAMP();                                             // (stamps: K loop from its second K tile | boundary | ...)
+            ktile(std::false_type{}, after_boundary);
+            for (int kt = 2; kt < nk; ++kt) ktile(std::false_type{});
+            after_boundary = true;
+            VLY_STAMP();
+            if (ct + G >= ntiles) break;
+            const int em0 = cm0, en0 = cn0;
+            ct += G;
+            tile_origin(ct, cm0, cn0);
+            boundary(em0, en0);
+            wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
+        }
+        epi_setup(cm0, cn0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            epi_row(i, [](int) {}, std::false_type{});
+        }
+        VLY_STAMP();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if VLY_P4_TIMING
+        VLY_STAMP();
+        if (threadIdx.x == 0 && blockIdx.x < 64 && slabs) {
+            unsigned long long* o = (unsigned long long*)slabs + (size_t)blockIdx.x * 65;
+            o[0] = (unsigned long long)tsn;
+            for (int q = 0; q < 64 && q < tsn; ++q) o[1 + q] = tstamp[q];
+        }
+#endif
+        return;
+    }
+    for (;;) {
+        VLY_STAMP();                                                 // (stamps of the unrolled schedule: K loop | epilogue | K loop | ...)
+        wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
+        if constexpr (ZF) pin_acc();
+        if constexpr (!ZF && !LIT) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        nfol = 0;
+        contributor = false;
         {
             int kt = SK ? cc.k : 0;
             const int kend = SK ? cc.kend : nk;
-            do ktile(); while (++kt < kend);
+            if constexpr (ZF || LIT) {                               // (first K step with C = 0)
+                ktile(std::true_type{});
+                while (++kt < kend) ktile(std::false_type{});
+            } else {
+                do ktile(std::false_type{}); while (++kt < kend);
+            }
         }
+        VLY_STAMP();
         if constexpr (SK) {
             const bool pool = cc.u < sk_units;
             contributor = pool && cc.kend < nk;                      // slices 0 .. S-2
@@ -1201,24 +1629,10 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                     for (int j = 0; j < NI; ++j) asm volatile("" : "+a"(acc[i][j]));
             }
         }
-        // SK owners (nfol = 1): the chain's running sum for the blocks of the current fragment row sits in sk_ld[]; the epilogue
-        // re-issues a block's load for row i + 1 as soon as it has consumed it (sk_next), so the reads of one row fly under
-        // the arithmetic of the row before.  (First version: one dependent load per block at its point of use = 128 exposed
-        // round trips per tile, +93 us on the 13B gate|up; second: two followers x a whole row ahead = 96 registers, spilled.)
-        [[maybe_unused]] f32x4 sk_ld[NI];
-        [[maybe_unused]] auto sk_next = [&](int i, int j0, int n) {  // loads of blocks j0 .. j0 + n - 1 of fragment row i
-            if (nfol == 0 || i >= MI) return;
-            uint32_t lo = (uint32_t)((i * NI * NT + tid) * 16);      // (opaque: see the contributor's stores)
-            asm volatile("" : "+v"(lo));
-            const char* sl = (const char*)(slabs + (size_t)(cc.u - sk_rem8) * (BM * BN)) + lo;
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                if (j >= j0 && j < j0 + n) sk_ld[j] = *(const f32x4*)(sl + j * (NT * 16));
-        };
-        [[maybe_unused]] auto slab_term = [&](int, int j) { return nfol ? sk_ld[j] : f32x4{0.f, 0.f, 0.f, 0.f}; };
         if constexpr (SKT) sk_next(0, 0, NI);
         // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
         // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
+        if constexpr (ZF) pin_acc();
         if (!(SK && contributor)) {
         if constexpr (OUT == VLY_OUT_BF16 && EPI == VLY_EPI_QKV_ROPE) {
             // RoPE + KV append on registers: a wave's 128 columns are ONE head (cn0 + wn0 is a multiple of 128),
@@ -1267,111 +1681,11 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 }
             }
         } else if constexpr (OUT == VLY_OUT_BF16) {
-            constexpr int NST = EPI == VLY_EPI_SWIGLU ? NI / 4 : NI / 2;                // 16-byte stores per fragment row
-            const int No = EPI == VLY_EPI_SWIGLU ? N >> 1 : N;
-            uint32_t vo[NST];                                        // byte offset of this lane's store s in fragment row i (advanced per row)
-            {
-                const uint32_t rowb = (uint32_t)(cm0 + wm0 + l15) * (uint32_t)ldc * 2u;
-#pragma unroll
-                for (int s = 0; s < NST; ++s) {
-                    const int n = EPI == VLY_EPI_SWIGLU ? ((cn0 + wn0) >> 1) + (4 * s + g) * 8
-                                                        : cn0 + wn0 + (2 * s + (g & 1)) * 16 + (g & 2) * 4;
-                    vo[s] = rowb + (n + 8 <= No ? (uint32_t)n * 2u : 0x80000000u);
-                }
-            }
-            const uint32_t rstep = (uint32_t)ldc * 32u;              // 16 rows further down
-            f32x4 bv[NI];                                            // the bias of this lane's 4 columns per block: once per tile
-            if constexpr (EPI != VLY_EPI_SWIGLU) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int n = cn0 + wn0 + j * 16 + g * 4;
-                    bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (bias) bv[j] = *(const f32x4*)(bias + min(n, N - 4));           // uniform branch, clamped (dropped at the store)
-                }
-            }
+            epi_setup(cm0, cn0);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 __builtin_amdgcn_sched_barrier(0);                   // row by row: keeps the accumulator reads from piling up
-                if constexpr (EPI == VLY_EPI_SWIGLU) {
-#pragma unroll
-                    for (int jq = 0; jq < NI / 4; ++jq) {
-                        // gate = even columns, up = odd columns (row-interleaved weights); the four blocks of one 16-byte store go
-                        // through every step of x_sigmoid2(gate, 1) * up together (see the quick_gelu branch)
-                        f32x2 gt[4], up[4], e[4];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            if constexpr (SKT) {
-                                const f32x4 v = acc_read(acc[i][4 * jq + jj]) + slab_term(i, 4 * jq + jj);
-                                gt[jj] = f32x2{v[0], v[2]};
-                                up[jj] = f32x2{v[1], v[3]};
-                            } else acc_read_pairs(acc[i][4 * jq + jj], gt[jj], up[jj]);
-                        }
-                        if constexpr (SKT) sk_next(i + 1, 4 * jq, 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) e[q] = gt[q] * -1.4426950408889634f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) e[q] += 1.f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) gt[q] *= e[q];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) gt[q] *= up[q];
-                        uint32_t d[4];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) d[jj] = pack_h2(gt[jj][0], gt[jj][1]);
-                        const auto p01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
-                        const auto p23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
-                        const auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
-                        const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{q0[0], q1[0], q0[1], q1[1]}, rsC, vo[jq], 0, 0);
-                        vo[jq] += rstep;
-                    }
-                } else {
-#pragma unroll
-                    for (int jp = 0; jp < NI / 2; ++jp) {
-                        // the four register pairs of two blocks go through every step TOGETHER: between a packed op and the
-                        // transcendental that consumes it (and back) the hardware wants a wait state, which independent
-                        // work fills (one chain at a time cost 487 s_nop per tile)
-                        f32x4 v0 = acc_read(acc[i][2 * jp]) + bv[2 * jp], v1 = acc_read(acc[i][2 * jp + 1]) + bv[2 * jp + 1];
-                        if constexpr (SKT) {
-                            v0 += slab_term(i, 2 * jp);
-                            v1 += slab_term(i, 2 * jp + 1);
-                            sk_next(i + 1, 2 * jp, 2);
-                        }
-                        f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
-                        if constexpr (EPI == VLY_EPI_QUICK_GELU) {
-                            constexpr float c = -1.4426950408889634f * 1.702f;           // x_sigmoid2's arithmetic, step by step
-                            f32x2 e[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) e[q] = x[q] * c;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_exp2f(e[q][0]), __builtin_amdgcn_exp2f(e[q][1])};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) e[q] += 1.f;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) e[q] = f32x2{__builtin_amdgcn_rcpf(e[q][0]), __builtin_amdgcn_rcpf(e[q][1])};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) x[q] *= e[q];
-                        }
-                        if constexpr (EPI == VLY_EPI_RELU) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) x[q] = f32x2{fmaxf(x[q][0], 0.f), fmaxf(x[q][1], 0.f)};
-                        }
-                        u32x2 pk[2];
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            pk[jj][0] = pack_h2(x[2 * jj][0], x[2 * jj][1]);
-                            pk[jj][1] = pack_h2(x[2 * jj + 1][0], x[2 * jj + 1][1]);
-                        }
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsC, vo[jp], 0, 0);
-                        vo[jp] += rstep;
-                    }
-                }
+                epi_row(i, [](int) {}, std::false_type{});
             }
         }
         if constexpr (OUT == VLY_OUT_F32) {                            // 16 bytes per lane already: 64 contiguous bytes per row and block
@@ -1426,15 +1740,35 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             ct += G;
         }
         tile_origin(ct, cm0, cn0);
+        if constexpr (ZF) pin_acc();
         {   // K step 0 of the next tile's first K tile: it landed before the last barrier B (same buffer rotation)
             auto r0 = rd_step0(smem + buf * STAGE);
 #pragma unroll
             for (int k = 0; k < MI + NI; ++k) r0(k);
         }
     }
+    VLY_STAMP();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no LDS-DMA may outlive the workgroup's LDS allocation
+#if VLY_P4_TIMING
+    VLY_STAMP();
+    if (!SK && threadIdx.x == 0 && blockIdx.x < 64 && slabs) {
+        unsigned long long* o = (unsigned long long*)slabs + (size_t)blockIdx.x * 65;
+        o[0] = (unsigned long long)tsn;
+        for (int q = 0; q < 64 && q < tsn; ++q) o[1 + q] = tstamp[q];
+    }
+#endif
 }
+#undef VLY_STAMP
 
+#if VLY_P4_TIMING
+static void* vlydbg_p4_buffer() {
+    static void* buf = [] { void* p = nullptr; (void)hipMalloc(&p, 64 * 65 * 8); (void)hipMemset(p, 0, 64 * 65 * 8); return p; }();
+    return buf;
+}
+extern "C" int vlydbg_p4_timing_read(unsigned long long* host) {        // 64 workgroups x (count, 64 stamps)
+    return (int)hipMemcpy(host, vlydbg_p4_buffer(), 64 * 65 * 8, hipMemcpyDeviceToHost);
+}
+#endif
 struct P4SkArgs {                                          // split-K remainder form (vly_gemm_bf16_streamk, tile hints 298 / 299)
     float* slabs;
     unsigned* flags;
@@ -1476,6 +1810,10 @@ int launch_p4(const void* A, const void* W, const float* bias, const float* R, v
         if (pin > 0 && rem > 0 && (pin == 1 || ((pin - 1) * rem8 <= sk->slab_cap && nk / pin >= 2))) sk_S = pin;
     }
     dim3 grid(SK || tiles >= cus ? cus : tiles), block(256);           // SK: every CU takes its share of the units
+#if VLY_P4_TIMING
+    P4SkArgs dbg{(float*)vlydbg_p4_buffer(), nullptr, 0u, 0};
+    if (!sk) sk = &dbg;
+#endif
 #define VLY_P4_LAUNCH(E, O)                                                                                                  \
     hipLaunchKernelGGL((gemm_p4_kernel<BM, BN, E, O, SK>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, \
                        N, K, lda, ldw, ldc, ldr, tm, tn, gm, rope ? *rope : RopeArgs{}, sk ? sk->slabs : nullptr,                 \

@@ -125,6 +125,7 @@ def _load_locked():
         raise ValleyHipError(f"{path} stores {'fp16' if lib.vly_storage_dtype() else 'bf16'} but VALLEY_PRECISION asks for "
                              f"{'fp16' if want else 'bf16'} tensors")
     _LIB = lib
+    runtime.bind_half("lib.load(%s)" % os.path.basename(path))        # the 16-bit storage type is final from here on
     return lib
 
 

@@ -32,6 +32,7 @@ class HipKVCache:
     (``past_key_values[0][0].shape[-2]``, serve/model_worker.py:381) and ``get_seq_length()``."""
 
     def __init__(self, layers: int, batch: int, heads: int, ctx_max: int, device):
+        runtime.bind_half("HipKVCache")                      # 16-bit tensors exist from here on: the storage type is final
         self.k = [torch.zeros((batch, heads, ctx_max, 128), dtype=runtime.HALF, device=device) for _ in range(layers)]
         self.v = [torch.zeros((batch, heads, ctx_max, 128), dtype=runtime.HALF, device=device) for _ in range(layers)]
         self.seq_len = 0
@@ -101,6 +102,7 @@ class HipLlama:
             raise ValueError("HIP Llama path requires head_dim == 128 (hidden = heads*128)")
         if hidden % 64 or intermediate % 64:
             raise ValueError("hidden and intermediate sizes must be multiples of 64")
+        runtime.bind_half("HipLlama")                        # its weights are allocated in runtime.HALF: final from here on
         self.H, self.heads, self.I, self.L, self.V, self.eps = hidden, heads, intermediate, layers, vocab, eps
         self.Vpad = (vocab + 7) // 8 * 8
         self.device = torch.device(device)

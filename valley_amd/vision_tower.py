@@ -59,6 +59,7 @@ class HipCLIPVisionTower:
             raise ValueError("the HIP tower supports the ViT-L/14 geometry only (1024 wide, 16 heads, 224/14)")
         if c.hidden_act != "quick_gelu":
             raise ValueError("only quick_gelu towers are supported")
+        runtime.bind_half("HipCLIPVisionTower")              # its weights are allocated in runtime.HALF: final from here on
         self.device = torch.device(device)
         self.layers: List[Dict[str, torch.Tensor]] = []
         self.loaded = False
