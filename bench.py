@@ -179,11 +179,14 @@ def cpu_baseline():
 
 
 def live_traffic(args, kernel_name):
-    """HBM-side bytes per launch of `kernel_name`, measured now: two `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE
-    do not fit the TCC slot budget together — MI355X_MICROARCH.md §rocprofv3 PMC slots — and nothing but --kernel-trace
-    rides along) over a short child run of this same bench, corrected as the guide's HBM section prescribes: both
-    counters x1024, FETCH_SIZE x2 on gfx950 (128-byte requests tallied at 64 B), WRITE_SIZE as is.
-    -> (bytes per launch | None, note)."""
+    """Hardware counters of `kernel_name`, measured now: three `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE do not fit the
+    TCC slot budget together — MI355X_MICROARCH.md §rocprofv3 PMC slots —, the SQ / GRBM pair has its own pass, and nothing but
+    --kernel-trace rides along) over a short child run of this same bench.
+      HBM-side bytes per launch: both counters x1024, FETCH_SIZE x2 on gfx950 (128-byte requests tallied at 64 B), WRITE_SIZE as is
+      (the guide's HBM section);
+      matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), both from the SAME pass;
+      sustained clock: GRBM_GUI_ACTIVE / 8 / the launch's duration in that pass's kernel trace.
+    -> (bytes per launch | None, note, {"mfma_busy", "sustained_clock_GHz", ...} | {})."""
     import csv
     import glob
     import shutil
@@ -191,32 +194,54 @@ def live_traffic(args, kernel_name):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {}
     out = tempfile.mkdtemp(prefix="vly_pmc_", dir="/tmp")
     key = kernel_name.replace(" ", "")
     per = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", c, "--", sys.executable,
+    extra = {}
+    for tag, counters in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]),
+                          ("MFMA", ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"])):
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", tag, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--config", args.config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-               "--no-kernel-events", "--traffic", "none", "--pack-weights", str(args.pack_weights)]
+               "--no-kernel-events", "--traffic", "none", "--also", "none", "--pack-weights", str(args.pack_weights)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                stderr=subprocess.PIPE, timeout=900)
         except Exception as e:  # noqa: BLE001
-            return None, f"rocprofv3 --pmc {c} failed: {e!r}"
-        files = glob.glob(os.path.join(out, "**", f"{c}_counter_collection.csv"), recursive=True)
+            return None, f"rocprofv3 --pmc {tag} failed: {e!r}", extra
+        files = glob.glob(os.path.join(out, "**", f"{tag}_counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
-            return None, f"rocprofv3 --pmc {c}: rc={r.returncode}, no counter file ({r.stderr.decode(errors='replace')[-200:]})"
-        vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                if row["Counter_Name"] == c and key in row["Kernel_Name"].replace(" ", "")]
-        if not vals:
-            return None, f"{kernel_name} not in the {c} pass"
-        per[c] = (sum(vals) / len(vals), len(vals))
+            if tag == "MFMA":                                      # the traffic passes stand on their own
+                extra = {"pmc_note": f"rocprofv3 --pmc {' '.join(counters)}: rc={r.returncode}, no counter file"}
+                break
+            return None, f"rocprofv3 --pmc {tag}: rc={r.returncode}, no counter file ({r.stderr.decode(errors='replace')[-200:]})", extra
+        rows = [row for row in csv.DictReader(open(files[0])) if key in row["Kernel_Name"].replace(" ", "")]
+        for c in counters:
+            vals = [float(row["Counter_Value"]) for row in rows if row["Counter_Name"] == c]
+            if not vals:
+                if tag == "MFMA":
+                    extra = {"pmc_note": f"{kernel_name} not in the {c} pass"}
+                    break
+                return None, f"{kernel_name} not in the {c} pass", extra
+            per[c] = (sum(vals) / len(vals), len(vals))
+        if tag == "MFMA" and "SQ_VALU_MFMA_BUSY_CYCLES" in per and "GRBM_GUI_ACTIVE" in per:
+            cycles = per["GRBM_GUI_ACTIVE"][0] / 8.0               # the counter sums the 8 XCDs' active cycles
+            extra = {"mfma_busy": round(per["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (1024.0 * cycles), 4),
+                     "pmc_launches": per["GRBM_GUI_ACTIVE"][1],
+                     "pmc_note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), one rocprofv3 --pmc pass of a 2-step child run; "
+                                 "clock = GRBM_GUI_ACTIVE / 8 / launch duration in that pass (profiled runs clock ~3 % under un-profiled ones)"}
+            tfiles = glob.glob(os.path.join(out, "**", "MFMA_kernel_trace.csv"), recursive=True)
+            if tfiles:
+                durs = [int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) for row in csv.DictReader(open(tfiles[0]))
+                        if key in row["Kernel_Name"].replace(" ", "")]
+                if durs:
+                    extra["sustained_clock_GHz"] = round(cycles / (sum(durs) / len(durs)), 3)
+                    extra["pmc_avg_launch_us"] = round(sum(durs) / len(durs) / 1e3, 2)
     shutil.rmtree(out, ignore_errors=True)
     b = 2 * 1024 * per["FETCH_SIZE"][0] + 1024 * per["WRITE_SIZE"][0]
     return int(b), (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two passes of `bench.py --config {args.config} --steps 2` on this "
                     f"box ({per['FETCH_SIZE'][1]} launches), x1024, FETCH_SIZE x2 (gfx950); fetch {2 * 1024 * per['FETCH_SIZE'][0] / 1e6:.1f} MB "
-                    f"+ write {1024 * per['WRITE_SIZE'][0] / 1e6:.1f} MB per launch")
+                    f"+ write {1024 * per['WRITE_SIZE'][0] / 1e6:.1f} MB per launch"), extra
 
 
 ALSO = {
@@ -224,6 +249,11 @@ ALSO = {
     "c2": (["--config", "c2", "--steps", "10", "--warmup", "3"], "configs[1]"),
     "c4_n1": (["--config", "c4", "--steps", "5", "--warmup", "2"], "configs[3], per-GPU shape at N = 1"),
     "c5_decode": (["--config", "c5", "--decode", "256", "--warmup", "8"], "configs[4]"),
+    # the same step with 8 live requests (serving.ContinuousBatcher; the reference's worker admits 5 at a time, model_worker.py:467-474)
+    "c5_decode_b8": (["--config", "c5", "--decode", "128", "--decode-batch", "8", "--warmup", "8"], "configs[4] x 8 concurrent requests"),
+    # the headline workload on the fp32 validation engines (valley_amd/precise.py): what the 1e-3 logit bound costs
+    "c3_fp32": (["--config", "c3", "--steps", "2", "--warmup", "1"], "configs[2] on the fp32 validation engines (logits within 1e-3)",
+                {"VALLEY_PRECISION": "fp32"}),
     # the headline workload on libvalley_hip_f16.so: IEEE fp16 storage is the reference's own inference dtype
     # (valley/inference/run_valley.py:39 `torch_dtype=torch.float16`); the child is told through VALLEY_PRECISION
     "c3_fp16": (["--config", "c3", "--steps", "10", "--warmup", "3"], "configs[2] at the reference's inference dtype (fp16 storage)",
@@ -258,8 +288,8 @@ def run_also(names, pack_weights):
         keep["workload"] = d.get("config", {}).get("workload")
         rf = d.get("roofline")
         if rf:
-            keep["roofline"] = {k: rf[k] for k in ("bound", "kernel", "shape", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
-                                                  "launches", "share_of_step_time", "bytes_per_token", "note") if k in rf}
+            keep["roofline"] = {k: rf[k] for k in ("bound", "kernel", "shape", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "hbm_GBps", "mfma_busy",
+                                                  "sustained_clock_GHz", "launches", "share_of_step_time", "bytes_per_token", "note") if k in rf}
         keep["child_wall_s"] = round(time.perf_counter() - t0, 1)
         out[name] = keep
     return out
@@ -278,6 +308,9 @@ def main():
                          "sequences (configs[3] at R = 8: B = 64, M = 22528 rows per GEMM).  `value` counts the local frames only.")
     ap.add_argument("--decode", type=int, default=0, metavar="N",
                     help="instead of the prefill step: prefill once, then time N greedy hipGraph decode steps (configs[4])")
+    ap.add_argument("--decode-batch", type=int, default=1, metavar="R",
+                    help="with --decode: R concurrent requests (<= 8) on ONE captured step through serving.ContinuousBatcher — the reference's "
+                         "worker admits 5 concurrent requests (serve/model_worker.py:467-474); the weight stream of a step is shared")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VALLEY_BENCH_STREAMS", "1")),
                     help="run the batch as this many independent sub-batches on separate HIP streams (tail filling)")
     ap.add_argument("--pack-weights", type=int, default=int(os.environ.get("VALLEY_PACK_WEIGHTS", "1")), choices=[0, 1],
@@ -352,6 +385,45 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     stage_events = []
     gather_events = []
+
+    if args.decode and args.decode_batch > 1:
+        # continuous batching: R live requests, each with its own T-frame visual prefix and KV rows, advance together
+        # through ONE captured decode step; the step streams every weight once whatever R is, so the aggregate rate scales with R
+        # until the R attention passes and the GEMVs' R accumulator rows show
+        from valley_amd.serving import ContinuousBatcher
+        R, n_new = args.decode_batch, args.decode
+        cb = ContinuousBatcher(model, slots=R, ctx_max=S + n_new + args.warmup + 8)
+        for r in range(R):
+            cb.add(input_ids[:1], images=frames[:1])
+        for _ in range(args.warmup):
+            cb.step()
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(n_new):
+            toks = cb.step()                                  # (one D2H read of the R tokens per step: the serving loop's own sync)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        assert len(toks) == R
+        ms_step = e0.elapsed_time(e1) / n_new
+        wbytes = 2.0 * (L * (4 * H * H + 3 * H * I) + H * mm.llama.Vpad)
+        ctx_mid = S + args.warmup + n_new / 2
+        kvbytes = 2.0 * 2 * L * H * ctx_mid * R
+        ach = (wbytes + kvbytes) / (ms_step * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "decode tokens/sec, all live requests (KV-cache, greedy, one hipGraph step per token)", "value": round(R * 1e3 / ms_step, 2),
+            "unit": "tokens/s", "n_gpus": 1, "steps": n_new, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DT, "data": "synthetic",
+            "config": {"workload": f"{cfg['label']} -> continuous batching, {R} live requests on one captured step, prefix S={S}, {n_new} tokens each",
+                       "name": args.config, "requests": R},
+            "tokens_per_s_per_request": round(1e3 / ms_step, 2), "wall_ms_per_step": round(wall / n_new * 1e3, 4),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                         "traffic": None, "bytes_per_token": int((wbytes + kvbytes) / R), "bytes_per_step": int(wbytes + kvbytes),
+                         "note": "algorithmic bytes per STEP = all matmul weights once (16-bit) + K and V of the mean context of every request"}}),
+            flush=True)
+        return
 
     if args.decode:
         # configs[4]: T-frame visual prefix, B=1, N generated tokens through the captured decode step
@@ -537,9 +609,9 @@ def main():
             # split-K pairs) is not one workload, its per-name average in rocprofv3 mixes them (kernel_all_shapes below)
             dshape, (tsum, fsum, n, name) = max(shapes.items(), key=lambda kv: kv[1][0])
             ach = fsum / tsum / 1e12
-            traffic, traffic_src = None, None
+            traffic, traffic_src, pmc = None, None, {}
             if args.traffic == "live" and world == 1:
-                traffic, traffic_src = live_traffic(args, name)
+                traffic, traffic_src, pmc = live_traffic(args, name)
             if traffic is None and args.traffic != "none":           # newest committed PMC run of this config
                 import glob
                 for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", f"r*_traffic_{args.config}.json"), recursive=True),
@@ -561,6 +633,11 @@ def main():
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                   "traffic_source": traffic_src, "algorithmic_bytes": algo_bytes,
                                   "traffic_over_algorithmic": round(traffic / algo_bytes, 2) if traffic else None,
+                                  # north_star's two rocprof quantities, from the live PMC passes: HBM-side GB/s of this kernel
+                                  # (counter bytes / the live events' launch time) and its matrix-core utilisation + sustained clock
+                                  "hbm_GBps": round(traffic / (tsum / n) / 1e9, 1) if traffic else None,
+                                  "mfma_busy": pmc.get("mfma_busy"), "sustained_clock_GHz": pmc.get("sustained_clock_GHz"),
+                                  "pmc": {k: v for k, v in pmc.items() if k not in ("mfma_busy", "sustained_clock_GHz")} or None,
                                   "launches": n, "avg_launch_us": round(tsum / n * 1e6, 2),
                                   "avg_flop_per_launch": round(fsum / n / 1e9, 3),
                                   "share_of_step_time": round(tsum / rec_steps / (ms_step * 1e-3), 3),

@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 5   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
+#define VLY_ABI_VERSION 6   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
                                vly_decode_attention_split, vly_gemv_attnmerge_bf16; 5: + vly_decode_layers(_supported),
-                               vly_decode_attention_merged */
+                               vly_decode_attention_merged; 6: vly_decode_layers(_supported) and tile hint 297 moved to the
+                               EXPERIMENTAL library (libvalley_hip_exp.so, section at the end), vly_gemv_bf16 takes M <= 16 */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -287,10 +288,12 @@ int vly_decode_attention_rows(const void *qkv_bf16, void *kcache_bf16, void *vca
  *   (as vly_decode_attention_rows).  Same RoPE / append arithmetic as vly_decode_attention; the softmax sums are
  *   associated per split, so outputs agree with it to fp32 rounding, not bit for bit. */
 #define VLY_DECODE_SPLITS 4
+#ifdef VLY_EXPERIMENTAL      /* round 3's form: libvalley_hip_exp.so only (the merged launch below is the default) */
 int vly_decode_attention_split(const void *qkv_bf16, void *kcache_bf16, void *vcache_bf16, const float *cos_table,
                                const float *sin_table, const uint8_t *key_valid, int key_valid_stride, float *partials,
                                int B, int heads, int past_len, const int32_t *past_len_dev, int past_len_dev_stride,
                                int ctx_max, void *stream);
+#endif
 
 /* The same launch, with the merge done by the LAST of a head's VLY_DECODE_SPLITS workgroups to finish (round 4): it combines the
  *   head's partials (the arithmetic of vly_gemv_attnmerge_bf16's prologue, in split order: bit-identical) and writes the
@@ -302,8 +305,12 @@ int vly_decode_attention_merged(const void *qkv_bf16, void *kcache_bf16, void *v
                                 void *out_bf16, uint32_t *arrivals, int B, int heads, int past_len,
                                 const int32_t *past_len_dev, int past_len_dev_stride, int ctx_max, void *stream);
 
-/* Weight-streaming GEMV for decode (M <= 8 rows):  same contract as vly_gemm_bf16
+/* Weight-streaming GEMV for decode (M <= 16 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
+ *   M <= 4: VALU dot products; 5 <= M <= 16: the same stream through MFMA 16x16x32 (sixteen weight rows x the M
+ *   activation rows per instruction) when K % 64 == 0, N % 4 == 0 and the rows are 16-byte aligned — the step of
+ *   several concurrent requests (the reference's worker admits 5, serve/model_worker.py:467-474) then costs what one
+ *   request's does.  Each output row depends on its own activation row only.  M > 8 needs the MFMA form.
  *   serve/model_worker.py:380-387 (one-token forward). */
 int vly_gemv_bf16(const void *A, const void *W, const float *bias, const float *residual, void *C,
                   int M, int N, int K, int lda, int ldw, int ldc, int ldr,
@@ -322,40 +329,10 @@ int vly_gemv_rmsnorm_bf16(const float *H, const float *gamma, float eps, const v
 /* The o projection of a decode step with the merge of vly_decode_attention_split's partials folded in:
  *   C = (merge(partials) as bf16 [M, heads*128]) · W^T + bias + residual, M <= 2 rows, 2048 <= K = heads*128 <= 6144.
  *   (HF LlamaAttention.forward: attn_output -> o_proj, behind serve/model_worker.py:380-387.) */
+#ifdef VLY_EXPERIMENTAL      /* libvalley_hip_exp.so only */
 int vly_gemv_attnmerge_bf16(const float *partials, const void *W, const float *bias, const float *residual, void *C,
                             int M, int N, int heads, int ldw, int ldc, int ldr, int out_dtype, void *stream);
-
-/* ALL decoder layers of a batch-1/2 decode step in ONE persistent launch (round 4; decode_step.hip): per layer the five
- *   phases input_layernorm + q|k|v, RoPE + KV append + split attention, merge + o + residual, post_attention_layernorm +
- *   gate|up + SwiGLU, down + residual — the launches vly_gemv_rmsnorm_bf16 / vly_decode_attention_split /
- *   vly_gemv_attnmerge_bf16 / vly_gemv_rmsnorm_bf16 / vly_gemv_bf16 of a layer, with the same arithmetic (the step is
- *   BIT-identical to them) — separated by grid barriers inside the launch, the weight stream running across every barrier.
- *   Replaces the loop body of serve/model_worker.py:380-387 (one-token forward) x num_hidden_layers.
- *     layers_dev : DEVICE array of n_layers descriptors (weights in the layouts of the entry points above: q|k|v fused
- *                  [3H, H], o [H, H], gate|up row-interleaved [2I, H], down [H, I], 16-bit storage type, row-major,
- *                  16-byte aligned; the two RMSNorm weights fp32 [H]; this layer's K / V cache [B, heads, ctx_max, 128])
- *     h          : fp32 [B, H] residual stream, in (token embeddings) and out (input of the final norm)
- *     qkv_scratch (16-bit [B, 3H]), partials (fp32 [B, heads, VLY_DECODE_SPLITS, 132]), mlp_scratch (fp32 [B, I]): workspaces
- *     pos_dev    : device int32, the position of the new token (pos_stride 0: one value; 1: one per batch row)
- *     sync       : VLY_DECODE_SYNC_WORDS uint32 of device memory, 64-byte aligned, private to this stream and to this
- *                  (n_layers) — zeroed ONCE by the caller before the first launch; the barrier counters continue from launch to
- *                  launch.  After a launch completed, sync[VLY_DECODE_SYNC_ABORT] != 0 means a workgroup gave up waiting at a
- *                  grid barrier (not every workgroup was resident: another kernel was holding CUs) and h is invalid — every
- *                  wait is bounded, the launch always ends; zero the words again before the next launch.
- *   Needs the whole GPU: one 1024-thread workgroup per CU, all resident.  B <= 2, heads * 128 == H, (H, I) in the 7B / 13B
- *   classes (vly_decode_layers_supported); -22 otherwise. */
-typedef struct vly_decode_layer {
-    const void *w_qkv, *w_o, *w_gu, *w_down;
-    const float *ln1, *ln2;
-    void *kcache, *vcache;
-} vly_decode_layer;
-#define VLY_DECODE_SYNC_WORDS 512
-#define VLY_DECODE_SYNC_ABORT 272
-int vly_decode_layers_supported(int B, int H, int heads, int I);
-int vly_decode_layers(const vly_decode_layer *layers_dev, int n_layers, float *h, void *qkv_scratch, float *partials,
-                      float *mlp_scratch, const float *cos_table, const float *sin_table, const uint8_t *key_valid,
-                      int key_valid_stride, const int32_t *pos_dev, int pos_stride, int B, int H, int heads, int I, float eps,
-                      int ctx_max, uint32_t *sync, void *stream);
+#endif
 
 /* fp32 -> bf16 (round-to-nearest-even) over n contiguous elements, n % 8 == 0: the `.to(dtype)`
  *   between an fp32 tensor and a GEMM input (only used on the `max`-pooling path, where the
@@ -428,6 +405,47 @@ int vly_pool_tokens_f32(const float *feats, float *out, int B, int T, int W, int
 /* vly_embed_splice with an fp32 embedding table [V,H] and fp32 visual tokens (valley_model.py:160, 195-247). */
 int vly_embed_splice_f32(const int32_t *row_map, const float *embed, const float *visual, float *out, int R, int H,
                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * EXPERIMENTAL entry points (these and the two #ifdef VLY_EXPERIMENTAL prototypes above): exported by libvalley_hip_exp.so only (the bf16 sources built with -DVLY_EXPERIMENTAL=1,
+ * valley_amd/build.py; VALLEY_EXPERIMENTAL=1 makes the Python binding load it).  Built to parity and measured BEHIND the default
+ * path they would replace, kept as tested experiments: no default path calls them, the shipped libraries
+ * (libvalley_hip.so, libvalley_hip_f16.so) do not carry them.  That library also accepts tile hint 297 of
+ * vly_gemm_bf16_streamk and the VLY_VIT_ATTN=4 / VLY_LLAMA_ATTN=1 kernels.
+ * --------------------------------------------------------------------------------------------------------------------- */
+#ifdef VLY_EXPERIMENTAL
+/* ALL decoder layers of a batch-1/2 decode step in ONE persistent launch (round 4; decode_step.hip): per layer the five
+ *   phases input_layernorm + q|k|v, RoPE + KV append + split attention, merge + o + residual, post_attention_layernorm +
+ *   gate|up + SwiGLU, down + residual — the launches vly_gemv_rmsnorm_bf16 / vly_decode_attention_split /
+ *   vly_gemv_attnmerge_bf16 / vly_gemv_rmsnorm_bf16 / vly_gemv_bf16 of a layer, with the same arithmetic (the step is
+ *   BIT-identical to them) — separated by grid barriers inside the launch, the weight stream running across every barrier.
+ *   Replaces the loop body of serve/model_worker.py:380-387 (one-token forward) x num_hidden_layers.
+ *     layers_dev : DEVICE array of n_layers descriptors (weights in the layouts of the entry points above: q|k|v fused
+ *                  [3H, H], o [H, H], gate|up row-interleaved [2I, H], down [H, I], 16-bit storage type, row-major,
+ *                  16-byte aligned; the two RMSNorm weights fp32 [H]; this layer's K / V cache [B, heads, ctx_max, 128])
+ *     h          : fp32 [B, H] residual stream, in (token embeddings) and out (input of the final norm)
+ *     qkv_scratch (16-bit [B, 3H]), partials (fp32 [B, heads, VLY_DECODE_SPLITS, 132]), mlp_scratch (fp32 [B, I]): workspaces
+ *     pos_dev    : device int32, the position of the new token (pos_stride 0: one value; 1: one per batch row)
+ *     sync       : VLY_DECODE_SYNC_WORDS uint32 of device memory, 64-byte aligned, private to this stream and to this
+ *                  (n_layers) — zeroed ONCE by the caller before the first launch; the barrier counters continue from launch to
+ *                  launch.  After a launch completed, sync[VLY_DECODE_SYNC_ABORT] != 0 means a workgroup gave up waiting at a
+ *                  grid barrier (not every workgroup was resident: another kernel was holding CUs) and h is invalid — every
+ *                  wait is bounded, the launch always ends; zero the words again before the next launch.
+ *   Needs the whole GPU: one 1024-thread workgroup per CU, all resident.  B <= 2, heads * 128 == H, (H, I) in the 7B / 13B
+ *   classes (vly_decode_layers_supported); -22 otherwise. */
+typedef struct vly_decode_layer {
+    const void *w_qkv, *w_o, *w_gu, *w_down;
+    const float *ln1, *ln2;
+    void *kcache, *vcache;
+} vly_decode_layer;
+#define VLY_DECODE_SYNC_WORDS 512
+#define VLY_DECODE_SYNC_ABORT 272
+int vly_decode_layers_supported(int B, int H, int heads, int I);
+int vly_decode_layers(const vly_decode_layer *layers_dev, int n_layers, float *h, void *qkv_scratch, float *partials,
+                      float *mlp_scratch, const float *cos_table, const float *sin_table, const uint8_t *key_valid,
+                      int key_valid_stride, const int32_t *pos_dev, int pos_stride, int B, int H, int heads, int I, float eps,
+                      int ctx_max, uint32_t *sync, void *stream);
+#endif  /* VLY_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -98,35 +98,43 @@ def _t(w: Dict, k: str) -> torch.Tensor:
 # tables stay fp32 in both.
 _ROUND = False
 _ROUND_DTYPE = torch.bfloat16
+_ROUND_KEEP = frozenset()         # storage points exempt from the rounding (tools/logit_precision_study.py switches them off one by one)
+# every storage point of the pipeline, by name (the ``site`` of each ``_q``): which tensor the HIP path holds in 16 bits
+ROUND_SITES = ("weights", "vit.pixels", "vit.ln", "vit.qkv", "vit.probs", "vit.attn_out", "vit.o_out", "vit.gelu", "vit.fc2_out",
+               "proj.in", "proj.rows", "embed", "ll.ln", "ll.qkv", "ll.rope", "ll.probs", "ll.attn_out", "ll.o_out", "ll.swiglu",
+               "ll.down_out", "ll.final_norm")
 
 
 class rounding:
     """Context manager: ``with oracle.rounding(): ...`` evaluates the path with 16-bit storage rounding — bf16 by default,
-    ``rounding(torch.float16)`` for the fp16 library (VALLEY_PRECISION=fp16, the reference's own inference dtype)."""
+    ``rounding(torch.float16)`` for the fp16 library (VALLEY_PRECISION=fp16, the reference's own inference dtype).
+    ``keep``: names from ROUND_SITES that stay fp32 (the ablation of tools/logit_precision_study.py)."""
 
-    def __init__(self, dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, dtype: torch.dtype = torch.bfloat16, keep=()):
         self._dtype = dtype
+        self._keep = frozenset(keep)
+        assert self._keep <= set(ROUND_SITES), self._keep - set(ROUND_SITES)
 
     def __enter__(self):
-        global _ROUND, _ROUND_DTYPE
-        self._old, _ROUND = (_ROUND, _ROUND_DTYPE), True
-        _ROUND_DTYPE = self._dtype
+        global _ROUND, _ROUND_DTYPE, _ROUND_KEEP
+        self._old, _ROUND = (_ROUND, _ROUND_DTYPE, _ROUND_KEEP), True
+        _ROUND_DTYPE, _ROUND_KEEP = self._dtype, self._keep
         return self
 
     def __exit__(self, *exc):
-        global _ROUND, _ROUND_DTYPE
-        _ROUND, _ROUND_DTYPE = self._old
+        global _ROUND, _ROUND_DTYPE, _ROUND_KEEP
+        _ROUND, _ROUND_DTYPE, _ROUND_KEEP = self._old
         return False
 
 
-def _q(x: torch.Tensor) -> torch.Tensor:
+def _q(x: torch.Tensor, site: str = "") -> torch.Tensor:
     """Round to the storage type (nearest-even) and back when the same-dtype mode is on; identity otherwise."""
-    return x.to(_ROUND_DTYPE).float() if _ROUND else x
+    return x.to(_ROUND_DTYPE).float() if _ROUND and site not in _ROUND_KEEP else x
 
 
 def _tw(w: Dict, k: str) -> torch.Tensor:
     """A GEMM weight (kept in bf16 by the HIP path)."""
-    return _q(_t(w, k))
+    return _q(_t(w, k), "weights")
 
 
 # --------------------------------------------------------------------------------------------
@@ -140,7 +148,7 @@ def quick_gelu(x: torch.Tensor) -> torch.Tensor:
 def clip_embeddings(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, prefix: str = "") -> torch.Tensor:
     """hf:clip/modeling_clip.py:203-218.  pixels [F,3,H,W] -> [F, 1+P, D]."""
     pw = _tw(w, prefix + "embeddings.patch_embedding.weight")
-    x = F.conv2d(_q(pixels.float()), pw, bias=None, stride=cfg.patch)      # [F, D, g, g]
+    x = F.conv2d(_q(pixels.float(), "vit.pixels"), pw, bias=None, stride=cfg.patch)      # [F, D, g, g]
     x = x.flatten(2).transpose(1, 2)                                        # [F, P, D]
     cls = _t(w, prefix + "embeddings.class_embedding").expand(x.shape[0], 1, -1)
     x = torch.cat([cls, x], dim=1)
@@ -151,26 +159,26 @@ def clip_attention(x: torch.Tensor, w: Dict, p: str, heads: int) -> torch.Tensor
     """hf:clip/modeling_clip.py:302-334 with eager_attention_forward :258-277 (no mask)."""
     Fn, N, D = x.shape
     hd = D // heads
-    q = _q(F.linear(x, _tw(w, p + "q_proj.weight"), _t(w, p + "q_proj.bias"))).view(Fn, N, heads, hd).transpose(1, 2)
-    k = _q(F.linear(x, _tw(w, p + "k_proj.weight"), _t(w, p + "k_proj.bias"))).view(Fn, N, heads, hd).transpose(1, 2)
-    v = _q(F.linear(x, _tw(w, p + "v_proj.weight"), _t(w, p + "v_proj.bias"))).view(Fn, N, heads, hd).transpose(1, 2)
+    q = _q(F.linear(x, _tw(w, p + "q_proj.weight"), _t(w, p + "q_proj.bias")), "vit.qkv").view(Fn, N, heads, hd).transpose(1, 2)
+    k = _q(F.linear(x, _tw(w, p + "k_proj.weight"), _t(w, p + "k_proj.bias")), "vit.qkv").view(Fn, N, heads, hd).transpose(1, 2)
+    v = _q(F.linear(x, _tw(w, p + "v_proj.weight"), _t(w, p + "v_proj.bias")), "vit.qkv").view(Fn, N, heads, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)
-    a = _q(torch.softmax(s, dim=-1, dtype=torch.float32))
-    o = _q(torch.matmul(a, v).transpose(1, 2).reshape(Fn, N, D))
-    return _q(F.linear(o, _tw(w, p + "out_proj.weight"), _t(w, p + "out_proj.bias")))
+    a = _q(torch.softmax(s, dim=-1, dtype=torch.float32), "vit.probs")
+    o = _q(torch.matmul(a, v).transpose(1, 2).reshape(Fn, N, D), "vit.attn_out")
+    return _q(F.linear(o, _tw(w, p + "out_proj.weight"), _t(w, p + "out_proj.bias")), "vit.o_out")
 
 
 def clip_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
     """hf:clip/modeling_clip.py:338-350: fc2(quick_gelu(fc1(x))); p ends in 'mlp.'."""
     h = F.linear(h, _tw(w, p + "fc1.weight"), _t(w, p + "fc1.bias"))
-    return _q(F.linear(_q(quick_gelu(h)), _tw(w, p + "fc2.weight"), _t(w, p + "fc2.bias")))
+    return _q(F.linear(_q(quick_gelu(h), "vit.gelu"), _tw(w, p + "fc2.weight"), _t(w, p + "fc2.bias")), "vit.fc2_out")
 
 
 def clip_layer(x: torch.Tensor, w: Dict, p: str, cfg: VisionCfg) -> torch.Tensor:
     """hf:clip/modeling_clip.py:353-383 (pre-LN encoder layer)."""
-    h = _q(F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm1.weight"), _t(w, p + "layer_norm1.bias"), cfg.eps))
+    h = _q(F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm1.weight"), _t(w, p + "layer_norm1.bias"), cfg.eps), "vit.ln")
     x = x + clip_attention(h, w, p + "self_attn.", cfg.heads)
-    h = _q(F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm2.weight"), _t(w, p + "layer_norm2.bias"), cfg.eps))
+    h = _q(F.layer_norm(x, (cfg.hidden,), _t(w, p + "layer_norm2.weight"), _t(w, p + "layer_norm2.bias"), cfg.eps), "vit.ln")
     return x + clip_mlp(h, w, p + "mlp.")
 
 
@@ -201,7 +209,7 @@ def vit_select(pixels: torch.Tensor, w: Dict, cfg: VisionCfg, select_layer: int 
 # --------------------------------------------------------------------------------------------
 def mm_project(feats: torch.Tensor, w: Dict) -> torch.Tensor:
     """valley_model.py:54-55,190: Linear(mm_hidden -> H) + bias on every token."""
-    return F.linear(_q(feats), _tw(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias"))
+    return F.linear(_q(feats, "proj.in"), _tw(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias"))
 
 
 def sinusoid_position_matrix(seq_len: int, d: int, n: float = 10000.0) -> torch.Tensor:
@@ -354,39 +362,39 @@ def llama_attention_block(h: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, 
     softmax(QK^T * hd^-0.5 + mask) V in fp32, o_proj.  h [B,S,H] is the NORMED hidden state; p ends in 'self_attn.'."""
     B, S, H = h.shape
     hd = H // cfg.heads
-    q = _q(F.linear(h, _tw(w, p + "q_proj.weight"))).view(B, S, cfg.heads, hd).transpose(1, 2)
-    k = _q(F.linear(h, _tw(w, p + "k_proj.weight"))).view(B, S, cfg.heads, hd).transpose(1, 2)
-    v = _q(F.linear(h, _tw(w, p + "v_proj.weight"))).view(B, S, cfg.heads, hd).transpose(1, 2)
-    q = _q(apply_rope(q, cos, sin))
-    k = _q(apply_rope(k, cos, sin))
+    q = _q(F.linear(h, _tw(w, p + "q_proj.weight")), "ll.qkv").view(B, S, cfg.heads, hd).transpose(1, 2)
+    k = _q(F.linear(h, _tw(w, p + "k_proj.weight")), "ll.qkv").view(B, S, cfg.heads, hd).transpose(1, 2)
+    v = _q(F.linear(h, _tw(w, p + "v_proj.weight")), "ll.qkv").view(B, S, cfg.heads, hd).transpose(1, 2)
+    q = _q(apply_rope(q, cos, sin), "ll.rope")
+    k = _q(apply_rope(k, cos, sin), "ll.rope")
     if past is not None:
         k = torch.cat([past[0], k], dim=2)
         v = torch.cat([past[1], v], dim=2)
     s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5) + mask
-    a = _q(torch.softmax(s, dim=-1, dtype=torch.float32))
+    a = _q(torch.softmax(s, dim=-1, dtype=torch.float32), "ll.probs")
     if attn_out is not None:                                 # HF's ``output_attentions``: the probabilities [B, heads, S, kv_len]
         attn_out.append(a)
-    o = _q(torch.matmul(a, v).transpose(1, 2).reshape(B, S, H))
+    o = _q(torch.matmul(a, v).transpose(1, 2).reshape(B, S, H), "ll.attn_out")
     out = F.linear(o, _tw(w, p + "o_proj.weight"))
     # prefill hands the projection to the residual add as a bf16 tensor; the <= 8-row decode step adds in the GEMV epilogue
-    return (_q(out) if B * S > 8 else out), (k, v)
+    return (_q(out, "ll.o_out") if B * S > 8 else out), (k, v)
 
 
 def llama_mlp(h: torch.Tensor, w: Dict, p: str) -> torch.Tensor:
     """hf:llama/modeling_llama.py:160-173: down(silu(gate(x)) * up(x)); p ends in 'mlp.'."""
     g = F.linear(h, _tw(w, p + "gate_proj.weight"))
     u = F.linear(h, _tw(w, p + "up_proj.weight"))
-    out = F.linear(_q(F.silu(g) * u), _tw(w, p + "down_proj.weight"))
-    return _q(out) if h.shape[0] * h.shape[1] > 8 else out
+    out = F.linear(_q(F.silu(g) * u, "ll.swiglu"), _tw(w, p + "down_proj.weight"))
+    return _q(out, "ll.down_out") if h.shape[0] * h.shape[1] > 8 else out
 
 
 def llama_layer(x: torch.Tensor, w: Dict, p: str, cfg: LlamaCfg, cos, sin, mask,
                 past: Optional[Tuple[torch.Tensor, torch.Tensor]], attn_out: Optional[list] = None):
     """hf:llama/modeling_llama.py:292-332 (pre-norm decoder layer)."""
-    h = _q(rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps))
+    h = _q(rms_norm(x, _t(w, p + "input_layernorm.weight"), cfg.eps), "ll.ln")
     o, kv = llama_attention_block(h, w, p + "self_attn.", cfg, cos, sin, mask, past, attn_out)
     x = x + o
-    h = _q(rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps))
+    h = _q(rms_norm(x, _t(w, p + "post_attention_layernorm.weight"), cfg.eps), "ll.ln")
     return x + llama_mlp(h, w, p + "mlp."), kv
 
 
@@ -408,7 +416,7 @@ def llama_forward(inputs_embeds: torch.Tensor, w: Dict, cfg: LlamaCfg,
     for i in range(L):
         x, kv = llama_layer(x, w, f"model.layers.{i}.", cfg, cos, sin, mask, None if past is None else past[i], attn_out)
         new_past.append(kv)
-    return _q(rms_norm(x, _t(w, "model.norm.weight"), cfg.eps)), new_past
+    return _q(rms_norm(x, _t(w, "model.norm.weight"), cfg.eps), "ll.final_norm"), new_past
 
 
 # --------------------------------------------------------------------------------------------
@@ -428,11 +436,11 @@ def valley_forward(input_ids: torch.Tensor, images, w: Dict, vw: Dict, lcfg: Lla
             pooled = []
             for f in raw:
                 if method == "mean":
-                    rows = _q(torch.cat([f[:, 1:].mean(0), f[:, 0]], 0))
-                    rows = _q(F.linear(rows, _tw(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias")))
+                    rows = _q(torch.cat([f[:, 1:].mean(0), f[:, 0]], 0), "proj.in")
+                    rows = _q(F.linear(rows, _tw(w, "model.mm_projector.weight"), _t(w, "model.mm_projector.bias")), "proj.rows")
                 else:
                     pr = mm_project(f, w)
-                    rows = _q(torch.cat([pr[:, 1:].max(0)[0], pr[:, 0]], 0))
+                    rows = _q(torch.cat([pr[:, 1:].max(0)[0], pr[:, 0]], 0), "proj.rows")
                 pooled.append((rows[:f.shape[1] - 1], rows[f.shape[1] - 1:]))
             emb = splice_visual_tokens(input_ids, emb, [mm_project(f, w) for f in raw], tok, method, w, pooled=pooled)
         else:

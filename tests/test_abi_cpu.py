@@ -10,9 +10,16 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
+def header_symbols(experimental: bool = False):
+    """The entry points include/valley_hip.h declares: its default section (what the two shipped libraries export), or — with
+    ``experimental`` — only the prototypes inside ``#ifdef VLY_EXPERIMENTAL`` blocks (libvalley_hip_exp.so adds those)."""
     txt = open(os.path.join(ROOT, "include", "valley_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    blocks = re.findall(r"#ifdef VLY_EXPERIMENTAL(.*?)#endif", txt, flags=re.S)
+    if experimental:
+        txt = "\n".join(blocks)
+    else:
+        txt = re.sub(r"#ifdef VLY_EXPERIMENTAL.*?#endif", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(vly_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -26,6 +33,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), n
     assert sorted(lib.EXPORTS) == names            # the ctypes binding covers exactly the header
     assert handle.vly_abi_version() == lib.ABI_VERSION
+
+
+def test_exported_symbols_are_exactly_the_header(tmp_path):
+    """`nm -D` of the two shipped libraries = the header's default section = the ctypes binding (the libraries carry only
+    what a default path calls); the experimental library adds exactly the header's EXPERIMENTAL prototypes."""
+    import subprocess
+    from valley_amd import build, lib
+    build.build(verbose=False)
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(ln.split()[-1] for ln in out.splitlines() if re.search(r" T vly_[a-z0-9_]+$", ln))
+
+    names, exp_names = header_symbols(), header_symbols(experimental=True)
+    assert exported(build.LIB) == names == exported(build.LIB_F16)
+    assert len(names) <= 50, len(names)
+    assert sorted(lib._SIGS_EXPERIMENTAL) == exp_names
+    assert exported(build.LIB_EXP) == sorted(names + exp_names)
 
 
 def test_fp16_library_exports_the_same_abi():

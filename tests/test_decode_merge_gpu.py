@@ -10,6 +10,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from valley_amd import lib as _vlib  # noqa: E402
+
+if not _vlib.EXPERIMENTAL:
+    # round 3's form (vly_decode_attention_split + vly_gemv_attnmerge_bf16) is the experimental library's: this module runs in the child
+    # process tests/test_experimental_gpu.py starts with VALLEY_EXPERIMENTAL=1
+    pytest.skip("round-3 split / merge form: experimental library only (tests/test_experimental_gpu.py runs this module)", allow_module_level=True)
+
 from tests.test_scale_gpu import SHAPES, _llama  # noqa: E402
 
 

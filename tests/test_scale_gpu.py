@@ -335,7 +335,7 @@ def test_c4_replicated_prefill_64_sequences_vs_oracle(monkeypatch):
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = []
     for ver in ("2", "1"):                                           # the env switch is read once per process: two children
-        env = dict(os.environ, VLY_LLAMA_ATTN=ver)
+        env = dict(os.environ, VLY_LLAMA_ATTN=ver, VALLEY_EXPERIMENTAL="1")     # (the register-staged witness kernel: experimental library)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("SUM")][-1])

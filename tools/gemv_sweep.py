@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GEMV (decode projection) rates on cold weights: rotates over enough weight copies to exceed the 256 MB
-Infinity Cache.  gemv_sweep.py "N,K,epi,f32res;..."  -> one JSON line per shape (TB/s of weight bytes)."""
+Infinity Cache.  gemv_sweep.py "N,K,epi,f32res;..." [M]  -> one JSON line per shape (TB/s of weight bytes); M rows (default 1)."""
 import json
 import os
 import sys
@@ -11,14 +11,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from valley_amd import ops  # noqa: E402
 
 d = torch.device("cuda:0")
+MROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 for spec in sys.argv[1].split(";"):
     N, K, epi, f32res = (int(x) for x in spec.split(","))
     ncopy = max(2, int(600e6 // (N * K * 2)) + 1)
     ws = [(torch.randn((N, K), device=d) * 0.02).to(torch.bfloat16) for _ in range(ncopy)]
-    a = torch.randn((1, K), device=d).to(torch.bfloat16)
+    a = torch.randn((MROWS, K), device=d).to(torch.bfloat16)
     No = N // 2 if epi == 2 else N
-    res = torch.zeros((1, N), device=d) if f32res else None
-    out = res if f32res else torch.empty((1, No), device=d, dtype=torch.bfloat16)
+    res = torch.zeros((MROWS, N), device=d) if f32res else None
+    out = res if f32res else torch.empty((MROWS, No), device=d, dtype=torch.bfloat16)
     for w in ws:
         ops.gemv(a, w, residual=res, epilogue=epi, out=out, out_dtype=out.dtype)
     torch.cuda.synchronize()
@@ -40,5 +41,5 @@ for spec in sys.argv[1].split(";"):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * ncopy)
-    print(json.dumps({"N": N, "K": K, "epi": epi, "f32res": f32res, "us": round(us, 2),
+    print(json.dumps({"M": MROWS, "N": N, "K": K, "epi": epi, "f32res": f32res, "us": round(us, 2),
                       "TBps": round(N * K * 2 / us / 1e6, 2), "copies": ncopy}), flush=True)

@@ -11,6 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvalley_hip.so")
 LIB_F16 = os.path.join(LIBDIR, "libvalley_hip_f16.so")      # the same sources with -DVLY_FP16=1 (IEEE fp16 storage)
+# the bf16 library plus the EXPERIMENTAL entry points and kernels (include/valley_hip.h's last section): only the units below are
+# compiled again, with -DVLY_EXPERIMENTAL=1; no default path loads it (VALLEY_EXPERIMENTAL=1 does; tests/test_experimental_gpu.py)
+LIB_EXP = os.path.join(LIBDIR, "libvalley_hip_exp.so")
+EXP_UNITS = ["decode_step.hip", "attention.hip", "gemm_bf16.hip", "gemv_bf16.hip"]
 SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip", "decode_step.hip"]
 
 
@@ -23,7 +27,7 @@ def hipcc() -> str:
 
 def needs_build() -> bool:
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "valley_hip.h")]
-    for lib in (LIB, LIB_F16):
+    for lib in (LIB, LIB_F16, LIB_EXP):
         if not os.path.exists(lib):
             return True
         t = os.path.getmtime(lib)
@@ -33,16 +37,25 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Both libraries (bf16 and fp16 storage), every translation unit compiled in parallel."""
+    """The two shipped libraries (bf16 and fp16 storage) and the experimental one, every stale translation unit compiled in parallel."""
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(os.path.join(LIBDIR, "f16"), exist_ok=True)
+    os.makedirs(os.path.join(LIBDIR, "exp"), exist_ok=True)
     if not force and not needs_build():
         return LIB
-    variants = [(LIB, LIBDIR, []), (LIB_F16, os.path.join(LIBDIR, "f16"), ["-DVLY_FP16=1"])]
+    variants = [(LIB, LIBDIR, [], SOURCES), (LIB_F16, os.path.join(LIBDIR, "f16"), ["-DVLY_FP16=1"], SOURCES),
+                (LIB_EXP, os.path.join(LIBDIR, "exp"), ["-DVLY_EXPERIMENTAL=1"], EXP_UNITS)]
     procs = []
-    for lib, odir, flags in variants:
-        for s in SOURCES:
+    # a translation unit is recompiled when its own source, a shared header (*.hpp, *.inc, valley_hip.h) or this recipe is newer than
+    # its object — editing one kernel file costs one compile per library, not twenty-two
+    shared = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip")] + \
+             [os.path.join(HERE, "..", "include", "valley_hip.h"), os.path.abspath(__file__)]
+    t_shared = max(os.path.getmtime(d) for d in shared)
+    for lib, odir, flags, units in variants:
+        for s in units:
             o = os.path.join(odir, s.replace(".hip", ".o"))
+            if not force and os.path.exists(o) and os.path.getmtime(o) >= max(t_shared, os.path.getmtime(os.path.join(CSRC, s))):
+                continue
             cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -53,8 +66,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    for lib, odir, _ in variants:
-        objs = [os.path.join(odir, s.replace(".hip", ".o")) for s in SOURCES]
+    for lib, odir, _, units in variants:
+        objs = [os.path.join(odir if s in units else LIBDIR, s.replace(".hip", ".o")) for s in SOURCES]
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

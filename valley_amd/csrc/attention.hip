@@ -939,9 +939,15 @@ __global__ void __launch_bounds__(256) attn_probs_kernel(const T* __restrict__ q
     for (int j = tid; j < kv_len; j += 256) o[j] = pr_sc[j] * inv;
 }
 
-// the two kernels that are NOT the default of their op (kept for A/B runs and as each other's bit-identity witness:
-// VLY_VIT_ATTN=4 -> vit_attn4_kernel, VLY_LLAMA_ATTN=1 -> llama_attn_kernel)
+// the two kernels that are NOT the default of their op (A/B runs and each other's bit-identity witness: VLY_VIT_ATTN=4 ->
+// vit_attn4_kernel, VLY_LLAMA_ATTN=1 -> llama_attn_kernel) live in the EXPERIMENTAL library only (libvalley_hip_exp.so,
+// -DVLY_EXPERIMENTAL=1, valley_amd/build.py): the shipped libraries carry one kernel per op
+#ifndef VLY_EXPERIMENTAL
+#define VLY_EXPERIMENTAL 0
+#endif
+#if VLY_EXPERIMENTAL
 #include "attention_ab.inc"
+#endif
 
 }  // namespace
 
@@ -949,6 +955,7 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
     // (out: the kernels store 16 bytes per lane since round 3)
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) { vly_set_error("vly_vit_attention: bad args F=%d (qkv and out 16-byte aligned)", F); return -22; }
     // VLY_VIT_ATTN=4 launches vit_attn4_kernel (persistent, LDS-DMA staged; measured 2 % faster at >= 128 frames, equal at 32)
+#if VLY_EXPERIMENTAL
     static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 1;
     if (ver == 4) {
         static const int cus = [] {
@@ -960,7 +967,10 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
         const int nheads = F * 16;
         hipLaunchKernelGGL(vit_attn4_kernel, dim3(nheads < cus ? nheads : cus), dim3(V4W * 64), 0, (hipStream_t)stream,
                            (const uint16_t*)qkv, (uint16_t*)out, nheads);
-    } else hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
+        return vly_check_launch("vly_vit_attention");
+    }
+#endif
+    hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
     return vly_check_launch("vly_vit_attention");
 }
 
@@ -984,17 +994,29 @@ extern "C" int vly_llama_attention(const void* qkv, const void* kcache, const vo
     }
     // llama_attn2_kernel (LDS-DMA tiles, two workgroups per CU: 59.3 -> 45.0 us per 13B layer at B = 8, S = 336; 77 -> 53 at S = 1024,
     // profiles/history/r03/r03_llama_attn2.txt).  VLY_LLAMA_ATTN=1 keeps the register-staged llama_attn_kernel (A/B runs and its tests).
+#if VLY_EXPERIMENTAL
     static const int ver = getenv("VLY_LLAMA_ATTN") ? atoi(getenv("VLY_LLAMA_ATTN")) : 2;
-    if (ver == 2 && (size_t)ctx_max * 256 < ((size_t)1 << 32)) {          // (per-head descriptors: no limit on the cache as a whole)
+#else
+    constexpr int ver = 2;
+#endif
+    if ((size_t)ctx_max * 256 >= ((size_t)1 << 32)) {
+        vly_set_error("vly_llama_attention: ctx_max %d exceeds the 4 GB a (batch, head) cache row may span", ctx_max);
+        return -22;
+    }
+    if (ver == 2) {                                                       // (per-head descriptors: no limit on the cache as a whole)
         hipLaunchKernelGGL(llama_attn2_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,
                            (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
                            S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
         return vly_check_launch("vly_llama_attention");
     }
+#if VLY_EXPERIMENTAL
     hipLaunchKernelGGL(llama_attn_kernel, dim3(heads, B, (S + 16 * LNW - 1) / (16 * LNW)), dim3(LNW * 64), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, (const uint16_t*)kcache, (const uint16_t*)vcache, key_valid, (uint16_t*)out,
                        S, heads, past_len, past_len_dev, key_valid_stride, ctx_max);
     return vly_check_launch("vly_llama_attention");
+#else
+    return -22;                                                           // (unreachable: ver == 2)
+#endif
 }
 
 extern "C" int vly_decode_attention(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
@@ -1034,6 +1056,7 @@ static int decode_split_launch(const char* name, const void* qkv, void* kcache, 
                                int heads, int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
                                void* merged, unsigned* arrivals, void* stream);
 
+#if VLY_EXPERIMENTAL      // round 3's form (partials merged in the o GEMV's prologue): the merged launch's bit-identity witness
 extern "C" int vly_decode_attention_split(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
                                           const uint8_t* key_valid, int key_valid_stride, float* partials, int B, int heads,
                                           int past_len, const int32_t* past_len_dev, int past_len_dev_stride, int ctx_max,
@@ -1041,6 +1064,7 @@ extern "C" int vly_decode_attention_split(const void* qkv, void* kcache, void* v
     return decode_split_launch("vly_decode_attention_split", qkv, kcache, vcache, cos_table, sin_table, key_valid, key_valid_stride,
                                partials, B, heads, past_len, past_len_dev, past_len_dev_stride, ctx_max, nullptr, nullptr, stream);
 }
+#endif
 
 extern "C" int vly_decode_attention_merged(const void* qkv, void* kcache, void* vcache, const float* cos_table, const float* sin_table,
                                            const uint8_t* key_valid, int key_valid_stride, float* partials, void* out,

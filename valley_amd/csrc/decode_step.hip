@@ -31,6 +31,12 @@
 // lane with s_sleep, every spin BOUNDED: a workgroup that gives up sets the abort word, everyone leaves at their next
 // barrier, and the host reads the word.  The sync words are zeroed ONCE by the caller and count on from launch to launch (every
 // launch passes the same number of barriers; see the kernel), and again by the caller after an abort.
+// EXPERIMENTAL: compiled into libvalley_hip_exp.so only (-DVLY_EXPERIMENTAL=1, valley_amd/build.py) — measured behind the five launches
+// it replaces, so the shipped libraries and include/valley_hip.h's default section do not carry it.
+#ifndef VLY_EXPERIMENTAL
+#define VLY_EXPERIMENTAL 0
+#endif
+#if VLY_EXPERIMENTAL
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -789,3 +795,5 @@ extern "C" int vly_decode_layers(const vly_decode_layer* layers_dev, int n_layer
     VLY_DL(2);
 #undef VLY_DL
 }
+
+#endif  // VLY_EXPERIMENTAL

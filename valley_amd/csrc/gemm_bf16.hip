@@ -137,6 +137,9 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 #ifndef VLY_P4_TIMING
 #define VLY_P4_TIMING 0
 #endif
+#ifndef VLY_EXPERIMENTAL
+#define VLY_EXPERIMENTAL 0          // 1: libvalley_hip_exp.so — also carries tile hint 297
+#endif
 
 // One phase of the 4-wave loop (PIPE 8): the MI x NI MFMAs of one 32-wide K step on fragments that are already in
 // registers, with up to three lists of other instructions (the NI + MI fragment reads of the NEXT step — W fragments
@@ -1921,8 +1924,14 @@ __attribute__((visibility("hidden"))) int valley_p4_streamk(int tile, const void
     int rc;
     // (256-row tiles, hint 297, round 4: the owner folds the chain's sum into its accumulators with f32 MFMAs before a plain
     // epilogue — with 256 accumulators per lane the epilogue has no 32 registers for slab terms; see the kernel)
-    if (tile == 297) rc = launch_p4<256, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
-    else if (tile == 298) rc = launch_p4<224, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
+    if (tile == 297) {
+#if VLY_EXPERIMENTAL
+        rc = launch_p4<256, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
+#else
+        vly_set_error("vly_gemm_bf16_streamk: tile 297 (split-K remainder on 256-row tiles: measured behind 197) is in libvalley_hip_exp.so only");
+        return -22;
+#endif
+    } else if (tile == 298) rc = launch_p4<224, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
     else rc = launch_p4<192, 256, true>(A, W, bias, R, C, M, N, K, lda, ldw, ldc, ldr, epi, out, st, nullptr, &sk);
     if (rc == 1) {
         vly_set_error("vly_gemm_bf16_streamk: tile %d needs 16-byte aligned rows of whole 8-column chunks and no residual for bf16 outputs", tile);

@@ -3,6 +3,7 @@
 // 16-byte loads (no LDS round trip — the operand is not shared between waves,
 // cdna_hip_programming §5 "GEMV / M <= 16"); the few activation rows stay L1/L2 resident.
 // Algorithmic bytes per launch = N*K*2 (weights) — activations and outputs are negligible.
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -161,6 +162,135 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
         return -22;
     }
 #undef VLY_GEMV
+    return vly_check_launch("vly_gemv_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5 <= M <= 16 rows (round 5): the same weight stream on the MATRIX cores.  gemv_kernel's dot products cost 16 VALU operations per row
+// and 16 bytes of weights — at eight rows (serving.ContinuousBatcher: eight live requests on one captured step) the step is VALU-
+// bound at 2.3x its batch-1 time although it streams the same bytes.  One MFMA 16x16x32 takes 16 weight rows x 32 k (1 KB: one 16-byte
+// load per lane, exactly the fragment the lane must supply) against 16 activation rows: 256 B/clk of weights per CU, far above what
+// HBM delivers (~15 B/clk/CU), whatever M is.
+//   * a workgroup owns 16 weight rows; its four waves take the 64-wide K pairs p = wave, wave + 4, ... (two MFMA steps = one whole
+//     128-byte line per row and wave) and meet in LDS at the end, summed in the fixed order wave 0 + 1 + 2 + 3;
+//   * two groups of two pairs in flight per wave (16 KB of weights requested ahead);
+//   * weights AND activations come through buffer descriptors that end with the last valid row: rows past N / M read as zero without
+//     a branch (no exec-masked loads: behind those hipcc waits vmcnt(0)), and the activation lanes past M cost no L1 traffic.
+// A row's result depends on that row and the weights only (every output element is its own MFMA accumulation chain in k order):
+// a request's tokens do not depend on what the other slots hold.
+// Measured at M = 8 on the 13B projections (profiles/r05/r05_gemv_rows.txt): 3.7-4.1 TB/s of weights on the wide shapes against 2.4-2.65
+// for the VALU kernel (13B step of eight requests 10.8 -> 9.0 ms), 6.6-6.8 at M = 1.  What keeps it from the M = 1 rate is the
+// fragment's shape: a 16-lane group of one load touches SIXTEEN rows (64 accesses of 16 bytes per instruction, ~16 B/clk per CU —
+// the same limit tools/probes/store_rate_cu.hip finds for the GEMM epilogue's stores); without the activation loads the stream
+// runs 4.6 TB/s, and the non-temporal hint costs 8 % here (each line is touched by two loads).  Up to four rows the VALU kernels
+// are faster (step of four requests 6.9 vs 7.3 ms): the dispatch starts at five.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int OUT>
+__global__ void __launch_bounds__(256) gemv_mfma_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
+                                                        int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int rows_w = min(16, N - n0);                               // valid weight rows of this block
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W) + (size_t)n0 * ldw, 0,
+                                                                         (uint32_t)(((size_t)(rows_w - 1) * ldw + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A), 0, (uint32_t)(((size_t)(M - 1) * lda + K) * 2),
+                                                                         0x00020000);
+    // lane (l15, g): 16 bytes at [row l15][k + 8 g]; a row past the end is pushed out of the descriptor's range (-> zeros, no traffic)
+    const uint32_t vw = l15 < rows_w ? (uint32_t)(l15 * ldw + g * 8) * 2u : 0x80000000u;
+    const uint32_t va = l15 < M ? (uint32_t)(l15 * lda + g * 8) * 2u : 0x80000000u;
+    auto ldw16 = [&](int k) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, vw, (uint32_t)k * 2u, 0)); };
+    auto lda16 = [&](int k) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA, va, (uint32_t)k * 2u, 0)); };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int P = K >> 6;                                             // 64-wide pairs of MFMA steps
+    struct Grp { bf16x8 w[4], a[4]; };                                // two pairs = four steps
+    auto load_grp = [&](Grp& q, int p) {                              // pairs p and p + 4 (both inside K: the caller checks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = (p + 4 * u) << 6;
+            q.w[2 * u] = ldw16(k);
+            q.w[2 * u + 1] = ldw16(k + 32);
+            q.a[2 * u] = lda16(k);
+            q.a[2 * u + 1] = lda16(k + 32);
+        }
+    };
+    auto mfma_grp = [&](const Grp& q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma16(q.w[u], q.a[u], acc);
+    };
+    int p = wave;
+    if (p + 4 < P) {
+        Grp q0, q1;
+        load_grp(q0, p);
+#pragma unroll 1
+        for (;;) {
+            const bool more1 = p + 12 < P;                            // a whole second group behind q0?
+            if (more1) load_grp(q1, p + 8);
+            mfma_grp(q0);
+            p += 8;
+            if (!more1) break;
+            const bool more0 = p + 12 < P;
+            if (more0) load_grp(q0, p + 8);
+            mfma_grp(q1);
+            p += 8;
+            if (!more0) break;
+        }
+    }
+    for (; p < P; p += 4) {                                           // the pairs that did not fill a group
+        const int k = p << 6;
+        const bf16x8 w0 = ldw16(k), w1 = ldw16(k + 32), a0 = lda16(k), a1 = lda16(k + 32);
+        acc = mfma16(w0, a0, acc);
+        acc = mfma16(w1, a1, acc);
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave) return;
+    acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];        // fixed order: wave 0 + 1 + 2 + 3
+    // lane (m = l15, g) holds C[m][n .. n + 3], n = n0 + 4 g
+    const int m = l15, n = n0 + 4 * g;
+    if (m >= M || n >= N) return;
+    f32x4 v = acc;
+    if (bias) v += *(const f32x4*)(bias + n);
+    if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
+    }
+    if constexpr (EPI == VLY_EPI_SWIGLU) {
+        float o0 = x_sigmoid(v[0], 1.f) * v[1], o1 = x_sigmoid(v[2], 1.f) * v[3];
+        asm volatile("" : "+v"(o0), "+v"(o1));                       // fp32 VALUES before the conversion (see gemv_kernel)
+        const size_t off = (size_t)m * ldc + (n >> 1);
+        if constexpr (OUT == VLY_OUT_BF16) *(uint32_t*)((uint16_t*)Cv + off) = (uint32_t)f2h(o0) | ((uint32_t)f2h(o1) << 16);
+        else *(float2*)((float*)Cv + off) = make_float2(o0, o1);
+    } else {
+        if (R) v += *(const f32x4*)(R + (size_t)m * ldr + n);
+        const size_t off = (size_t)m * ldc + n;
+        if constexpr (OUT == VLY_OUT_BF16) {
+            u32x2 pk;
+            pk[0] = (uint32_t)f2h(v[0]) | ((uint32_t)f2h(v[1]) << 16);
+            pk[1] = (uint32_t)f2h(v[2]) | ((uint32_t)f2h(v[3]) << 16);
+            *(u32x2*)((uint16_t*)Cv + off) = pk;
+        } else {
+            *(f32x4*)((float*)Cv + off) = v;
+        }
+    }
+}
+
+int launch_mfma_rows(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                     int ldr, int epi, int out, hipStream_t st) {
+    dim3 grid((N + 15) / 16), block(256);
+#define VLY_GEMV_M(E, O)                                                                                                          \
+    hipLaunchKernelGGL((gemv_mfma_kernel<E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, \
+                       ldc, ldr)
+    if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMV_M(VLY_EPI_NONE, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMV_M(VLY_EPI_NONE, VLY_OUT_F32);
+    else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMV_M(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
+    else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMV_M(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+    else {
+        vly_set_error("vly_gemv_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
+        return -22;
+    }
+#undef VLY_GEMV_M
     return vly_check_launch("vly_gemv_bf16");
 }
 
@@ -415,12 +545,26 @@ int launch_norm_mr(const float* H, const float* gamma, float eps, const void* W,
 
 extern "C" int vly_gemv_bf16(const void* A, const void* W, const float* bias, const float* residual, void* C, int M,
                              int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, void* stream) {
-    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 8 || lda % 8 || ldw % 8 || ldw <= 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||
+    if (M <= 0 || M > 16 || N <= 0 || K <= 0 || K % 8 || lda % 8 || ldw % 8 || ldw <= 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||
         (epilogue == VLY_EPI_SWIGLU && (N % 2 || residual))) {
-        vly_set_error("vly_gemv_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d", M, N, K, lda, ldw);
+        vly_set_error("vly_gemv_bf16: unsupported shape/alignment M=%d N=%d K=%d lda=%d ldw=%d (M <= 16)", M, N, K, lda, ldw);
         return -22;
     }
     hipStream_t st = (hipStream_t)stream;
+    // five rows and more: the matrix-core form (gemv_mfma_kernel), when its 16-byte / 8-byte vector accesses line up; VLY_GEMV_MFMA=0
+    // keeps the VALU kernels (A/B runs; M <= 8 only)
+    static const bool no_mfma = getenv("VLY_GEMV_MFMA") && atoi(getenv("VLY_GEMV_MFMA")) == 0;
+    const int No = epilogue == VLY_EPI_SWIGLU ? N / 2 : N;
+    const bool mfma_ok = K % 64 == 0 && N % 4 == 0 && ldc % 4 == 0 && (size_t)M * lda * 2 < (1ull << 31) && (size_t)16 * ldw * 2 < (1ull << 31) &&
+                         ((uintptr_t)C & (out_dtype == VLY_OUT_F32 ? 15 : (epilogue == VLY_EPI_SWIGLU ? 3 : 7))) == 0 &&
+                         (!bias || ((uintptr_t)bias & 15) == 0) && (!residual || (ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                         (epilogue != VLY_EPI_SWIGLU || (out_dtype == VLY_OUT_BF16 ? ldc % 2 == 0 : true)) && No > 0;
+    if (M >= 5 && mfma_ok && !(no_mfma && M <= 8))
+        return launch_mfma_rows(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
+    if (M > 8) {
+        vly_set_error("vly_gemv_bf16: 9 <= M <= 16 needs K %% 64 == 0, N %% 4 == 0 and 16-byte aligned rows (M=%d N=%d K=%d ldc=%d)", M, N, K, ldc);
+        return -22;
+    }
     if (M == 1) return launch_mr<1>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
     if (M == 2) return launch_mr<2>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
     if (M <= 4) return launch_mr<4>(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
@@ -450,6 +594,10 @@ extern "C" int vly_gemv_rmsnorm_bf16(const float* H, const float* gamma, float e
     return launch_norm_mr<2, 0>(H, gamma, eps, W, bias, residual, C, M, N, K, ldh, ldw, ldc, ldr, epilogue, out_dtype, st, "vly_gemv_rmsnorm_bf16");
 }
 
+#ifndef VLY_EXPERIMENTAL
+#define VLY_EXPERIMENTAL 0
+#endif
+#if VLY_EXPERIMENTAL      // round 3's o projection with the attention merge in its prologue (libvalley_hip_exp.so only)
 extern "C" int vly_gemv_attnmerge_bf16(const float* partials, const void* W, const float* bias, const float* residual, void* C, int M,
                                        int N, int heads, int ldw, int ldc, int ldr, int out_dtype, void* stream) {
     const int K = heads * 128;
@@ -463,3 +611,4 @@ extern "C" int vly_gemv_attnmerge_bf16(const float* partials, const void* W, con
     if (M == 1) return launch_norm_mr<1, 1>(partials, nullptr, 0.f, W, bias, residual, C, M, N, K, heads, ldw, ldc, ldr, VLY_EPI_NONE, out_dtype, st, "vly_gemv_attnmerge_bf16");
     return launch_norm_mr<2, 1>(partials, nullptr, 0.f, W, bias, residual, C, M, N, K, heads, ldw, ldc, ldr, VLY_EPI_NONE, out_dtype, st, "vly_gemv_attnmerge_bf16");
 }
+#endif

@@ -32,6 +32,7 @@ SPLIT_ATTN = os.environ.get("VALLEY_DECODE_SPLIT_ATTN", "1") != "0"       # flas
 PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "0") != "0"
 # round 4: where the split attention's partials are merged — "attn": by the last workgroup of a head inside the attention launch
 # (vly_decode_attention_merged; the o projection is then a plain GEMV), "oproj": in the o GEMV's prologue (round 3).  Same bits.
+# ("oproj" and the persistent step need the experimental library: VALLEY_EXPERIMENTAL=1, include/valley_hip.h's EXPERIMENTAL prototypes)
 MERGE_IN = os.environ.get("VALLEY_DECODE_MERGE", "attn")
 
 class DecodeSession:

@@ -49,13 +49,9 @@ _SIGS = {
     "vly_resize_v_norm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_incr_i32": (c_int, [_P, c_int, c_int, _P]),
     "vly_gemv_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "vly_decode_attention_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "vly_decode_attention_merged": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "vly_llama_attention_probs": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "vly_gemv_attnmerge_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemv_rmsnorm_bf16": (c_int, [_P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "vly_decode_layers_supported": (c_int, [c_int, c_int, c_int, c_int]),
-    "vly_decode_layers": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P]),
     "vly_decode_attention": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "vly_decode_attention_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_int, _P]),
     "vly_gemm_bf16_splitk2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -78,7 +74,15 @@ _SIGS = {
     "vly_embed_splice_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 5
+ABI_VERSION = 6
+# include/valley_hip.h "EXPERIMENTAL entry points": exported by libvalley_hip_exp.so only (VALLEY_EXPERIMENTAL=1); bound when present
+_SIGS_EXPERIMENTAL = {
+    "vly_decode_attention_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "vly_gemv_attnmerge_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vly_decode_layers_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "vly_decode_layers": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P]),
+}
+EXPERIMENTAL = os.environ.get("VALLEY_EXPERIMENTAL", "0") not in ("", "0")
 
 
 class ValleyHipError(RuntimeError):
@@ -88,7 +92,16 @@ class ValleyHipError(RuntimeError):
 def lib_path() -> str:
     """libvalley_hip.so (bf16 storage) or libvalley_hip_f16.so (VALLEY_PRECISION=fp16); VALLEY_HIP_LIB overrides."""
     from . import runtime
+    if EXPERIMENTAL and "VALLEY_HIP_LIB" not in os.environ:
+        if runtime.PRECISION == "fp16":
+            raise ValleyHipError("VALLEY_EXPERIMENTAL=1: the experimental library exists for bf16 storage only")
+        return _build.LIB_EXP
     return os.environ.get("VALLEY_HIP_LIB", _build.LIB_F16 if runtime.PRECISION == "fp16" else _build.LIB)
+
+
+def experimental() -> bool:
+    """True when the loaded library carries the experimental entry points (libvalley_hip_exp.so)."""
+    return hasattr(load(), "vly_decode_layers") and getattr(load(), "_vly_experimental", False)
 
 
 def load():
@@ -117,6 +130,15 @@ def _load_locked():
             raise ValleyHipError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    lib._vly_experimental = False
+    try:
+        for name, (res, args) in _SIGS_EXPERIMENTAL.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        lib._vly_experimental = True
+    except AttributeError:
+        pass
     if lib.vly_abi_version() != ABI_VERSION:
         raise ValleyHipError(f"ABI mismatch: library {lib.vly_abi_version()} vs binding {ABI_VERSION}")
     from . import runtime

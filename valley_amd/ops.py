@@ -317,7 +317,7 @@ def gemm_qkv_rope(a, w, qkv, rope: "RopeKV"):
 
 
 def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None):
-    """Weight-streaming kernel for M <= 8 rows (decode)."""
+    """Weight-streaming kernels for a few rows (decode): M <= 4 on the VALU, 5 <= M <= 16 on the matrix cores (gemv_mfma_kernel)."""
     out_dtype = runtime.HALF if out_dtype is None else out_dtype
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
@@ -419,7 +419,8 @@ def _flush_caches(device):
 
 
 CANDIDATES = [("tile", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 51, 53, 54, 55, 73, 74, 76, 83, 84, 86, 93, 94, 97, 98, 99, 197, 198, 199)] + \
-             [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186, 297, 298, 299)]
+             [("sk", t) for t in (51, 55, 73, 74, 76, 83, 84, 86, 151, 155, 183, 184, 186, 298, 299)] + \
+             ([("sk", 297)] if _lib.EXPERIMENTAL else [])    # (297: the experimental library's split-K remainder on 256-row tiles)
 TUNE_TRIALS = int(os.environ.get("VALLEY_TUNE_TRIALS", "3"))
 TUNE_FINALISTS = 4   # after TUNE_TRIALS calls per candidate the best few are re-timed to 3 x TUNE_TRIALS calls each
 _ONLINE = {}         # key -> {"cands": [...], "times": {cand: [ms]}, "pending": [(cand, e0, e1)]}
@@ -953,6 +954,12 @@ def decode_attention_rows(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch
 DECODE_SPLITS = 4          # VLY_DECODE_SPLITS
 
 
+def _need_experimental(what: str) -> None:
+    if not _lib.experimental():
+        raise _lib.ValleyHipError(f"{what} is exported by libvalley_hip_exp.so only: set VALLEY_EXPERIMENTAL=1 (include/valley_hip.h, "
+                                  "EXPERIMENTAL entry points)")
+
+
 def decode_partials(B: int, heads: int, device) -> torch.Tensor:
     """Workspace of decode_attention_split / gemv_attnmerge: fp32 [B, heads, DECODE_SPLITS, 132]."""
     return torch.empty((B, heads, DECODE_SPLITS, 132), dtype=torch.float32, device=device)
@@ -993,6 +1000,7 @@ def decode_attention_split(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torc
                                                      ctx_max, _stream())
         _lib.check(rc, "vly_decode_attention_merged")
         return out
+    _need_experimental("vly_decode_attention_split (round 3's form; the default merges inside the launch: pass out= and arrivals=)")
     rc = _lib.load().vly_decode_attention_split(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                                                 _ptr(key_valid), kv_stride, partials.data_ptr(), B, heads, past_len, _ptr(past_dev),
                                                 1 if per_row else 0, ctx_max, _stream())
@@ -1019,6 +1027,7 @@ def gemv_attnmerge(partials: torch.Tensor, w, bias=None, residual=None, out_dtyp
         _chk(residual, torch.float32, "residual", contiguous=False)
         assert tuple(residual.shape) == (B, N) and residual.stride(1) == 1
     od = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    _need_experimental("vly_gemv_attnmerge_bf16")
     rc = _lib.load().vly_gemv_attnmerge_bf16(partials.data_ptr(), wt.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), B, N, heads,
                                              ldw, out.stride(0), residual.stride(0) if residual is not None else 0, od, _stream())
     _lib.check(rc, "vly_gemv_attnmerge_bf16")
@@ -1031,6 +1040,8 @@ DECODE_SYNC_ABORT = 272    # VLY_DECODE_SYNC_ABORT
 
 def decode_layers_ok(B: int, H: int, heads: int, I: int) -> bool:
     """Shapes vly_decode_layers takes: B <= 2, heads * 128 == H, (H, I) of the 7B / 13B classes."""
+    if not _lib.experimental():                               # libvalley_hip_exp.so only (VALLEY_EXPERIMENTAL=1)
+        return False
     return bool(_lib.load().vly_decode_layers_supported(B, H, heads, I))
 
 

@@ -210,9 +210,14 @@ class ValleyLlamaModel:
             return self._encode_clips_locked(images)
 
     def _encode_clips_locked(self, images):
-        clips = list(images) if isinstance(images, (list, tuple)) else [images[b] for b in range(len(images))]
-        Ts = [int(c.shape[0]) for c in clips]
-        frames = torch.cat([c.to(self.device) for c in clips], 0) if len(clips) > 1 else clips[0].to(self.device)
+        if isinstance(images, torch.Tensor) and images.dim() == 5 and images.is_contiguous():
+            # [B, T, 3, 224, 224] (valley_model.py:179-184): the clips ARE one contiguous run of frames — a view, not a 38 MB copy
+            Ts = [int(images.shape[1])] * int(images.shape[0])
+            frames = images.to(self.device).view(-1, *images.shape[2:])
+        else:
+            clips = list(images) if isinstance(images, (list, tuple)) else [images[b] for b in range(len(images))]
+            Ts = [int(c.shape[0]) for c in clips]
+            frames = torch.cat([c.to(self.device) for c in clips], 0) if len(clips) > 1 else clips[0].to(self.device)
         sel = getattr(self.config, "mm_vision_select_layer", -1)
         feats = self.vision_tower.encode(frames, select_layer=sel)            # fp32 [F,257,1024]
         method = self.patch_pooling_method
