@@ -307,7 +307,7 @@ int vly_decode_attention_merged(const void *qkv_bf16, void *kcache_bf16, void *v
 
 /* Weight-streaming GEMV for decode (M <= 16 rows):  same contract as vly_gemm_bf16
  *   (epilogues, residual, out dtype) but HBM-bound by construction: every weight byte is read once.
- *   M <= 4: VALU dot products; 5 <= M <= 16: the same stream through MFMA 16x16x32 (sixteen weight rows x the M
+ *   M <= 2: VALU dot products; 3 <= M <= 16: the same stream through MFMA 16x16x32 (sixteen weight rows x the M
  *   activation rows per instruction) when K % 64 == 0, N % 4 == 0 and the rows are 16-byte aligned — the step of
  *   several concurrent requests (the reference's worker admits 5, serve/model_worker.py:467-474) then costs what one
  *   request's does.  Each output row depends on its own activation row only.  M > 8 needs the MFMA form.

@@ -166,7 +166,7 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
 }
 
 // ---------------------------------------------------------------------------------------------
-// 5 <= M <= 16 rows (round 5): the same weight stream on the MATRIX cores.  gemv_kernel's dot products cost 16 VALU operations per row
+// 3 <= M <= 16 rows (round 5): the same weight stream on the MATRIX cores.  gemv_kernel's dot products cost 16 VALU operations per row
 // and 16 bytes of weights — at eight rows (serving.ContinuousBatcher: eight live requests on one captured step) the step is VALU-
 // bound at 2.3x its batch-1 time although it streams the same bytes.  One MFMA 16x16x32 takes 16 weight rows x 32 k (1 KB: one 16-byte
 // load per lane, exactly the fragment the lane must supply) against 16 activation rows: 256 B/clk of weights per CU, far above what
@@ -179,12 +179,10 @@ int launch_mr(const void* A, const void* W, const float* bias, const float* R, v
 // A row's result depends on that row and the weights only (every output element is its own MFMA accumulation chain in k order):
 // a request's tokens do not depend on what the other slots hold.
 // Measured at M = 8 on the 13B projections (profiles/r05/r05_gemv_rows.txt): 3.7-4.1 TB/s of weights on the wide shapes against 2.4-2.65
-// for the VALU kernel (13B step of eight requests 10.8 -> 9.0 ms), 6.6-6.8 at M = 1.  What keeps it from the M = 1 rate is the
-// fragment's shape: a 16-lane group of one load touches SIXTEEN rows (64 accesses of 16 bytes per instruction, ~16 B/clk per CU —
-// the same limit tools/probes/store_rate_cu.hip finds for the GEMM epilogue's stores); without the activation loads the stream
-// runs 4.6 TB/s, and the non-temporal hint costs 8 % here (each line is touched by two loads).  Up to four rows the VALU kernels
-// are faster (step of four requests 6.9 vs 7.3 ms): the dispatch starts at five.
-// ---------------------------------------------------------------------------------------------
+// for the VALU kernel, 6.6-6.8 at M = 1.  What keeps THIS form from the M = 1 rate is the fragment's shape: a 16-lane group of one
+// load touches SIXTEEN rows (64 accesses of 16 bytes per instruction, ~16 B/clk per CU — the same limit tools/probes/store_rate_cu.hip
+// finds for the GEMM epilogue's stores); without the activation loads the stream runs 4.6 TB/s, and a non-temporal hint costs 8 %
+// (each line is touched by two loads).  It is kept as the A/B form (VLY_GEMV_MFMA=1); the default is gemv_mfma2_kernel below.
 template <int EPI, int OUT>
 __global__ void __launch_bounds__(256) gemv_mfma_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                         const float* __restrict__ bias, const float* __restrict__ R, void* __restrict__ Cv,
@@ -276,8 +274,130 @@ __global__ void __launch_bounds__(256) gemv_mfma_kernel(const uint16_t* __restri
     }
 }
 
+// ---- the same through an LDS ring (round 5, second form).  gemv_mfma_kernel loads every lane's MFMA fragment straight from global
+// memory: a 16-lane group of such a load touches sixteen rows, and the CU's load path then moves ~16 B/clk (3.7-4.1 TB/s of weights
+// chip-wide; tools/probes/store_rate_cu.hip measures the same cliff for stores).  Here the bytes travel as the M = 1 kernel's do —
+// whole 128-byte lines, eight rows per instruction — by LDS-DMA into a per-wave ring, and the fragment shape is produced by the
+// ds_read: every wave owns NSLOT slots of {16 weight rows x 128 B, 16 activation rows x 128 B} = one 64-wide K pair, keeps
+// NSLOT - 1 pairs in flight (counted vmcnt: LDS-DMA retires in issue order), and needs no barrier — producer and consumer of a slot
+// are the same wave.  Rows are stored with the chunk swizzle of the GEMM stages (chunk ^= row & 7, applied to the SOURCE address).
+// Measured (profiles/r05/r05_gemv_rows_v3.txt, M = 8): q|k|v 5.5, gate|up 5.5, lm_head 5.7 TB/s; o 3.5 and down 4.2 (320 row blocks
+// of 16 are five waves per CU: too few bytes in flight); the 13B step of eight live requests 10.8 (VALU) -> 9.0 (fragments from
+// global) -> 6.35 ms = 1259 tokens/s, 5.9x the single request's 214; three and four requests 6.3 / 6.9 -> 5.6 / 5.7 ms.
+template <int EPI, int OUT, int NW, bool BIGM>       // BIGM: 9 .. 16 activation rows (a second activation DMA per pair, 4 KB slots)
+__global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                             const float* __restrict__ bias, const float* __restrict__ R,
+                                                             void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
+    constexpr int NSLOT = BIGM ? 4 : 5, SLOT = BIGM ? 4096 : 3072;      // 64 / 60 KB of ring per 4-wave workgroup: two workgroups per CU
+    __shared__ __attribute__((aligned(16))) char ring[NW][NSLOT][SLOT];
+    __shared__ f32x4 red[NW - 1][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    // DMA source of this lane: row (lane >> 3) of an 8-row half, 16-byte chunk ((lane & 7) ^ (row & 7)); rows past the end re-read the last
+    const int r8 = lane >> 3, ch = (lane & 7) ^ (r8 & 7);            // (row + 8 has the same low three bits)
+    const uint16_t* w_lo = W + (size_t)min(n0 + r8, N - 1) * ldw + ch * 8;
+    const uint16_t* w_hi = W + (size_t)min(n0 + 8 + r8, N - 1) * ldw + ch * 8;
+    const uint16_t* a_lo = A + (size_t)min(r8, M - 1) * lda + ch * 8;
+    [[maybe_unused]] const uint16_t* a_hi = A + (size_t)min(8 + r8, M - 1) * lda + ch * 8;
+    constexpr bool two_a = BIGM;
+    char* my = &ring[wave][0][0];
+    // (asm, not the builtin: hipcc knows that the builtin writes LDS and waits vmcnt(0) in front of every ds_read that follows — the
+    // ring would hold one pair in flight; M0 = the LDS address of the instruction's 1 KB, the hardware adds lane * 16)
+    const uint32_t my_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)my);
+    auto dma = [&](const uint16_t* src, uint32_t dst) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    };
+    auto issue = [&](int p, int slot) {                              // pair p -> slot: 3 or 4 LDS-DMA instructions of 1 KB
+        const uint32_t d = my_lds + (uint32_t)slot * SLOT;
+        const int k = p << 6;
+        dma(w_lo + k, d);
+        dma(w_hi + k, d + 1024);
+        dma(a_lo + k, d + 2048);
+        if (two_a) dma(a_hi + k, d + 3072);
+    };
+    // fragment reads: row l15, chunk (4 step + g) ^ (l15 & 7)
+    const int rd0 = l15 * 128 + (((0 + g) ^ (l15 & 7)) << 4), rd1 = l15 * 128 + (((4 + g) ^ (l15 & 7)) << 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int P = K >> 6;
+    const int n = (P - wave + NW - 1) / NW;                          // pairs of this wave: p = wave + NW i
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i)
+        if (i < n) issue(wave + NW * i, i);
+    int slot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int ahead = i + NSLOT - 1;
+        if (ahead < n) {
+            issue(wave + NW * ahead, (slot + NSLOT - 1) % NSLOT);
+            // pair i has landed when at most the (NSLOT - 1) younger pairs' instructions are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NSLOT - 1) * (two_a ? 4 : 3)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail: nothing more to request
+        }
+        const char* s = my + slot * SLOT;
+        const bf16x8 w0 = *(const bf16x8*)(s + rd0), w1 = *(const bf16x8*)(s + rd1);
+        const bf16x8 a0 = *(const bf16x8*)(s + 2048 + rd0), a1 = *(const bf16x8*)(s + 2048 + rd1);
+        acc = mfma16(w0, a0, acc);
+        acc = mfma16(w1, a1, acc);
+        slot = (slot + 1) % NSLOT;
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave) return;
+#pragma unroll
+    for (int wv = 1; wv < NW; ++wv) acc += red[wv - 1][lane];        // fixed order: wave 0 + 1 + 2 + ...
+    const int m = l15, nn = n0 + 4 * g;
+    if (m >= M || nn >= N) return;
+    f32x4 v = acc;
+    if (bias) v += *(const f32x4*)(bias + nn);
+    if constexpr (EPI == VLY_EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x_sigmoid(v[r], 1.702f);
+    }
+    if constexpr (EPI == VLY_EPI_SWIGLU) {
+        float o0 = x_sigmoid(v[0], 1.f) * v[1], o1 = x_sigmoid(v[2], 1.f) * v[3];
+        asm volatile("" : "+v"(o0), "+v"(o1));
+        const size_t off = (size_t)m * ldc + (nn >> 1);
+        if constexpr (OUT == VLY_OUT_BF16) *(uint32_t*)((uint16_t*)Cv + off) = (uint32_t)f2h(o0) | ((uint32_t)f2h(o1) << 16);
+        else *(float2*)((float*)Cv + off) = make_float2(o0, o1);
+    } else {
+        if (R) v += *(const f32x4*)(R + (size_t)m * ldr + nn);
+        const size_t off = (size_t)m * ldc + nn;
+        if constexpr (OUT == VLY_OUT_BF16) {
+            u32x2 pk;
+            pk[0] = (uint32_t)f2h(v[0]) | ((uint32_t)f2h(v[1]) << 16);
+            pk[1] = (uint32_t)f2h(v[2]) | ((uint32_t)f2h(v[3]) << 16);
+            *(u32x2*)((uint16_t*)Cv + off) = pk;
+        } else {
+            *(f32x4*)((float*)Cv + off) = v;
+        }
+    }
+}
+
 int launch_mfma_rows(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                      int ldr, int epi, int out, hipStream_t st) {
+    // VLY_GEMV_MFMA: 2 (default) = the LDS-ring form, 1 = fragments straight from global memory (A/B runs)
+    static const int form = [] { const char* e = getenv("VLY_GEMV_MFMA"); return e ? atoi(e) : 2; }();
+    if (form != 1) {
+        dim3 g2((N + 15) / 16), b2(256);
+        // (eight waves per workgroup — one workgroup per CU — measured 3-5 % behind four on the narrow shapes: r05_gemv_rows_v2.txt)
+#define VLY_GEMV_M2(E, O)                                                                                                              \
+        do {                                                                                                                           \
+            if (M > 8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, true>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, \
+                                          lda, ldw, ldc, ldr);                                                                         \
+            else hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, false>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, lda, \
+                                    ldw, ldc, ldr);                                                                                    \
+        } while (0)
+        if (epi == VLY_EPI_NONE && out == VLY_OUT_BF16) VLY_GEMV_M2(VLY_EPI_NONE, VLY_OUT_BF16);
+        else if (epi == VLY_EPI_NONE && out == VLY_OUT_F32) VLY_GEMV_M2(VLY_EPI_NONE, VLY_OUT_F32);
+        else if (epi == VLY_EPI_QUICK_GELU && out == VLY_OUT_BF16) VLY_GEMV_M2(VLY_EPI_QUICK_GELU, VLY_OUT_BF16);
+        else if (epi == VLY_EPI_SWIGLU && out == VLY_OUT_BF16) VLY_GEMV_M2(VLY_EPI_SWIGLU, VLY_OUT_BF16);
+        else {
+            vly_set_error("vly_gemv_bf16: unsupported epilogue/out_dtype combination (%d,%d)", epi, out);
+            return -22;
+        }
+#undef VLY_GEMV_M2
+        return vly_check_launch("vly_gemv_bf16");
+    }
     dim3 grid((N + 15) / 16), block(256);
 #define VLY_GEMV_M(E, O)                                                                                                          \
     hipLaunchKernelGGL((gemv_mfma_kernel<E, O>), grid, block, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, lda, ldw, \
@@ -551,7 +671,7 @@ extern "C" int vly_gemv_bf16(const void* A, const void* W, const float* bias, co
         return -22;
     }
     hipStream_t st = (hipStream_t)stream;
-    // five rows and more: the matrix-core form (gemv_mfma_kernel), when its 16-byte / 8-byte vector accesses line up; VLY_GEMV_MFMA=0
+    // three rows and more: the matrix-core form (gemv_mfma_kernel), when its 16-byte / 8-byte vector accesses line up; VLY_GEMV_MFMA=0
     // keeps the VALU kernels (A/B runs; M <= 8 only)
     static const bool no_mfma = getenv("VLY_GEMV_MFMA") && atoi(getenv("VLY_GEMV_MFMA")) == 0;
     const int No = epilogue == VLY_EPI_SWIGLU ? N / 2 : N;
@@ -559,7 +679,8 @@ extern "C" int vly_gemv_bf16(const void* A, const void* W, const float* bias, co
                          ((uintptr_t)C & (out_dtype == VLY_OUT_F32 ? 15 : (epilogue == VLY_EPI_SWIGLU ? 3 : 7))) == 0 &&
                          (!bias || ((uintptr_t)bias & 15) == 0) && (!residual || (ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                          (epilogue != VLY_EPI_SWIGLU || (out_dtype == VLY_OUT_BF16 ? ldc % 2 == 0 : true)) && No > 0;
-    if (M >= 5 && mfma_ok && !(no_mfma && M <= 8))
+    static const int min_rows = [] { const char* e = getenv("VLY_GEMV_MFMA_MIN_ROWS"); return e ? atoi(e) : 3; }();      // (A/B runs)
+    if (M >= min_rows && M >= 3 && mfma_ok && !(no_mfma && M <= 8))
         return launch_mfma_rows(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st);
     if (M > 8) {
         vly_set_error("vly_gemv_bf16: 9 <= M <= 16 needs K %% 64 == 0, N %% 4 == 0 and 16-byte aligned rows (M=%d N=%d K=%d ldc=%d)", M, N, K, ldc);

@@ -317,7 +317,7 @@ def gemm_qkv_rope(a, w, qkv, rope: "RopeKV"):
 
 
 def gemv(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=None):
-    """Weight-streaming kernels for a few rows (decode): M <= 4 on the VALU, 5 <= M <= 16 on the matrix cores (gemv_mfma_kernel)."""
+    """Weight-streaming kernels for a few rows (decode): M <= 2 on the VALU, 3 <= M <= 16 on the matrix cores (LDS-ring form) (gemv_mfma_kernel)."""
     out_dtype = runtime.HALF if out_dtype is None else out_dtype
     return _gemm_common("vly_gemv_bf16", a, w, bias, residual, epilogue, out_dtype, out, ())
 
