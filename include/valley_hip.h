@@ -407,7 +407,7 @@ int vly_embed_splice_f32(const int32_t *row_map, const float *embed, const float
                          void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
- * EXPERIMENTAL entry points (these and the two #ifdef VLY_EXPERIMENTAL prototypes above): exported by libvalley_hip_exp.so only (the bf16 sources built with -DVLY_EXPERIMENTAL=1,
+ * EXPERIMENTAL entry points (these and the two #ifdef VLY_EXPERIMENTAL prototypes above): exported by libvalley_hip_exp.so / libvalley_hip_exp_f16.so only (the sources built with -DVLY_EXPERIMENTAL=1,
  * valley_amd/build.py; VALLEY_EXPERIMENTAL=1 makes the Python binding load it).  Built to parity and measured BEHIND the default
  * path they would replace, kept as tested experiments: no default path calls them, the shipped libraries
  * (libvalley_hip.so, libvalley_hip_f16.so) do not carry them.  That library also accepts tile hint 297 of

@@ -50,7 +50,7 @@ def test_exported_symbols_are_exactly_the_header(tmp_path):
     assert exported(build.LIB) == names == exported(build.LIB_F16)
     assert len(names) <= 50, len(names)
     assert sorted(lib._SIGS_EXPERIMENTAL) == exp_names
-    assert exported(build.LIB_EXP) == sorted(names + exp_names)
+    assert exported(build.LIB_EXP) == sorted(names + exp_names) == exported(build.LIB_EXP_F16)
 
 
 def test_fp16_library_exports_the_same_abi():

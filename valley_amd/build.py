@@ -14,6 +14,7 @@ LIB_F16 = os.path.join(LIBDIR, "libvalley_hip_f16.so")      # the same sources w
 # the bf16 library plus the EXPERIMENTAL entry points and kernels (include/valley_hip.h's last section): only the units below are
 # compiled again, with -DVLY_EXPERIMENTAL=1; no default path loads it (VALLEY_EXPERIMENTAL=1 does; tests/test_experimental_gpu.py)
 LIB_EXP = os.path.join(LIBDIR, "libvalley_hip_exp.so")
+LIB_EXP_F16 = os.path.join(LIBDIR, "libvalley_hip_exp_f16.so")   # the same on fp16 storage (the experiments' bit-identity tests run on both types)
 EXP_UNITS = ["decode_step.hip", "attention.hip", "gemm_bf16.hip", "gemv_bf16.hip"]
 SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip", "decode_step.hip"]
 
@@ -27,7 +28,7 @@ def hipcc() -> str:
 
 def needs_build() -> bool:
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "valley_hip.h")]
-    for lib in (LIB, LIB_F16, LIB_EXP):
+    for lib in (LIB, LIB_F16, LIB_EXP, LIB_EXP_F16):
         if not os.path.exists(lib):
             return True
         t = os.path.getmtime(lib)
@@ -41,10 +42,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(os.path.join(LIBDIR, "f16"), exist_ok=True)
     os.makedirs(os.path.join(LIBDIR, "exp"), exist_ok=True)
+    os.makedirs(os.path.join(LIBDIR, "exp_f16"), exist_ok=True)
     if not force and not needs_build():
         return LIB
     variants = [(LIB, LIBDIR, [], SOURCES), (LIB_F16, os.path.join(LIBDIR, "f16"), ["-DVLY_FP16=1"], SOURCES),
-                (LIB_EXP, os.path.join(LIBDIR, "exp"), ["-DVLY_EXPERIMENTAL=1"], EXP_UNITS)]
+                (LIB_EXP, os.path.join(LIBDIR, "exp"), ["-DVLY_EXPERIMENTAL=1"], EXP_UNITS),
+                (LIB_EXP_F16, os.path.join(LIBDIR, "exp_f16"), ["-DVLY_EXPERIMENTAL=1", "-DVLY_FP16=1"], EXP_UNITS)]
     procs = []
     # a translation unit is recompiled when its own source, a shared header (*.hpp, *.inc, valley_hip.h) or this recipe is newer than
     # its object — editing one kernel file costs one compile per library, not twenty-two
@@ -66,8 +69,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    for lib, odir, _, units in variants:
-        objs = [os.path.join(odir if s in units else LIBDIR, s.replace(".hip", ".o")) for s in SOURCES]
+    for lib, odir, _flags, units in variants:
+        base = os.path.join(LIBDIR, "f16") if "-DVLY_FP16=1" in _flags else LIBDIR      # the units a variant does not recompile
+        objs = [os.path.join(odir if s in units else base, s.replace(".hip", ".o")) for s in SOURCES]
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

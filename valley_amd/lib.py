@@ -93,9 +93,7 @@ def lib_path() -> str:
     """libvalley_hip.so (bf16 storage) or libvalley_hip_f16.so (VALLEY_PRECISION=fp16); VALLEY_HIP_LIB overrides."""
     from . import runtime
     if EXPERIMENTAL and "VALLEY_HIP_LIB" not in os.environ:
-        if runtime.PRECISION == "fp16":
-            raise ValleyHipError("VALLEY_EXPERIMENTAL=1: the experimental library exists for bf16 storage only")
-        return _build.LIB_EXP
+        return _build.LIB_EXP_F16 if runtime.PRECISION == "fp16" else _build.LIB_EXP
     return os.environ.get("VALLEY_HIP_LIB", _build.LIB_F16 if runtime.PRECISION == "fp16" else _build.LIB)
 
 
