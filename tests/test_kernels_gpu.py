@@ -140,6 +140,22 @@ def test_gemv(M):
         assert torch.equal(full[:M], ops.gemv(a.to(d), w.to(d), bias.to(d), out_dtype=torch.float32))
 
 
+@pytest.mark.parametrize("M,N,K", [(3, 64, 64), (8, 20, 128), (16, 1000, 192), (9, 48, 320), (4, 4096, 64 * 21)])
+def test_gemv_rows_short_and_ragged_k(M, N, K):
+    """The LDS-ring form at the edges of its K split: fewer K pairs than waves (K = 64: one pair, three idle waves), pair counts that
+    do not fill the ring (2, 3, 5) or a group (21), a last row block with 4 valid rows (N = 20), both slot layouts (M <= 8, M > 8)."""
+    from valley_amd import ops
+    d = dev()
+    a = rnd((M, K), 31, dtype=HALF).to(d)
+    w = rnd((N, K), 32, 0.05, dtype=HALF).to(d)
+    bias = rnd((N,), 33, 0.5).to(d)
+    base = a.float() @ w.float().t()
+    out = ops.gemv(a, w, bias, out_dtype=torch.float32)
+    assert maxabs(out.cpu(), (base + bias).cpu()) < 2e-3 * max(1.0, float(base.abs().max()))
+    o16 = ops.gemv(a, w)
+    assert relerr(o16, base) < 4e-3
+
+
 @pytest.mark.parametrize("N,K,epi", [(5120, 5120, 0), (27648, 5120, 2), (5120, 13824, 0), (4096, 11008, 0), (32008, 5120, 0)])
 def test_gemv_rows_on_the_matrix_cores_at_decode_shapes(N, K, epi):
     """The decode projections of the 13B / 7B models at eight live requests (K = 11008 = 172 pairs: the ragged tail of the K split;

@@ -54,7 +54,17 @@ def main():
                 if "scratch_" in code:
                     outside.append((j - i, code.strip()))
             j += 1
+        # the kernel descriptor must allocate every accumulation register the asm names (it does so only because of the clobber list
+        # at the kernel's entry): next_free_vgpr - accum_offset >= highest named register + 1
+        named = [int(x, 0) for ln in asm[i:j] for x in re.findall(r"\ba\[(?:\d+|0x[0-9a-f]+):(\d+|0x[0-9a-f]+)\]", ln.split(";")[0])]
+        desc = "\n".join(asm[j:j + 120])
+        nf = re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", desc)
+        ao = re.search(r"\.amdhsa_accum_offset\s+(\d+)", desc)
         lit = n_mfma > 0 and n_mfma_compiler == 0 and "v_mfma" not in "\n".join(c for _, c in outside)
+        if lit and named and nf and ao and int(nf.group(1)) - int(ao.group(1)) < max(named) + 1:
+            outside.append((0, f"descriptor allocates {int(nf.group(1)) - int(ao.group(1))} accumulation registers, the asm names a{max(named)}"))
+        if lit and not (nf and ao):
+            outside.append((0, "kernel descriptor not found behind the kernel"))
         if n_mfma_compiler:              # the compiler manages this kernel's accumulators (builtin MFMAs): not audited
             lit = False
         if lit:

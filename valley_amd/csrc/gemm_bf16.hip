@@ -111,14 +111,18 @@ constexpr int P8_BAR_GAP = 8;       // barrier A this many MFMAs (~140 clk, a ds
 constexpr int P8_RD2_START = 1;     // phase 2: reads of the next tile's K step 0 after MFMA 1, 3, 5, ...
 constexpr int P8_RD2_STRIDE = 2;
 constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MFMAs before its buffer_load
-// the persistent kernel's tile boundary (round 5; DESIGN.md §4 "the tile boundary"):
-//   VLY_P4_ZEROFREE  the first K step of a tile is issued with C = 0 — no 256 v_accvgpr_write per tile (+2.0..2.2 % on the K = 1024
-//                    shapes, profiles/r05/r05_boundary_ab_1.txt)
-//   VLY_P4_ROLL      the ROLLING epilogue: the finished tile's epilogue runs row by row INSIDE the next tile's first K tile (implies
-//                    ZEROFREE) — see `boundary` in gemm_p4_kernel
+// the persistent kernel's tile boundary (round 5; DESIGN.md §4.1 "the tile boundary").  The rolled instantiations — bf16 outputs, every
+// epilogue but the fused RoPE, no split-K — keep their accumulators BY NAME (mfma16_lit below) and issue a tile's first K step with
+// C = 0 (no 256 v_accvgpr_write per tile: +2.0..2.2 % on the K = 1024 shapes, profiles/r05/r05_boundary_ab_1_switches.txt); on top:
+//   VLY_P4_ROLL / VLY_P4_ROLL_MASK  the ROLLING epilogue: the finished tile's epilogue runs row by row INSIDE the next tile's first K
+//                    tile (`boundary` in gemm_p4_kernel), for the epilogues of the mask
+//   VLY_P4_LIT=0     accumulators as C++ values everywhere (the round-4 kernel; A/B builds)
 //   VLY_P4_DROPSTORE diagnostic: every store of the bf16 epilogue is issued out of range (dropped by the hardware)
+//   VLY_P4_TIMING    anatomy builds: s_memtime stamps at the seams of every tile (tools/p4_boundary_times.py)
 // (measured and removed: waiting for the loads in flight BEFORE the epilogue's first store so that the next K tile's counted wait
-//  does not also wait for the stores' acknowledgements — -0.7 .. +0.9 %, noise: the stores throttle the epilogue at their ISSUE)
+//  does not also wait for the stores' acknowledgements — -0.7 .. +0.9 %, noise: the stores throttle the epilogue at their ISSUE;
+//  the zero-free first step with the accumulators as loop-carried C++ values tied "+a" — +2 % until any restructuring of the loop
+//  made hipcc resolve a phi in arch VGPRs: 86 .. 446 spilled registers under three forms of pinning)
 #ifndef VLY_P4_ROLL
 #define VLY_P4_ROLL 1
 #endif
@@ -127,9 +131,6 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 #endif                              // (still with the accumulators by name and the zero-free first K step)
 #ifndef VLY_P4_LIT
 #define VLY_P4_LIT 1                // 0: accumulators as C++ values everywhere (the round-4 kernel)
-#endif
-#ifndef VLY_P4_ZEROFREE
-#define VLY_P4_ZEROFREE 1
 #endif
 #ifndef VLY_P4_DROPSTORE
 #define VLY_P4_DROPSTORE 0
@@ -148,22 +149,6 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 // does: ISA of the first version had nine ds_reads + lgkmcnt(0) ahead of the first MFMA of each phase).  One wave per
 // SIMD: nothing else hides a gap in this wave's MFMA stream.
 // f1(k), k < N1, goes after MFMA number S1 + k * D1 (row-major over the MI x NI MFMAs); f2 / f3 likewise
-// D = A . B + 0 into the accumulator block `c` (asm: the builtin with a zero C makes hipcc treat the block as a new value and move the
-// accumulators out of the accumulation registers; tied "+a", the block stays where the previous tile's MFMAs left it)
-VLY_DEVICE void mfma16_zero(f32x4& c, const bf16x8& a, const bf16x8& b) {
-#if VLY_FP16
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
-#endif
-}
-VLY_DEVICE void mfma16_acc(f32x4& c, const bf16x8& a, const bf16x8& b) {      // D = A . B + C, same pinning
-#if VLY_FP16
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#endif
-}
 // ---- accumulators by NAME (round 5, the rolled kernels).  Block b of a wave's tile IS a[4b : 4b + 3]: every MFMA and every read of
 // the accumulators is an asm statement that spells the registers out (the block number is an immediate operand, printed into the
 // register range), and no C++ value ever holds an accumulator.  hipcc allocates the accumulation registers only because of the one
@@ -199,8 +184,7 @@ VLY_DEVICE f32x4 acc_read_lit(int blk) {
         VLY_A8(8), VLY_A8(9), VLY_A8(10), VLY_A8(11), VLY_A8(12), VLY_A8(13), VLY_A8(14), VLY_A8(15), VLY_A8(16), VLY_A8(17), VLY_A8(18),   \
         VLY_A8(19), VLY_A8(20), VLY_A8(21), VLY_A8(22), VLY_A8(23), VLY_A8(24), "a250", "a251", "a252", "a253", "a254", "a255"
 
-// MODE: 0 = builtin accumulate into acc[][], 1 = asm with C = 0 and the block tied "+a" (ZEROFREE without ROLL), 2 / 3 = accumulators by
-// name: accumulate / C = 0
+// MODE: 0 = builtin accumulate into acc[][]; 2 / 3 = accumulators by name: accumulate / first K step of a tile (C = 0)
 template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, int N4, int S4, int D4, int MODE = 0,
           typename F1, typename F2, typename F3, typename F4, typename ACC>
 VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[NI], F1&& f1, F2&& f2, F3&& f3, F4&& f4) {
@@ -214,7 +198,6 @@ VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[N
         for (int j = 0; j < NI; ++j) {
             if constexpr (MODE == 3) mfma16_lit_zero(i * NI + j, wf[j], af[i]);
             else if constexpr (MODE == 2) mfma16_lit(i * NI + j, wf[j], af[i]);
-            else if constexpr (MODE == 1) mfma16_zero(acc[i][j], wf[j], af[i]);
             else acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
             const int t = i * NI + j;
             if (N1 > 0 && t >= S1 && (t - S1) % D1 == 0 && (t - S1) / D1 < N1) {
@@ -1154,30 +1137,12 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsC =
         __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (uint32_t)M * (uint32_t)ldc * (OUT == VLY_OUT_BF16 ? 2u : 4u), 0x00020000);
     int buf = 0;                                                     // buffer of the K tile being computed
-    // (clearing the accumulators = 256 v_accvgpr_write per tile.  Round 3: a peeled first K step with C = 0 as the MFMA's inline
-    // constant — builtin or asm with an "=a" result — makes hipcc keep the accumulators in arch VGPRs inside the K loop and spill
-    // 213 registers.  Round 5 (VLY_P4_ZEROFREE): the accumulators are ONE set of values carried through the persistent loop,
-    // cleared once per launch, and the first K step of a tile is the asm MFMA with C = 0 and its block tied "+a" — to the
-    // compiler an accumulation like any other.)
     constexpr bool LIT = VLY_P4_LIT != 0 && !SK && OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE;     // the accumulators by name (mfma16_lit)
     constexpr bool ROLL = VLY_P4_ROLL != 0 && LIT && ((VLY_P4_ROLL_MASK >> EPI) & 1) != 0;
     constexpr int NST_ = EPI == VLY_EPI_SWIGLU ? NI / 4 : NI / 2;    // 16-byte stores per fragment row of the bf16 epilogue
     static_assert(!ROLL || N1 + MI * NST_ <= 63, "vmcnt is a 6-bit count");
-    constexpr bool ZF = false;                                       // (the tied-operand form of the zero-free first step: spills since the lambdas moved; see LIT)
-    if constexpr (LIT) asm volatile("" ::: VLY_ALL_AGPRS);           // the kernel owns a0 .. a255
-    f32x4 acc[MI][NI];
-    if constexpr (ZF) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    auto pin_acc = [&]() {        // "the accumulators ARE in the accumulation registers": at every merge point of the loop-carried
-#pragma unroll                    // values (left alone, hipcc resolves the loop's phis in arch VGPRs and spills ~210 registers)
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) asm volatile("" : "+a"(acc[i][j]));
-    };
+    if constexpr (LIT) asm volatile("" ::: VLY_ALL_AGPRS);           // the kernel owns a0 .. a255 (this is what makes the descriptor allocate them)
+    f32x4 acc[MI][NI];                                               // (untouched, and optimised away, when LIT)
     bool wave_live = false;                                          // this wave's slab of the tile being computed lies inside the problem
     // first_c: the first K tile of a tile.  relaxed (ROLL): the first K tile after a boundary — the stream of vector-memory operations
     // is then [pieces of the K tile this barrier publishes] [the epilogue's stores] [N1 pieces], and vmcnt retires loads AND stores in
@@ -1190,7 +1155,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago
         if (wave_live)
-            phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE, LIT ? (FIRST ? 3 : 2) : (FIRST && ZF ? 1 : 0)>(
+            phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE, LIT ? (FIRST ? 3 : 2) : 0>(
                 acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
         else {
             __builtin_amdgcn_s_barrier();
@@ -1509,8 +1474,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     for (;;) {
         VLY_STAMP();                                                 // (stamps of the unrolled schedule: K loop | epilogue | K loop | ...)
         wave_live = __builtin_amdgcn_readfirstlane((cm0 + wm0 < M && cn0 + wn0 < N) ? 1 : 0) != 0;
-        if constexpr (ZF) pin_acc();
-        if constexpr (!ZF && !LIT) {
+        if constexpr (!LIT) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1521,7 +1485,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         {
             int kt = SK ? cc.k : 0;
             const int kend = SK ? cc.kend : nk;
-            if constexpr (ZF || LIT) {                               // (first K step with C = 0)
+            if constexpr (LIT) {                                     // (first K step with C = 0)
                 ktile(std::true_type{});
                 while (++kt < kend) ktile(std::false_type{});
             } else {
@@ -1635,7 +1599,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         if constexpr (SKT) sk_next(0, 0, NI);
         // ---- epilogue on registers; lane holds C[m][n .. n+3], m = .. + l15, n = .. + 4*g.  The next tile's first fragments
         // are NOT kept across it (they are re-read below): 64 more registers for the epilogue, one LDS round trip per tile
-        if constexpr (ZF) pin_acc();
         if (!(SK && contributor)) {
         if constexpr (OUT == VLY_OUT_BF16 && EPI == VLY_EPI_QKV_ROPE) {
             // RoPE + KV append on registers: a wave's 128 columns are ONE head (cn0 + wn0 is a multiple of 128),
@@ -1743,7 +1706,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             ct += G;
         }
         tile_origin(ct, cm0, cn0);
-        if constexpr (ZF) pin_acc();
         {   // K step 0 of the next tile's first K tile: it landed before the last barrier B (same buffer rotation)
             auto r0 = rd_step0(smem + buf * STAGE);
 #pragma unroll
