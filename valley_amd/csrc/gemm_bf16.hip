@@ -932,9 +932,13 @@ VLY_DEVICE void acc_read_pairs(const f32x4& a, f32x2& even, f32x2& odd) {
 //     the next tile's K tiles are landing in nor a barrier, and its stores are in flight while the next tile's MFMAs run;
 //   * past the last tile the load cursor re-requests the last K tile (valid addresses, free buffer): one code path, the
 //     vmcnt bookkeeping never changes, 128 KB of redundant L2 reads per workgroup and launch.
-// vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads return in order,
-// so an older load (the K tile this barrier publishes) cannot be outstanding unless the N1 younger ones are — whatever the
-// stores issued in between do; they only make the wait conservative.
+// vmcnt and the stores: before barrier B the wave waits for "at most N1 operations outstanding".  Loads AND stores retire
+// through vmcnt in issue order (tools/probes/vmcnt_store_order.hip, round 5), so the wait covers the K tile this barrier
+// publishes — and every store issued before its N1 youngest loads: the unrolled schedule waits for its epilogue's stores here,
+// the rolled one (round 5, `boundary`) issues the pieces first and counts the stores in.
+// Round 5: the instantiations with bf16 outputs (all epilogues but the fused RoPE, no split-K) hold their accumulators BY NAME
+// (mfma16_lit: a[4 b : 4 b + 3] spelled out in asm, no C++ accumulator values) — that is what allows the zero-free first K step
+// and the rolling epilogue; the others (fp32 outputs, RoPE, SK) keep the C++ accumulators and the round-4 schedule.
 // SK = true (tile hints 298 / 299 of vly_gemm_bf16_streamk, round 3): the same kernel with the REMAINDER ROUND split along K.
 // The tiles past the last whole round of G workgroups (G = CUs) would cost a whole round for a fraction of the chip; instead
 // each of them is cut into S equal K slices (S chosen by the host so that S x remainder fills whole rounds: 164 tiles x 3 =

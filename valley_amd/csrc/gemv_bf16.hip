@@ -282,24 +282,37 @@ __global__ void __launch_bounds__(256) gemv_mfma_kernel(const uint16_t* __restri
 // NSLOT - 1 pairs in flight (counted vmcnt: LDS-DMA retires in issue order), and needs no barrier — producer and consumer of a slot
 // are the same wave.  Rows are stored with the chunk swizzle of the GEMM stages (chunk ^= row & 7, applied to the SOURCE address).
 // Measured (profiles/r05/r05_gemv_rows_v3.txt, M = 8): q|k|v 5.5, gate|up 5.5, lm_head 5.7 TB/s; o 3.5 and down 4.2 (320 row blocks
-// of 16 are five waves per CU: too few bytes in flight); the 13B step of eight live requests 10.8 (VALU) -> 9.0 (fragments from
-// global) -> 6.35 ms = 1259 tokens/s, 5.9x the single request's 214; three and four requests 6.3 / 6.9 -> 5.6 / 5.7 ms.
-template <int EPI, int OUT, int NW, bool BIGM>       // BIGM: 9 .. 16 activation rows (a second activation DMA per pair, 4 KB slots)
+// of 16: see HALF8); the 13B step of eight live requests 10.8 (VALU) -> 9.0 (fragments from global) -> 6.35 -> 6.25 ms (HALF8) =
+// 1280 tokens/s, 6.0x the single request's 214; three and four requests 6.3 / 6.9 -> 5.6 / 5.7 ms.
+// HALF8 (M <= 8, narrow N): a workgroup owns EIGHT weight rows and the MFMA's sixteen rows are those eight rows at two K positions
+// (LDS rows 0-7: k in [128 p, 128 p + 64), rows 8-15: the same weight rows at [128 p + 64, 128 p + 128)), the sixteen activation
+// columns likewise the eight activation rows at the two positions: D[n][m] (n, m < 8) and D[n + 8][m + 8] are the two halves of
+// C[n][m]; the off-diagonal quadrants pair a K position with the other one and are dropped.  Half the MFMA work is wasted (it is
+// 20x over-provisioned here) and the row blocks are twice as many: o / down of the 13B decoder are 640 workgroups instead of 320.
+// Measured (M = 8): o 15.05 -> 14.4 us (3.48 -> 3.64 TB/s), down 34.4 -> 32.6 (4.11 -> 4.34); the 13B step of eight requests 6.35 ->
+// 6.25 ms.  The narrow shapes stay well under the wide ones' 5.5 TB/s whatever the block shape and ring depth: they are 9-24 us
+// kernels whose workgroups (two resident per CU) each pay their own first-byte latency and reduction tail.  Summation order differs
+// from the sixteen-row form (two K positions accumulate separately), so batch invariance holds inside M <= 8 and inside M > 8.
+template <int EPI, int OUT, int NW, bool BIGM, bool HALF8 = false>       // BIGM: 9 .. 16 activation rows (a second activation DMA per pair, 4 KB slots)
 __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                              const float* __restrict__ bias, const float* __restrict__ R,
                                                              void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
-    constexpr int NSLOT = BIGM ? 4 : 5, SLOT = BIGM ? 4096 : 3072;      // 64 / 60 KB of ring per 4-wave workgroup: two workgroups per CU
+    static_assert(!(BIGM && HALF8), "HALF8 is the M <= 8 form");
+    constexpr bool FOUR_K = BIGM || HALF8;                            // 4 KB slots: 16 LDS rows of weights + 16 of activations
+    constexpr int NSLOT = FOUR_K ? 4 : 5, SLOT = FOUR_K ? 4096 : 3072;  // 64 / 60 KB of ring per 4-wave workgroup: two workgroups per CU
+    // (HALF8 with 3 / 5 slots: 14.5 / 16.8 us against 14.4 on the 13B o projection — the ring's depth is not what bounds the narrow shapes)
+    constexpr int KSH = HALF8 ? 7 : 6;                                // a slot covers 128 (HALF8) or 64 k
     __shared__ __attribute__((aligned(16))) char ring[NW][NSLOT][SLOT];
-    __shared__ f32x4 red[NW - 1][64];
+    __shared__ f32x4 red[HALF8 ? NW : NW - 1][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * (HALF8 ? 8 : 16);
     // DMA source of this lane: row (lane >> 3) of an 8-row half, 16-byte chunk ((lane & 7) ^ (row & 7)); rows past the end re-read the last
     const int r8 = lane >> 3, ch = (lane & 7) ^ (r8 & 7);            // (row + 8 has the same low three bits)
     const uint16_t* w_lo = W + (size_t)min(n0 + r8, N - 1) * ldw + ch * 8;
-    const uint16_t* w_hi = W + (size_t)min(n0 + 8 + r8, N - 1) * ldw + ch * 8;
+    const uint16_t* w_hi = HALF8 ? w_lo + 64 : W + (size_t)min(n0 + 8 + r8, N - 1) * ldw + ch * 8;
     const uint16_t* a_lo = A + (size_t)min(r8, M - 1) * lda + ch * 8;
-    [[maybe_unused]] const uint16_t* a_hi = A + (size_t)min(8 + r8, M - 1) * lda + ch * 8;
-    constexpr bool two_a = BIGM;
+    [[maybe_unused]] const uint16_t* a_hi = HALF8 ? a_lo + 64 : A + (size_t)min(8 + r8, M - 1) * lda + ch * 8;
+    constexpr bool two_a = FOUR_K;
     char* my = &ring[wave][0][0];
     // (asm, not the builtin: hipcc knows that the builtin writes LDS and waits vmcnt(0) in front of every ds_read that follows — the
     // ring would hold one pair in flight; M0 = the LDS address of the instruction's 1 KB, the hardware adds lane * 16)
@@ -309,7 +322,7 @@ __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __r
     };
     auto issue = [&](int p, int slot) {                              // pair p -> slot: 3 or 4 LDS-DMA instructions of 1 KB
         const uint32_t d = my_lds + (uint32_t)slot * SLOT;
-        const int k = p << 6;
+        const int k = p << KSH;
         dma(w_lo + k, d);
         dma(w_hi + k, d + 1024);
         dma(a_lo + k, d + 2048);
@@ -318,7 +331,7 @@ __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __r
     // fragment reads: row l15, chunk (4 step + g) ^ (l15 & 7)
     const int rd0 = l15 * 128 + (((0 + g) ^ (l15 & 7)) << 4), rd1 = l15 * 128 + (((4 + g) ^ (l15 & 7)) << 4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int P = K >> 6;
+    const int P = K >> KSH;
     const int n = (P - wave + NW - 1) / NW;                          // pairs of this wave: p = wave + NW i
 #pragma unroll
     for (int i = 0; i < NSLOT - 1; ++i)
@@ -340,11 +353,22 @@ __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __r
         acc = mfma16(w1, a1, acc);
         slot = (slot + 1) % NSLOT;
     }
-    if (wave) red[wave - 1][lane] = acc;
-    __syncthreads();
-    if (wave) return;
+    if constexpr (HALF8) {
+        // every wave publishes; lane (m < 8, g < 2) of wave 0 sums, wave by wave, the quadrant D[n][m] and its partner D[n + 8][m + 8]
+        // (lane + 40: column m + 8, row group g + 2) — fixed order
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave || l15 >= 8 || g >= 2) return;
+        acc = red[0][lane] + red[0][lane + 40];
 #pragma unroll
-    for (int wv = 1; wv < NW; ++wv) acc += red[wv - 1][lane];        // fixed order: wave 0 + 1 + 2 + ...
+        for (int wv = 1; wv < NW; ++wv) acc += red[wv][lane] + red[wv][lane + 40];
+    } else {
+        if (wave) red[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave) return;
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) acc += red[wv - 1][lane];    // fixed order: wave 0 + 1 + 2 + ...
+    }
     const int m = l15, nn = n0 + 4 * g;
     if (m >= M || nn >= N) return;
     f32x4 v = acc;
@@ -378,11 +402,16 @@ int launch_mfma_rows(const void* A, const void* W, const float* bias, const floa
     // VLY_GEMV_MFMA: 2 (default) = the LDS-ring form, 1 = fragments straight from global memory (A/B runs)
     static const int form = [] { const char* e = getenv("VLY_GEMV_MFMA"); return e ? atoi(e) : 2; }();
     if (form != 1) {
-        dim3 g2((N + 15) / 16), b2(256);
+        // eight-row blocks (HALF8) where sixteen-row blocks leave the CUs unevenly loaded: fewer than three blocks per CU, M <= 8
+        static const int half_pin = [] { const char* e = getenv("VLY_GEMV_HALF8"); return e ? atoi(e) : -1; }();     // (A/B runs)
+        const bool half8 = M <= 8 && K % 128 == 0 && (half_pin >= 0 ? half_pin != 0 : (N + 15) / 16 < 3 * cu_count());
+        dim3 g2(half8 ? (N + 7) / 8 : (N + 15) / 16), b2(256);
         // (eight waves per workgroup — one workgroup per CU — measured 3-5 % behind four on the narrow shapes: r05_gemv_rows_v2.txt)
 #define VLY_GEMV_M2(E, O)                                                                                                              \
         do {                                                                                                                           \
-            if (M > 8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, true>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, \
+            if (half8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, false, true>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
+                                          K, lda, ldw, ldc, ldr);                                                                      \
+            else if (M > 8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, true>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, \
                                           lda, ldw, ldc, ldr);                                                                         \
             else hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, false>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, lda, \
                                     ldw, ldc, ldr);                                                                                    \
