@@ -119,7 +119,9 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 //   VLY_P4_LIT=0     accumulators as C++ values everywhere (the round-4 kernel; A/B builds)
 //   VLY_P4_DROPSTORE diagnostic: every store of the bf16 epilogue is issued out of range (dropped by the hardware)
 //   VLY_P4_TIMING    anatomy builds: s_memtime stamps at the seams of every tile (tools/p4_boundary_times.py)
-// (measured and removed: waiting for the loads in flight BEFORE the epilogue's first store so that the next K tile's counted wait
+// (measured and removed — commit b4a1225 holds both: whole-line epilogue stores (8 rows x 128 B per instruction by a row_ror:8 exchange)
+//  and a four-phase start skew of an XCD's workgroups, alone and together: -1.8 .. +1.1 %, profiles/r05/r05_boundary_ab_4_fullline_skew.txt;
+//  waiting for the loads in flight BEFORE the epilogue's first store so that the next K tile's counted wait
 //  does not also wait for the stores' acknowledgements — -0.7 .. +0.9 %, noise: the stores throttle the epilogue at their ISSUE;
 //  the zero-free first step with the accumulators as loop-carried C++ values tied "+a" — +2 % until any restructuring of the loop
 //  made hipcc resolve a phi in arch VGPRs: 86 .. 446 spilled registers under three forms of pinning)
@@ -137,12 +139,6 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 #endif
 #ifndef VLY_P4_TIMING
 #define VLY_P4_TIMING 0
-#endif
-#ifndef VLY_P4_FULLLINE
-#define VLY_P4_FULLLINE 0           // experiment: the plain / quick_gelu / ReLU epilogues store 8 rows x 128 B per instruction (see epi_row)
-#endif
-#ifndef VLY_P4_SKEW_CLK
-#define VLY_P4_SKEW_CLK 0           // experiment: workgroup i of an XCD starts (i & 3) x this many cycles late (see gemm_p4_kernel)
 #endif
 #ifndef VLY_EXPERIMENTAL
 #define VLY_EXPERIMENTAL 0          // 1: libvalley_hip_exp.so — also carries tile hint 297
@@ -1001,11 +997,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     const int l15 = lane & 15, g = lane >> 4;
     const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;
     const int nk = K / BK;
-    if constexpr (VLY_P4_SKEW_CLK > 0) {
-        // experiment: the four phases (i & 3) of an XCD's workgroups i = blockIdx.x >> 3 reach their store bursts at different times
-        const int ph = ((int)blockIdx.x >> 3) & 3;
-        for (int w = 0; w < ph * (VLY_P4_SKEW_CLK / 1024); ++w) __builtin_amdgcn_s_sleep(16);      // s_sleep 16 = 1024 clk
-    }
     __builtin_assume(nk >= 2);                                       // launcher: K >= 128 (a zero-trip K loop would make the accumulators a phi)
     const uint32_t wk = ldw < 0 ? (uint32_t)((N + 63) >> 6) * 4096u : (uint32_t)BK;
     // tile index -> (m0, n0): the mapping of gemm_kernel (XCD-contiguous runs, groups of gm m-tiles); tile t runs on
@@ -1220,16 +1211,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 const uint32_t rowb = (uint32_t)(em0 + wm0 + l15) * (uint32_t)ldc * 2u;
 #pragma unroll
                 for (int s = 0; s < NST; ++s) {
-                    if constexpr (VLY_P4_FULLLINE != 0 && EPI != VLY_EPI_SWIGLU) {
-                        // store s = 2 q + h covers fragment rows 8 h .. 8 h + 7 and the 128-byte run of blocks 4 q .. 4 q + 3: the lanes that
-                        // own a row (l15 < 8 for h = 0, l15 >= 8 for h = 1) hold its first 64 bytes, their partners l15 ^ 8 the second 64
-                        const int q = s >> 1, h = s & 1;
-                        const bool second = h == 0 ? l15 >= 8 : l15 < 8;          // (store 1: lanes >= 8 carry the odd pair's piece; store 2: lanes < 8)
-                        const int n = en0 + wn0 + q * 64 + (second ? 32 : 0) + (g & 1) * 16 + (g & 2) * 4;
-                        const uint32_t rb = (uint32_t)(em0 + wm0 + (l15 & 7) + 8 * h) * (uint32_t)ldc * 2u;
-                        vo[s] = rb + (n + 8 <= No && !VLY_P4_DROPSTORE ? (uint32_t)n * 2u : 0x80000000u);
-                        continue;
-                    }
                     const int n = EPI == VLY_EPI_SWIGLU ? ((en0 + wn0) >> 1) + (4 * s + g) * 8
                                                         : en0 + wn0 + (2 * s + (g & 1)) * 16 + (g & 2) * 4;
                     vo[s] = rowb + (n + 8 <= No && !VLY_P4_DROPSTORE ? (uint32_t)n * 2u : 0x80000000u);
@@ -1308,7 +1289,6 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                     hook(8 * jq + 7);
                 }
             } else {
-                [[maybe_unused]] u32x4 xa_keep;                      // (VLY_P4_FULLLINE: the even pair's piece, until the odd pair's is ready)
 #pragma unroll
                 for (int jp = 0; jp < NI / 2; ++jp) {
                     // the four register pairs of two blocks go through every step TOGETHER: between a packed op and the
@@ -1360,29 +1340,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                     if constexpr (EPI != VLY_EPI_QUICK_GELU) hook(4 * jp + 2);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                    if constexpr (VLY_P4_FULLLINE != 0) {
-                        // whole 128-byte lines: the two 64-byte pieces of a row (this pair's and the next pair's) meet in ONE instruction —
-                        // lanes l15 >= 8 take the odd pair's piece of row l15 - 8 for store 1, lanes l15 < 8 that of row l15 + 8 for store 2
-                        // (row_ror:8 inside each row of 16 lanes; bank_mask picks the half that receives)
-                        if ((jp & 1) == 0) {
-                            xa_keep = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                        } else {
-                            const u32x4 xb = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                            u32x4 y1, y2;
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                y1[w] = (uint32_t)__builtin_amdgcn_update_dpp((int)xa_keep[w], (int)xb[w], 0x128, 0xf, 0xc, false);
-                                y2[w] = (uint32_t)__builtin_amdgcn_update_dpp((int)xa_keep[w], (int)xb[w], 0x128, 0xf, 0x3, false);
-                            }
-                            if constexpr (DEFER) { held[jp - 1] = y1; held[jp] = y2; }
-                            else {
-                                __builtin_amdgcn_raw_buffer_store_b128(y1, rsC, vo[jp - 1], 0, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(y2, rsC, vo[jp], 0, 0);
-                                vo[jp - 1] += rstep;
-                                vo[jp] += rstep;
-                            }
-                        }
-                    } else if constexpr (DEFER) held[jp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    if constexpr (DEFER) held[jp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
                     else {
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsC, vo[jp], 0, 0);
                         vo[jp] += rstep;
