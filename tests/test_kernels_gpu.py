@@ -944,14 +944,18 @@ def test_gemm_qkv_rope_rejects_narrow_tiles_and_falls_back():
     assert torch.equal(qkv[:, :heads * 128], ref[:, :heads * 128]) and torch.equal(kc, k2)
 
 
+@pytest.mark.parametrize("shape", [(4100, 4360, 320), (8200, 4360, 128), (6000, 6104, 192)])
 @pytest.mark.parametrize("tile", [197, 198, 199])
-def test_gemm_persistent_many_tiles_bit_identical_to_tile9(tile):
+def test_gemm_persistent_many_tiles_bit_identical_to_tile9(tile, shape):
     """The persistent 4-wave kernel on a problem with MORE tiles than workgroups (several tiles per workgroup, a partial
     last round, ragged last tile row and column, dead waves): same MFMA, same K order as the 16-wave tile -> identical bits,
-    for every epilogue, bf16 and fp32 outputs, fp32 residual, row-major and block-ordered weights."""
+    for every epilogue, bf16 and fp32 outputs, fp32 residual, row-major and block-ordered weights.  Round 5: the bf16-output
+    instantiations hold their accumulators by name and roll a finished tile's epilogue into the next tile's first K tile —
+    (8200, 4360, 128) is 594 tiles of TWO K tiles (every K tile is a boundary or follows one, three tiles per workgroup),
+    (6000, 6104, 192) three K tiles; a wave that sat a tile out and is live in the next one re-reads its fragments."""
     from valley_amd import ops
     d = dev()
-    M, N, K = 4100, 4360, 320                                   # 17 x 18 tiles of 256 x 256 = 306 > 256 workgroups
+    M, N, K = shape                                             # (4100, 4360): 17 x 18 tiles of 256 x 256 = 306 > 256 workgroups
     a = rnd((M, K), 201, dtype=HALF).to(d)
     w = rnd((N, K), 202, 0.05, dtype=HALF).to(d)
     bias = rnd((N,), 203, 0.5).to(d)
