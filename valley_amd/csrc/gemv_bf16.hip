@@ -293,13 +293,25 @@ __global__ void __launch_bounds__(256) gemv_mfma_kernel(const uint16_t* __restri
 // 6.25 ms.  The narrow shapes stay well under the wide ones' 5.5 TB/s whatever the block shape and ring depth: they are 9-24 us
 // kernels whose workgroups (two resident per CU) each pay their own first-byte latency and reduction tail.  Summation order differs
 // from the sixteen-row form (two K positions accumulate separately), so batch invariance holds inside M <= 8 and inside M > 8.
+// What the narrow shapes are NOT bound by (profiles/r05/r05_gemv_h8_variants.txt): 2 / 3 / 4 waves per workgroup with 3 / 4 / 6 slots (two to
+// four workgroups per CU, 7.7-12.8 MB requested ahead chip-wide) all run o 14.3-14.8 and down 31.9-33.7 us.  What they ARE partly bound
+// by (r05_gemv_a_witness.txt, timing witnesses with wrong results, since removed): without the activation fetches — every workgroup
+// re-reads all of A[8][K] from L2, as many bytes as its weights — o runs 12.4 and down 27.8 us (4.2 / 5.1 TB/s; the wide shapes move
+// < 3 %).  Sharing A between more weight rows needs a K split across workgroups and a fix-up pass whose tail costs what it saves on
+// 14 us kernels.
+#ifndef VLY_GEMV_H8_NW
+#define VLY_GEMV_H8_NW 4          // waves per eight-row workgroup and slots per wave (A/B: tools/ab_lib.py build x --src gemv_bf16.hip -D...)
+#endif
+#ifndef VLY_GEMV_H8_NSLOT
+#define VLY_GEMV_H8_NSLOT 4
+#endif
 template <int EPI, int OUT, int NW, bool BIGM, bool HALF8 = false>       // BIGM: 9 .. 16 activation rows (a second activation DMA per pair, 4 KB slots)
 __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                              const float* __restrict__ bias, const float* __restrict__ R,
                                                              void* __restrict__ Cv, int M, int N, int K, int lda, int ldw, int ldc, int ldr) {
     static_assert(!(BIGM && HALF8), "HALF8 is the M <= 8 form");
     constexpr bool FOUR_K = BIGM || HALF8;                            // 4 KB slots: 16 LDS rows of weights + 16 of activations
-    constexpr int NSLOT = FOUR_K ? 4 : 5, SLOT = FOUR_K ? 4096 : 3072;  // 64 / 60 KB of ring per 4-wave workgroup: two workgroups per CU
+    constexpr int NSLOT = HALF8 ? VLY_GEMV_H8_NSLOT : FOUR_K ? 4 : 5, SLOT = FOUR_K ? 4096 : 3072;  // 64 / 60 KB of ring per 4-wave workgroup: two workgroups per CU
     // (HALF8 with 3 / 5 slots: 14.5 / 16.8 us against 14.4 on the 13B o projection — the ring's depth is not what bounds the narrow shapes)
     constexpr int KSH = HALF8 ? 7 : 6;                                // a slot covers 128 (HALF8) or 64 k
     __shared__ __attribute__((aligned(16))) char ring[NW][NSLOT][SLOT];
@@ -409,7 +421,7 @@ int launch_mfma_rows(const void* A, const void* W, const float* bias, const floa
         // (eight waves per workgroup — one workgroup per CU — measured 3-5 % behind four on the narrow shapes: r05_gemv_rows_v2.txt)
 #define VLY_GEMV_M2(E, O)                                                                                                              \
         do {                                                                                                                           \
-            if (half8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, false, true>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
+            if (half8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, VLY_GEMV_H8_NW, false, true>), g2, dim3(VLY_GEMV_H8_NW * 64), 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, \
                                           K, lda, ldw, ldc, ldr);                                                                      \
             else if (M > 8) hipLaunchKernelGGL((gemv_mfma2_kernel<E, O, 4, true>), g2, b2, 0, st, (const uint16_t*)A, (const uint16_t*)W, bias, R, C, M, N, K, \
                                           lda, ldw, ldc, ldr);                                                                         \
