@@ -484,6 +484,60 @@ def test_decode_attention_split_and_merge(B, past, pad, ctx_max, per_row):
         assert relerr(ops.gemv_attnmerge(parts, w), want - res) < 8e-3
 
 
+@pytest.mark.parametrize("B,heads,pasts,pad,ctx_max", [(8, 40, [463, 336, 0, 64, 399, 255, 128, 1], 5, 600), (3, 16, [700, 63, 1100], 300, 1200),
+                                                       (5, 32, [10, 20, 30, 40, 50], 0, 64), (1, 16, [336], 0, 600)])
+def test_decode_attention_merged_rows(B, heads, pasts, pad, ctx_max):
+    """vly_decode_attention_merged with per-row positions — the attention of serving.ContinuousBatcher's captured step for any number
+    of rows (round 5; one to eight live requests) — against vly_decode_attention_rows: identical cache appends, outputs equal to the
+    rounding of the split summation order; the ticket counters are back at zero; a second launch on the same inputs is bit-identical
+    (the merge order is fixed, whichever workgroup of a head finishes last); a row's output does not depend on the other rows.
+    Eight rows x 40 heads run three splits per head, five x 32 three, the others four (decode_split_launch)."""
+    from valley_amd import ops
+    d = dev()
+    cos, sin = _rope_tables(ctx_max)
+    cos, sin = cos.to(d), sin.to(d)
+    kc = torch.zeros((B, heads, ctx_max, 128), dtype=HALF)
+    vc = torch.zeros_like(kc)
+    for b in range(B):
+        if pasts[b]:
+            kc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 130 + b, dtype=HALF)
+            vc[b, :, :pasts[b]] = rnd((heads, pasts[b], 128), 140 + b, dtype=HALF)
+    qkv = rnd((B, 3 * heads * 128), 132, dtype=HALF).to(d)
+    valid = torch.ones((B, ctx_max), dtype=torch.uint8)
+    valid[0, :min(pad, pasts[0])] = 0
+    valid = valid.to(d)
+    pos = torch.tensor(pasts, dtype=torch.int32, device=d)
+    k1, v1 = kc.to(d), vc.to(d)
+    want = ops.decode_attention_rows(qkv, k1, v1, cos, sin, valid, B, heads, pos)
+    outs = []
+    for _ in range(2):
+        k2, v2 = kc.to(d), vc.to(d)
+        parts = ops.decode_partials(B, heads, d)
+        arrivals = torch.zeros((B * heads,), dtype=torch.int32, device=d)
+        got = torch.empty((B, heads * 128), dtype=HALF, device=d)
+        ops.decode_attention_split(qkv, k2, v2, cos, sin, valid, B, heads, 0, parts, past_dev=pos, per_row=True, out=got, arrivals=arrivals)
+        torch.cuda.synchronize()
+        assert int(arrivals.abs().sum().item()) == 0
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])
+    assert maxabs(outs[0], want) <= 2e-2 and relerr(outs[0], want) < 4e-3, (maxabs(outs[0], want), relerr(outs[0], want))
+    # a row's output does not depend on what the OTHER rows of the same launch hold (the launch's shape — rows, heads, hence the
+    # number of splits per head — is the session's, not the request's): other rows' queries, caches and positions replaced
+    if B > 1:
+        qkv4 = qkv.clone()
+        qkv4[1:] = rnd((B - 1, 3 * heads * 128), 133, dtype=HALF).to(d)
+        kc4, vc4 = kc.clone(), vc.clone()
+        kc4[1:] = kc4[1:].flip(0) * 0.5
+        vc4[1:] = vc4[1:].flip(0) * 0.5
+        pos4 = pos.clone()
+        pos4[1:] = torch.clamp(pos[1:].flip(0) + 3, max=ctx_max - 2)
+        other = torch.empty((B, heads * 128), dtype=HALF, device=d)
+        ops.decode_attention_split(qkv4, kc4.to(d), vc4.to(d), cos, sin, valid, B, heads, 0, ops.decode_partials(B, heads, d), past_dev=pos4,
+                                   per_row=True, out=other, arrivals=torch.zeros((B * heads,), dtype=torch.int32, device=d))
+        assert torch.equal(other[0], outs[0][0])
+
+
 @pytest.mark.parametrize("tile", [0, 2, 7, 8, 84, 86, 9])
 @pytest.mark.parametrize("M,N,K", [(1312, 1024, 1024), (300, 264, 192), (77, 512, 128)])
 def test_gemm_splitk2_and_add2_rmsnorm(M, N, K, tile):

@@ -772,13 +772,25 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     u32x4 vv[16], kk[16];
     uint8_t kvalid = 1;
     const int jmax = max(min(hi, pos) - 1, 0);                // last row this split may read (row 0 of the cache if there is none)
+    // (round 5: a pass covers 256 keys but a split's range is often 128 — kv_len 257..512 — and then half of the 32 loads per thread
+    // fetched a clamped row nobody uses: waves whose 64 keys lie past the range skip their K rows, a pass of at most 128 keys skips
+    // the upper eight V chunks.  Wave- and workgroup-uniform branches; the values were masked before, the arithmetic is unchanged.)
     auto request = [&](int c0) {
-        const u32x4* kr = (const u32x4*)(kbase + (size_t)min(c0 + tid, jmax) * 128);
+        if (c0 + (tid & ~63) < hi) {                          // (wave-uniform)
+            const u32x4* kr = (const u32x4*)(kbase + (size_t)min(c0 + tid, jmax) * 128);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) kk[c] = kr[c];
+            for (int c = 0; c < 16; ++c) kk[c] = kr[c];
+        }
         if (kvld) kvalid = kvld[min(c0 + tid, hi - 1)];       // (uniform branch)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) vv[u] = *(const u32x4*)(vbase + (size_t)min(c0 + (tid >> 4) + 16 * u, jmax) * 128 + 8 * (tid & 15));
+        for (int u = 0; u < 8; ++u) vv[u] = *(const u32x4*)(vbase + (size_t)min(c0 + (tid >> 4) + 16 * u, jmax) * 128 + 8 * (tid & 15));
+        if (hi - c0 > 128) {                                  // (uniform)
+#pragma unroll
+            for (int u = 8; u < 16; ++u) vv[u] = *(const u32x4*)(vbase + (size_t)min(c0 + (tid >> 4) + 16 * u, jmax) * 128 + 8 * (tid & 15));
+        } else {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) vv[u] = u32x4{0u, 0u, 0u, 0u};
+        }
     };
     request(lo);
     // ---- RoPE on q (every split), on k + append, v append (the owner): decode_fused_kernel's arithmetic
@@ -881,6 +893,16 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     }
     if (merged) split_merge_if_last(partials, merged, arrivals, heads, h, b, sc);
 }
+
+// Round 5, the launch at EIGHT rows (serving.ContinuousBatcher; 320 heads x 4 splits, ~61 MB of K / V per layer of the 13B step):
+// 20.7 us per layer, 19.5 with the unused loads skipped (above) — 3.1 TB/s, against 23.0 for decode_fused_kernel's 320 workgroups.
+// Three restructurings measured no better in the step (profiles/r05/r05_decode_b8_attention.txt) and are not kept:
+//   * sixteen lanes per key for K as for V (a wave instruction reads four whole 256-byte rows instead of touching 64; 16-lane DPP
+//     sum per score, probabilities stay in registers): 1273 vs 1288 tokens/s at eight requests, 215.4 vs 216.2 at one;
+//   * two, three or four splits per head chosen by the launch's rounds of workgroups: 18.8 / 19.5 / 19.6 us;
+//   * decode_step.hip's register-lean form (K row and V chunks in two halves, 128 registers, four workgroups per CU): 26 us.
+// So neither the K access shape, nor the rounds, nor the occupancy bounds it; what is left is each workgroup's chain position ->
+// K / V round trip -> two barriers -> write-through publish -> ticket, which more resident workgroups only stretch.
 
 // ---- vly_llama_attention_probs: HF's ``output_attentions`` (round 4) -------------------------------------------------------
 // The flash-style kernels above never hold a row of probabilities; a caller that asks for them (valley_model.py:281,324-330

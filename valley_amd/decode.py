@@ -34,6 +34,7 @@ PERSISTENT = os.environ.get("VALLEY_DECODE_PERSISTENT", "0") != "0"
 # (vly_decode_attention_merged; the o projection is then a plain GEMV), "oproj": in the o GEMV's prologue (round 3).  Same bits.
 # ("oproj" and the persistent step need the experimental library: VALLEY_EXPERIMENTAL=1, include/valley_hip.h's EXPERIMENTAL prototypes)
 MERGE_IN = os.environ.get("VALLEY_DECODE_MERGE", "attn")
+SPLIT_ROWS = os.environ.get("VALLEY_DECODE_SPLIT_ROWS", "1") != "0"       # round 5: the merged split attention for 3 .. 8 rows as well
 
 class DecodeSession:
     def __init__(self, llama: HipLlama, cache: HipKVCache, use_graph: bool = True, per_row_positions: bool = False):
@@ -75,7 +76,11 @@ class DecodeSession:
         # the three norm -> projection seams as one launch each where the fused kernel takes the shape (bit-identical either way;
         # VALLEY_DECODE_FUSE_NORM=0 keeps the pairs, for A/B runs)
         fused = FUSE_NORM and ops.gemv_rmsnorm_ok(B, ll.H)
-        split = SPLIT_ATTN and ops.gemv_rmsnorm_ok(B, ll.H) and ll.heads * 128 == ll.H
+        # every head over four workgroups.  Merged inside the attention launch (the default) it does not depend on the o GEMV's form, so
+        # three to eight rows take it too: at eight requests decode_fused_kernel's 320 workgroups of 512 threads are 1.25 rounds of one
+        # workgroup per CU (23 us per layer, 15 % of the step); 1280 quarter-head workgroups stream the same K / V evenly
+        # (VALLEY_DECODE_SPLIT_ROWS=0: the one-workgroup-per-head kernel for more than two rows, A/B runs)
+        split = SPLIT_ATTN and ll.heads * 128 == ll.H and (ops.gemv_rmsnorm_ok(B, ll.H) or (SPLIT_ROWS and MERGE_IN == "attn"))
         ops.embed_splice(self.tok, ll.embed, None, out=self.h)
         if self.persistent:
             if self.table is None or self._table_gen != c.generation:      # raw pointers: the cache's storage may have moved
