@@ -2,7 +2,7 @@
 """Audit of the kernels that own their accumulation registers BY NAME (gemm_p4_kernel's rolled instantiations, gemm_bf16.hip
 "accumulators by name"): in the ISA hipcc emits for them, no instruction OUTSIDE an inline-asm block may name an accumulation
 register — the compiler has no value there, and a spill or copy of its own into a0..a255 would silently corrupt a tile.  Also
-required: no scratch, no spilled registers.  Usage: agpr_audit.py [-Dflags ...]   (exit code 1 on any finding)"""
+required: no scratch, no spilled registers.  Usage: agpr_audit.py [--p32] [-Dflags ...]   (exit code 1 on any finding)"""
 import os
 import re
 import subprocess
@@ -15,16 +15,21 @@ SRC = os.path.join(ROOT, "valley_amd", "csrc", "gemm_bf16.hip")
 
 def main():
     flags = sys.argv[1:]
+    src, kern = SRC, "gemm_p4_kernel"
+    if "--p32" in flags:                                     # the 32x32x16 persistent kernel (gemm_p32.hip): every instantiation is by name
+        flags.remove("--p32")
+        src, kern = os.path.join(ROOT, "valley_amd", "csrc", "gemm_p32.hip"), "gemm_p32_kernel"
+    stem = os.path.basename(src)[:-4]
     with tempfile.TemporaryDirectory() as td:
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-save-temps", "-c", SRC,
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-save-temps", "-c", src,
                                "-o", os.path.join(td, "g.o")], cwd=td, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(td, "gemm_bf16-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+        asm = open(os.path.join(td, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
     bad = 0
     kernels = 0
     i = 0
     areg = re.compile(r"\ba(\[(\d+|0x[0-9a-f]+)(:(\d+|0x[0-9a-f]+))?\]|\d+\b)")
     while i < len(asm):
-        m = re.match(r"^(_ZN\S*gemm_p4_kernel\S*):", asm[i])
+        m = re.match(r"^(_ZN\S*" + kern + r"\S*):", asm[i])
         if not m:
             i += 1
             continue

@@ -1910,6 +1910,10 @@ __attribute__((visibility("hidden"))) int valley_p4_streamk(int tile, const void
 
 extern "C" int vly_gemm_tile_for(int M, int N) { return pick_tile(M, N); }
 
+// gemm_p32.hip: the persistent kernel on the 32x32x16 MFMA (tile hint 397); 1 = the problem does not fit it
+int valley_p32_gemm(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw, int ldc, int epi,
+                    int out, hipStream_t st, int deep);
+
 static int run_tile(int t, int tile_hint, const void* A, const void* W, const float* bias, const float* residual, void* C,
                     int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, hipStream_t st,
                     void* C2, const RopeArgs* rope = nullptr) {
@@ -1917,6 +1921,11 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
 #define VLY_TILE_ARGS_RAW A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
 #ifdef VLY_FEW_TILES                                        /* fast A/B builds (tools/ab_lib.py): only the tiles under study */
     switch (t) {
+        case 397:
+        case 398: {
+            const int rc = rope || C2 ? 1 : valley_p32_gemm(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, epilogue, out_dtype, st, t == 398);
+            return rc == 1 ? run_tile(197, tile_hint, VLY_TILE_ARGS_RAW) : rc;
+        }
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 97: return launch_tile<256, 256, 128, 128, 8>(VLY_TILE_ARGS);
         case 98: return launch_tile<224, 256, 112, 128, 8>(VLY_TILE_ARGS);
@@ -1946,6 +1955,11 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 93: return launch_tile<256, 128, 64, 32, 6>(VLY_TILE_ARGS);
         case 94: return launch_tile<128, 256, 32, 64, 6>(VLY_TILE_ARGS);
+        case 397:                                           // persistent on the 32x32x16 MFMA (gemm_p32.hip); what it does not take goes to 197
+        case 398: {                                         // (398: its DEEP form — four resident fragment sets, burst stores)
+            const int rc = rope || C2 ? 1 : valley_p32_gemm(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, epilogue, out_dtype, st, t == 398);
+            return rc == 1 ? run_tile(197, tile_hint, VLY_TILE_ARGS_RAW) : rc;
+        }
         // 4 waves x (128 x 128): a quarter of the 16-wave tile's LDS fragment traffic (PIPE 8 comment)
         case 197:                                           // persistent: one workgroup per CU walks the tiles (gemm_p4_kernel)
         case 198:
