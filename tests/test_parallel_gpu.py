@@ -49,6 +49,28 @@ def test_bench_multi_rank_launch_path():
         assert 0 < d["allgather_share_of_step"] < 1
 
 
+def test_bench_self_launch_defaults_to_configs3():
+    """`python bench.py --gpus 2` with NO launcher: the script re-executes itself under torch.distributed.run, and at
+    N > 1 its default workload is BASELINE configs[3] as written (c4: 32 frames x 8 clips per GPU, 13B prefill REPLICATED over all
+    N x 8 sequences), with the sharded-prefill (weak scaling) form of the same step measured in the same run under also.sharded_prefill.
+    Two ranks share the one GPU of the test box (gloo carries the gather)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VALLEY_BENCH_SAME_DEVICE="1", VALLEY_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["steps"] == 3
+    assert j["config"]["name"] == "c4" and "32 frames x 8 clips per GPU" in j["config"]["workload"]
+    assert j["config"]["prefill_batch_per_gpu"] == 16 and "replicated-prefill" in j["config"]["parallelism"]
+    assert j["dist"]["world_size"] == 2 and j["dist"]["prefill"] == "replicated"
+    sh = j["also"]["sharded_prefill"]
+    assert sh["prefill_batch_per_gpu"] == 8 and sh["value"] > j["value"]          # (the replicated prefill does twice the LLM work)
+
+
 def _gpu_count():
     try:
         import torch

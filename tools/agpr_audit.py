@@ -2,7 +2,7 @@
 """Audit of the kernels that own their accumulation registers BY NAME (gemm_p4_kernel's rolled instantiations, gemm_bf16.hip
 "accumulators by name"): in the ISA hipcc emits for them, no instruction OUTSIDE an inline-asm block may name an accumulation
 register — the compiler has no value there, and a spill or copy of its own into a0..a255 would silently corrupt a tile.  Also
-required: no scratch, no spilled registers.  Usage: agpr_audit.py [--p32] [-Dflags ...]   (exit code 1 on any finding)"""
+required: no scratch, no spilled registers.  Usage: agpr_audit.py [--p32 | --p16] [-Dflags ...]   (exit code 1 on any finding)"""
 import os
 import re
 import subprocess
@@ -19,6 +19,9 @@ def main():
     if "--p32" in flags:                                     # the 32x32x16 persistent kernel (gemm_p32.hip): every instantiation is by name
         flags.remove("--p32")
         src, kern = os.path.join(ROOT, "valley_amd", "csrc", "gemm_p32.hip"), "gemm_p32_kernel"
+    if "--p16" in flags:                                     # the 16x16x32 chains-of-two persistent kernel (gemm_p16.hip)
+        flags.remove("--p16")
+        src, kern = os.path.join(ROOT, "valley_amd", "csrc", "gemm_p16.hip"), "gemm_p16_kernel"
     stem = os.path.basename(src)[:-4]
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-save-temps", "-c", src,

@@ -31,6 +31,14 @@ for n in sys.argv[1].split(","):
             assert L.vly_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, None, out.data_ptr(), M, N, K, K, K,
                                    out.shape[1], 0, epi, 0, HINT, st) == 0
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):                                  # back to back: settled (power-limited) clock
+            L.vly_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, None, out.data_ptr(), M, N, K, K, K,
+                            out.shape[1], 0, epi, 0, HINT, st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
         host = (ctypes.c_ulonglong * (64 * 65))()
         assert L.vlydbg_p32_timing_read(host) == 0
         nk = K // 64
@@ -48,8 +56,9 @@ for n in sys.argv[1].split(","):
                     rest.append((s2 - s1) / (nk - HEAD))
                     drain.append(s3 - s2)
         if not head:
-            print(f"{n} {sh}: one tile per workgroup, whole kernel {statistics.median(total):.0f} clk")
+            print(f"{n} {sh}: one tile per workgroup")
             continue
         tile = HEAD * statistics.median(head) + (nk - HEAD) * statistics.median(rest) + statistics.median(drain)
         print(f"{n:8s}/{HINT} {sh}: kernel {statistics.median(total):.0f} clk | per K tile: head {statistics.median(head):.0f}  rest {statistics.median(rest):.0f} "
-              f"(ideal 2048) | drain {statistics.median(drain):.0f} | tile {tile:.0f} = {2048 * nk / tile:.3f} of MFMA-bound", flush=True)
+              f"(ideal 2048) | drain {statistics.median(drain):.0f} | tile {tile:.0f} = {2048 * nk / tile:.3f} of MFMA-bound | {us:.1f} us = "
+              f"{2.0 * M * N * K / us / 1e6:.0f} TFLOP/s, clock {statistics.median(total) / us / 1e3:.2f} GHz", flush=True)

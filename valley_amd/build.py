@@ -16,7 +16,7 @@ LIB_F16 = os.path.join(LIBDIR, "libvalley_hip_f16.so")      # the same sources w
 LIB_EXP = os.path.join(LIBDIR, "libvalley_hip_exp.so")
 LIB_EXP_F16 = os.path.join(LIBDIR, "libvalley_hip_exp_f16.so")   # the same on fp16 storage (the experiments' bit-identity tests run on both types)
 EXP_UNITS = ["decode_step.hip", "attention.hip", "gemm_bf16.hip", "gemv_bf16.hip"]
-SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_p32.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip", "decode_step.hip"]
+SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_p32.hip", "gemm_p16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip", "decode_step.hip"]
 
 
 def hipcc() -> str:

@@ -1913,6 +1913,9 @@ extern "C" int vly_gemm_tile_for(int M, int N) { return pick_tile(M, N); }
 // gemm_p32.hip: the persistent kernel on the 32x32x16 MFMA (tile hint 397); 1 = the problem does not fit it
 int valley_p32_gemm(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw, int ldc, int epi,
                     int out, hipStream_t st, int deep);
+// gemm_p16.hip: the persistent kernel on the 16x16x32 MFMA in chains of two, parked whole-line stores (tile hint 497); 1 = does not fit
+int valley_p16_gemm(const void* A, const void* W, const float* bias, const float* R, void* C, int M, int N, int K, int lda, int ldw, int ldc, int epi,
+                    int out, hipStream_t st);
 
 static int run_tile(int t, int tile_hint, const void* A, const void* W, const float* bias, const float* residual, void* C,
                     int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, int out_dtype, hipStream_t st,
@@ -1921,6 +1924,10 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
 #define VLY_TILE_ARGS_RAW A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, epilogue, out_dtype, st, C2, rope
 #ifdef VLY_FEW_TILES                                        /* fast A/B builds (tools/ab_lib.py): only the tiles under study */
     switch (t) {
+        case 497: {
+            const int rc = rope || C2 ? 1 : valley_p16_gemm(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, epilogue, out_dtype, st);
+            return rc == 1 ? run_tile(197, tile_hint, VLY_TILE_ARGS_RAW) : rc;
+        }
         case 397:
         case 398: {
             const int rc = rope || C2 ? 1 : valley_p32_gemm(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, epilogue, out_dtype, st, t == 398);
@@ -1955,6 +1962,10 @@ static int run_tile(int t, int tile_hint, const void* A, const void* W, const fl
         case 9: return launch_tile<256, 256, 64, 64, 0>(VLY_TILE_ARGS);
         case 93: return launch_tile<256, 128, 64, 32, 6>(VLY_TILE_ARGS);
         case 94: return launch_tile<128, 256, 32, 64, 6>(VLY_TILE_ARGS);
+        case 497: {                                         // persistent, 16x16x32 in chains of two, parked whole-line stores (gemm_p16.hip)
+            const int rc = rope || C2 ? 1 : valley_p16_gemm(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, epilogue, out_dtype, st);
+            return rc == 1 ? run_tile(197, tile_hint, VLY_TILE_ARGS_RAW) : rc;
+        }
         case 397:                                           // persistent on the 32x32x16 MFMA (gemm_p32.hip); what it does not take goes to 197
         case 398: {                                         // (398: its DEEP form — four resident fragment sets, burst stores)
             const int rc = rope || C2 ? 1 : valley_p32_gemm(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, epilogue, out_dtype, st, t == 398);

@@ -32,12 +32,12 @@
 #include <cstring>
 #include <type_traits>
 #include <utility>
-#include "common.hpp"
+#include "gemm_persist.hpp"
 #include "../../include/valley_hip.h"
 
-int vly_tile_group_height(int M, int N, int K, int tiles_m, int tiles_n, int BM, int BN, int wg_per_cu);
-
 namespace {
+using namespace vlyp;
+typedef TileMap P32Map;
 
 constexpr int BK = 64;
 
@@ -83,20 +83,6 @@ VLY_DEVICE void acc_read16(int blk, float (&v)[16]) {
                      : "=v"(v[4 * q]), "=v"(v[4 * q + 1]), "=v"(v[4 * q + 2]), "=v"(v[4 * q + 3])
                      : "i"(16 * blk + 4 * q), "i"(16 * blk + 4 * q + 1), "i"(16 * blk + 4 * q + 2), "i"(16 * blk + 4 * q + 3));
 }
-#define VLY_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
-#define VLY_ALL_AGPRS                                                                                                                  \
-    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", VLY_A8(1), VLY_A8(2), VLY_A8(3), VLY_A8(4), VLY_A8(5), VLY_A8(6), VLY_A8(7), \
-        VLY_A8(8), VLY_A8(9), VLY_A8(10), VLY_A8(11), VLY_A8(12), VLY_A8(13), VLY_A8(14), VLY_A8(15), VLY_A8(16), VLY_A8(17), VLY_A8(18),   \
-        VLY_A8(19), VLY_A8(20), VLY_A8(21), VLY_A8(22), VLY_A8(23), VLY_A8(24), "a250", "a251", "a252", "a253", "a254", "a255"
-
-// x / d for x, d < 2^16 with mg = floor(2^32 / d) + 1 (host): exact, one s_mul_hi_u32 — the tile -> origin map stays on the scalar unit
-VLY_DEVICE int udiv_magic(int x, unsigned mg) { return mg ? (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)x, mg)) : x; }      // (mg = 0: d = 1)
-
-struct P32Map {                     // tile order (gemm_bf16.hip's: XCD-contiguous runs, groups of gm m-tiles), divisions by multiplication
-    int tiles_m, tiles_n, gm, gsz, ghl;             // gsz = gm * tiles_n; ghl = height of the last group
-    unsigned mg_gsz, mg_gm, mg_ghl;
-};
-
 // 16 MFMAs of one K step; hook(t) runs behind MFMA t.  MODE 1: C = 0 (first K step of a tile without bias)
 template <int MODE, typename H>
 VLY_DEVICE void step32(const bf16x8 (&fa)[4], const bf16x8 (&fw)[4], H&& hook) {
@@ -113,15 +99,6 @@ VLY_DEVICE void step32(const bf16x8 (&fa)[4], const bf16x8 (&fw)[4], H&& hook) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int... I, typename F>
-VLY_DEVICE void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-VLY_DEVICE void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-
-VLY_DEVICE uint32_t w_row_off32(int n, int ldw) {
-    return ldw < 0 ? (uint32_t)(n >> 6) * 4096u + (uint32_t)(n & 63) * 64u : __umul24((uint32_t)n, (uint32_t)ldw);
 }
 
 // DEEP = false: the finished tile is parked in registers and trickles out under the next tile (64 fragment registers, one barrier per
@@ -156,17 +133,7 @@ gemm_p32_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, 
     const uint32_t wk = ldw < 0 ? (uint32_t)((N + 63) >> 6) * 4096u : (uint32_t)BK;
     const int No = SWI ? N >> 1 : N;
 
-    auto tile_origin = [&](int t, int& m0, int& n0) {                   // scalar unit only
-        const int xcd = t & 7, qd = ntiles >> 3, rm = ntiles & 7;
-        const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (t >> 3);
-        const int grp = udiv_magic(swz, mp.mg_gsz), first = grp * mp.gm;
-        const int rr = swz - grp * mp.gsz;
-        const bool lastg = first + mp.gm > mp.tiles_m;
-        const int gh = lastg ? mp.ghl : mp.gm;
-        const int c = udiv_magic(rr, lastg ? mp.mg_ghl : mp.mg_gm);
-        m0 = (first + rr - c * gh) * BM;
-        n0 = c * BN;
-    };
+    auto tile_origin = [&](int t, int& m0, int& n0) { vlyp::tile_origin<BM, BN>(mp, ntiles, t, m0, n0); };
     // Operands through descriptors that END with the last row: a piece whose row lies past M (N) is out of range and reads as zero —
     // no per-row clamp, so a lane's source offset is LINEAR in the piece number: one register per operand (gemm_p4_kernel keeps 14-16).
     // (Rows past N of a block-packed W land in later blocks or past the end: finite garbage or zero in columns that are never stored.)
@@ -672,26 +639,8 @@ __attribute__((visibility("hidden"))) int valley_p32_gemm(const void* A, const v
         return 1;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     if ((long)tm * tn >= 65536 || lda >= (1 << 24) || (ldw > 0 && ldw >= (1 << 24)) || M >= (1 << 24) || N >= (1 << 24)) return 1;
-    const int gm = vly_tile_group_height(M, N, K, tm, tn, BM, BN, 1);
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (getenv("VLY_P4_GRID")) n = atoi(getenv("VLY_P4_GRID"));
-        return n > 0 ? n / 8 * 8 : 256;
-    }();
-    const int tiles = tm * tn;
-    P32Map mp;
-    mp.tiles_m = tm;
-    mp.tiles_n = tn;
-    mp.gm = gm;
-    mp.gsz = gm * tn;
-    const int groups = (tm + gm - 1) / gm;
-    mp.ghl = tm - (groups - 1) * gm;
-    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) / (unsigned long long)d) + 1ull); };
-    mp.mg_gsz = magic(mp.gsz);
-    mp.mg_gm = magic(mp.gm);
-    mp.mg_ghl = magic(mp.ghl);
+    const P32Map mp = make_tile_map(M, N, K, BM, BN);
+    const int cus = persistent_grid_cus(), tiles = tm * tn;
     dim3 grid(tiles >= cus ? cus : tiles), block(256);
     unsigned long long* ts = nullptr;
 #if VLY_P32_TIMING
