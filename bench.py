@@ -254,6 +254,10 @@ ALSO = {
     # the headline workload on the fp32 validation engines (valley_amd/precise.py): what the 1e-3 logit bound costs
     "c3_fp32": (["--config", "c3", "--steps", "2", "--warmup", "1"], "configs[2] on the fp32 validation engines (logits within 1e-3)",
                 {"VALLEY_PRECISION": "fp32"}),
+    # the same engines with every GEMM as three 16-bit partial products on the production MFMA kernels (ops_f32, VALLEY_F32_GEMM=x3):
+    # what the 1e-3 bound costs once the contractions leave the f32-input MFMA
+    "c3_x3": (["--config", "c3", "--steps", "3", "--warmup", "1"], "configs[2] on the split-operand engines (fp32 tensors, GEMMs = hi.hi + hi.lo + lo.hi on the bf16 MFMA; logits within 1e-3)",
+              {"VALLEY_PRECISION": "fp32", "VALLEY_F32_GEMM": "x3"}),
     # the headline workload on libvalley_hip_f16.so: IEEE fp16 storage is the reference's own inference dtype
     # (valley/inference/run_valley.py:39 `torch_dtype=torch.float16`); the child is told through VALLEY_PRECISION
     "c3_fp16": (["--config", "c3", "--steps", "10", "--warmup", "3"], "configs[2] at the reference's inference dtype (fp16 storage)",
@@ -372,6 +376,10 @@ def main():
     # compute dtype of the line: the library's 16-bit storage / MFMA operand type (bf16 default; VALLEY_PRECISION=fp16 runs
     # the same step on libvalley_hip_f16.so — the reference's own inference dtype)
     DT = runtime.PRECISION                                    # "bf16" | "fp16" | "fp32" (the validation engines)
+    if DT == "fp32":
+        from valley_amd import ops_f32
+        if ops_f32.GEMM_MODE == "x3":
+            DT = "fp32 tensors; GEMMs as 3 bf16 partial products (hi.hi + hi.lo + lo.hi), fp32 accumulation"
     from valley_amd import weights as W
 
     cfg = CONFIGS[args.config]

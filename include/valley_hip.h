@@ -30,10 +30,11 @@
 extern "C" {
 #endif
 
-#define VLY_ABI_VERSION 6   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
+#define VLY_ABI_VERSION 7   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
                                vly_decode_attention_split, vly_gemv_attnmerge_bf16; 5: + vly_decode_layers(_supported),
                                vly_decode_attention_merged; 6: vly_decode_layers(_supported) and tile hint 297 moved to the
-                               EXPERIMENTAL library (libvalley_hip_exp.so, section at the end), vly_gemv_bf16 takes M <= 16 */
+                               EXPERIMENTAL library (libvalley_hip_exp.so, section at the end), vly_gemv_bf16 takes M <= 16; 7: + vly_split3_f32,
+                               tile hints 397 / 398 / 497 of vly_gemm_bf16 */
 
 /* epilogues of vly_gemm_bf16 */
 #define VLY_EPI_NONE        0   /* C = A W^T (+bias) (+residual)                                   */
@@ -376,6 +377,15 @@ int vly_gemm_skinny_bf16(const void *A_bf16, const void *W_bf16, const float *bi
  *   alias C. */
 int vly_gemm_f32(const float *A, const float *W, const float *bias, const float *residual, float *C,
                  int M, int N, int K, int lda, int ldw, int ldc, int ldr, int epilogue, void *stream);
+
+/* Split-operand images for the fp32 engines' GEMMs (round 6; VALLEY_F32_GEMM=x3): out3[M, 3 Kp] (16-bit storage) from fp32 x[M, K]
+ *   with x = hi + lo, hi = rn16(x), lo = rn16(x - hi): order 0 -> [hi | hi | lo] (activations), order 1 -> [hi | lo | hi] (weights),
+ *   every segment Kp >= K wide, pad columns zero.  vly_gemm_bf16 over K' = 3 Kp with fp32 output then equals the fp32 product up to
+ *   2^-16 relative per term (a_hi w_hi + a_hi w_lo + a_lo w_hi, each exact in fp32) — the arithmetic of hf:clip/modeling_clip.py:293-350
+ *   / hf:llama/modeling_llama.py:160-173,230-241 at a third of the 16-bit MFMA rate instead of a sixteenth.  epilogue applies the
+ *   PRODUCING GEMM's activation first (vly_gemm_f32's expressions): NONE, QUICK_GELU, RELU, or SWIGLU (x then has 2 K interleaved
+ *   (gate, up) columns).  K % 4 == 0, Kp % 4 == 0, ldx % 4 == 0, x 16-byte aligned. */
+int vly_split3_f32(const float *x, int ldx, void *out3_half, int M, int K, int Kp, int epilogue, int order, void *stream);
 
 /* out = softmax(q k^T * head_dim^-0.5 [+ mask]) v in fp32 (hf:clip/modeling_clip.py:259-277 without mask;
  *   hf:llama/modeling_llama.py:191-213 with causal + key-validity mask: key j visible to query i iff

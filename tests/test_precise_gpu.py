@@ -246,6 +246,68 @@ def test_fp32_mode_13b_layer_shapes_within_1e3_of_oracle():
     assert e < TOL_FP32
 
 
+# ---- (i-b) the same bound on the split-operand engine (VALLEY_F32_GEMM=x3, round 6) -----------------------------------------------
+@pytest.fixture
+def x3_mode():
+    """The fp32 engines with every GEMM as three 16-bit partial products (hi.hi + hi.lo + lo.hi) on vly_gemm_bf16 (ops_f32.GEMM_MODE)."""
+    from valley_amd import ops_f32, runtime
+    if runtime.HALF != torch.bfloat16:
+        pytest.skip("the split-operand GEMMs are built on the bf16 library")
+    ops_f32.set_gemm_mode("x3")
+    yield
+    ops_f32.set_gemm_mode("exact")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 264, 128, 0), (771, 1028, 1024, 0), (2056, 4096, 1024, 1), (672, 2048, 1024, 2), (512, 1024, 592, 0),
+                                       (4, 512, 256, 0)])
+def test_x3_gemm_vs_fp64(M, N, K, epi, x3_mode):
+    """a . w^T as hi.hi + hi.lo + lo.hi: relative error ~2^-16 per term, against the fp64 product of the SAME fp32 operands; the
+    activation of a producing GEMM is applied by the consumer's operand split (X3Act) and checked through a second GEMM."""
+    from valley_amd import ops_f32 as F
+    a = rnd((M, K), 1).cuda()
+    w = rnd((N, K), 2, K ** -0.5).cuda()
+    b = rnd((N,), 3).cuda()
+    r = rnd((M, N), 4).cuda()
+    ref = a.double() @ w.double().t() + b.double()
+    if epi == 0:
+        got = F.gemm(a, w, b, residual=r)
+        ref = ref + r.double()
+        e = float((got.double() - ref).abs().max() / ref.abs().max())
+        print(f"x3 gemm {M}x{N}x{K}: max error / max |c| = {e:.2e}")
+        assert e < 4e-5
+        return
+    act = F.gemm(a, w, b, epilogue=epi)
+    assert isinstance(act, F.X3Act)
+    if epi == 1:
+        mid = ref / (1 + torch.exp(-1.702 * ref))
+    else:
+        mid = ref[:, 0::2] / (1 + torch.exp(-ref[:, 0::2])) * ref[:, 1::2]
+    w2 = rnd((512, mid.shape[1]), 5, mid.shape[1] ** -0.5).cuda()
+    got = F.gemm(act, w2)
+    ref2 = mid @ w2.double().t()
+    e = float((got.double() - ref2).abs().max() / ref2.abs().max())
+    print(f"x3 gemm {M}x{N}x{K}, epilogue {epi} applied by the next GEMM's split: max error / max |c| = {e:.2e}")
+    assert e < 6e-5
+
+
+def test_x3_mode_tower_vs_reference_fixture(x3_mode):
+    test_fp32_mode_tower_vs_reference_fixture()
+
+
+@pytest.mark.parametrize("method", ["mean", "max", "temporal_importance", "temporal_transformer"])
+def test_x3_mode_logits_within_1e3_of_reference(method, x3_mode):
+    """BASELINE.json's "logits within 1e-3 of reference" on the engine that runs at a third (not a sixteenth) of the production rate."""
+    test_fp32_mode_logits_within_1e3_of_reference(method)
+
+
+def test_x3_mode_splice_cases_and_decode_vs_reference(x3_mode):
+    test_fp32_mode_splice_cases_and_decode_vs_reference()
+
+
+def test_x3_mode_13b_layer_shapes_within_1e3_of_oracle(x3_mode):
+    test_fp32_mode_13b_layer_shapes_within_1e3_of_oracle()
+
+
 # ---- (ii) the bf16 path against the same-dtype oracle --------------------------------------------------------------------
 @pytest.mark.parametrize("method", ["mean", "max"])
 def test_bf16_path_vs_same_dtype_oracle(method):

@@ -256,6 +256,72 @@ __global__ void __launch_bounds__(256) embed_splice_f32_kernel(const int32_t* __
 
 }  // namespace
 
+// ---- split-operand form of the fp32 GEMMs (round 6, VALLEY_F32_GEMM=x3; valley_amd/ops_f32.py) ---------------------------------------
+// An fp32 value x = hi + lo + O(2^-16 x) with hi = rn16(x), lo = rn16(x - hi) (two 16-bit storage values).  A product a w then is
+// a_hi w_hi + a_hi w_lo + a_lo w_hi up to 2^-16 relative (the dropped a_lo w_lo and the tails), every partial product exact in fp32.
+// Written as ONE contraction over 3 K: A3 = [a_hi | a_hi | a_lo], W3 = [w_hi | w_lo | w_hi], so that the existing 16-bit MFMA kernels
+// (vly_gemm_bf16, fp32 accumulation, fp32 output + bias + residual) compute it unchanged at a third of their rate — ~5x the exact
+// f32-input MFMA.  This kernel builds either image from fp32 rows: order 0 = [hi | hi | lo] (activations), 1 = [hi | lo | hi]
+// (weights); every segment is Kp >= K wide (pad columns zero: the GEMM wants 3 Kp % 64 == 0).  epi applies the producing GEMM's
+// activation first, with vly_gemm_f32's own expressions: QUICK_GELU, RELU, or SWIGLU (x holds 2 K interleaved (gate, up) columns).
+template <int EPI>
+__global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int M, int K, int Kp,
+                                                      int order) {
+    const long total = (long)M * (Kp >> 2);
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int m = (int)(t / (Kp >> 2)), k = (int)(t % (Kp >> 2)) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {                                                          // (K % 4 == 0)
+        if constexpr (EPI == VLY_EPI_SWIGLU) {
+            const f32x4 a = *(const f32x4*)(x + (size_t)m * ldx + 2 * k), b = *(const f32x4*)(x + (size_t)m * ldx + 2 * k + 4);
+            v[0] = a[0] / (1.f + expf(-a[0])) * a[1];
+            v[1] = a[2] / (1.f + expf(-a[2])) * a[3];
+            v[2] = b[0] / (1.f + expf(-b[0])) * b[1];
+            v[3] = b[2] / (1.f + expf(-b[2])) * b[3];
+        } else {
+            const f32x4 a = *(const f32x4*)(x + (size_t)m * ldx + k);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = a[r];
+                if constexpr (EPI == VLY_EPI_QUICK_GELU) v[r] = v[r] / (1.f + expf(-1.702f * v[r]));
+                if constexpr (EPI == VLY_EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+        }
+    }
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        hi[r] = f2h(v[r]);
+        lo[r] = f2h(v[r] - h2f(hi[r]));
+    }
+    const u32x2 H = {(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+    const u32x2 L = {(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+    uint16_t* row = out + (size_t)m * (3 * Kp) + k;
+    *(u32x2*)row = H;
+    *(u32x2*)(row + Kp) = order ? L : H;
+    *(u32x2*)(row + 2 * Kp) = order ? H : L;
+}
+
+extern "C" int vly_split3_f32(const float* x, int ldx, void* out3, int M, int K, int Kp, int epilogue, int order, void* stream) {
+    const int kin = epilogue == VLY_EPI_SWIGLU ? 2 * K : K;
+    if (M <= 0 || K <= 0 || K % 4 || Kp < K || Kp % 4 || ldx < kin || ldx % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out3 & 7) || (order & ~1)) {
+        vly_set_error("vly_split3_f32: bad args M=%d K=%d Kp=%d ldx=%d order=%d", M, K, Kp, ldx, order);
+        return -22;
+    }
+    const long total = (long)M * (Kp >> 2);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (epilogue) {
+        case VLY_EPI_NONE: hipLaunchKernelGGL(split3_kernel<VLY_EPI_NONE>, grid, block, 0, st, x, ldx, (uint16_t*)out3, M, K, Kp, order); break;
+        case VLY_EPI_QUICK_GELU: hipLaunchKernelGGL(split3_kernel<VLY_EPI_QUICK_GELU>, grid, block, 0, st, x, ldx, (uint16_t*)out3, M, K, Kp, order); break;
+        case VLY_EPI_RELU: hipLaunchKernelGGL(split3_kernel<VLY_EPI_RELU>, grid, block, 0, st, x, ldx, (uint16_t*)out3, M, K, Kp, order); break;
+        case VLY_EPI_SWIGLU: hipLaunchKernelGGL(split3_kernel<VLY_EPI_SWIGLU>, grid, block, 0, st, x, ldx, (uint16_t*)out3, M, K, Kp, order); break;
+        default: vly_set_error("vly_split3_f32: bad epilogue %d", epilogue); return -22;
+    }
+    return vly_check_launch("vly_split3_f32");
+}
+
 extern "C" int vly_gemm_f32(const float* A, const float* W, const float* bias, const float* residual, float* C, int M, int N,
                             int K, int lda, int ldw, int ldc, int ldr, int epilogue, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || K % GK || N % 4 || lda % 4 || ldw % 4 || ldc % 2 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) ||

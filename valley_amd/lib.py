@@ -64,6 +64,7 @@ _SIGS = {
                                        c_int, _P]),
     "vly_gemm_skinny_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     # fp32 "precise" path
+    "vly_split3_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_attention_f32": (c_int, [_P, c_long, c_int, _P, _P, c_long, c_long, c_int, _P, c_int, _P, c_long, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, _P]),
@@ -74,7 +75,7 @@ _SIGS = {
     "vly_embed_splice_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 6
+ABI_VERSION = 7
 # include/valley_hip.h "EXPERIMENTAL entry points": exported by libvalley_hip_exp.so only (VALLEY_EXPERIMENTAL=1); bound when present
 _SIGS_EXPERIMENTAL = {
     "vly_decode_attention_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),

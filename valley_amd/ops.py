@@ -733,6 +733,24 @@ def gemm(a, w, bias=None, residual=None, epilogue=EPI_NONE, out_dtype=None, out=
     return gemm_streamk(a, w, bias, residual, epilogue, out_dtype, out, t)
 
 
+def gemm_tiles_tuned(a, w, bias=None, residual=None, out=None):
+    """gemm() restricted to the whole-tile kernels (no stream-K, no skinny, no GEMV): for operands that exist in the block-ordered
+    layout only — the split-operand images of the fp32 engines (ops_f32, VALLEY_F32_GEMM=x3).  Plain epilogue, fp32 or 16-bit out."""
+    M = a.shape[0]
+    N, K = w.shape
+    assert out is not None
+    if GEMM_MODE != "tuned" or M <= 8:
+        return gemm_mfma(a, w, bias, residual, EPI_NONE, out.dtype, out, 0)
+    key = _tune_key(M, N, K, EPI_NONE, out.dtype, bias is not None, residual is not None, w) + ("tiles",)
+    choice = _TUNED.get(key)
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing() or _no_trials():
+            choice = ("tile", 0)
+        else:
+            return _online_trial(key, a, w, bias, residual, EPI_NONE, out.dtype, out, candidates=[c for c in CANDIDATES if c[0] == "tile"])[0]
+    return gemm_mfma(a, w, bias, residual, EPI_NONE, out.dtype, out, choice[1])
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_f32: bool = False,
               out: Optional[torch.Tensor] = None):
     _chk(x, torch.float32, "x")

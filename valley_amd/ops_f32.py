@@ -6,15 +6,105 @@ from typing import Optional
 
 import torch
 
+import os
+
 from . import lib as _lib
+from . import runtime
 from .ops import EPI_NONE, EPI_SWIGLU, POOL_MEAN, _chk, _ptr, _stream
 
 F32 = torch.float32
 
+# How the fp32 engines contract (VALLEY_F32_GEMM, or set_gemm_mode):
+#   "exact" (default): vly_gemm_f32 — fp32 operands on the exact f32-input MFMA (1/16 of the 16-bit MFMA rate);
+#   "x3": SPLIT OPERANDS — every fp32 operand as a 16-bit pair hi + lo, three partial products (hi.hi + hi.lo + lo.hi) as ONE
+#         vly_gemm_bf16 over 3 K with fp32 accumulation and fp32 output (include/valley_hip.h: vly_split3_f32).  ~2^-16 relative per
+#         term instead of 2^-24: the engine that keeps logits within 1e-3 of the fp32 reference at a third of the production rate
+#         (VERDICT r5 #3).  Everything that is not a GEMM (norms, attention, RoPE, softmax, pooling) stays on the fp32 kernels.
+GEMM_MODE = os.environ.get("VALLEY_F32_GEMM", "exact").lower()
+if GEMM_MODE not in ("exact", "x3"):
+    raise ValueError(f"VALLEY_F32_GEMM must be exact or x3, got {GEMM_MODE!r}")
+X3_MIN_N = 256          # narrower GEMMs (the v2 pooling score, N = 1) stay on vly_gemm_f32
 
-def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         epilogue: int = EPI_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual, fp32 operands on the exact f32 MFMA."""
+
+def set_gemm_mode(mode: str) -> None:
+    global GEMM_MODE
+    if mode not in ("exact", "x3"):
+        raise ValueError(mode)
+    GEMM_MODE = mode
+
+
+class X3Act:
+    """The fp32 PRE-activation output of a split-operand GEMM whose activation (quick_gelu | ReLU | SwiGLU) is applied by the next
+    GEMM's operand split — one pass over the tensor instead of three.  Deliberately not a tensor: only gemm() may consume it."""
+
+    def __init__(self, pre: torch.Tensor, epilogue: int):
+        self.pre, self.epilogue = pre, epilogue
+        M, N = pre.shape
+        self.shape = (M, N // 2 if epilogue == EPI_SWIGLU else N)
+
+    def materialize(self) -> torch.Tensor:
+        """fp32 activated tensor (callers other than gemm(): tests)."""
+        x = self.pre
+        if self.epilogue == EPI_SWIGLU:
+            return x[:, 0::2] / (1 + torch.exp(-x[:, 0::2])) * x[:, 1::2]
+        return torch.relu(x) if self.epilogue == 3 else x / (1 + torch.exp(-1.702 * x))
+
+
+_X3_WEIGHTS = {}        # id(fp32 weight tensor) -> (weakref to it, its version, its [hi | lo | hi] image in the tile kernels' block layout)
+
+
+def _split3(x: torch.Tensor, K: int, epilogue: int, order: int) -> torch.Tensor:
+    M = x.shape[0]
+    Kp = (K + 63) // 64 * 64
+    out = torch.empty((M, 3 * Kp), dtype=runtime.HALF, device=x.device)
+    rc = _lib.load().vly_split3_f32(x.data_ptr(), x.stride(0), out.data_ptr(), M, K, Kp, epilogue, order, _stream())
+    _lib.check(rc, "vly_split3_f32")
+    return out
+
+
+def _x3_weight(w: torch.Tensor):
+    from . import ops
+    import weakref
+    key = id(w)
+    hit = _X3_WEIGHTS.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    w3 = _split3(w if w.stride(0) % 4 == 0 else w.contiguous(), w.shape[1], EPI_NONE, 1)
+    pw = ops.PackedWeight(w3)
+    pw.plain = None                                          # (only the block-ordered copy is read: 6 bytes per parameter)
+    del w3
+    _X3_WEIGHTS[key] = (weakref.ref(w, lambda _r, k=key: _X3_WEIGHTS.pop(k, None)), w._version, pw)   # (dies with the tensor: ids are reused)
+    return pw
+
+
+def _gemm_x3(a, w, bias, residual, epilogue, out):
+    from . import ops
+    K = w.shape[1]
+    if isinstance(a, X3Act):
+        a3 = _split3(a.pre, K, a.epilogue, 0)
+    else:
+        a3 = _split3(a, K, EPI_NONE, 0)
+    pw = _x3_weight(w)
+    M, N = a3.shape[0], w.shape[0]
+    if epilogue == EPI_NONE:
+        if out is None:
+            out = torch.empty((M, N), dtype=F32, device=a3.device)
+        ops.gemm_tiles_tuned(a3, pw, bias, residual, out)
+        return out
+    assert residual is None and out is None
+    pre = torch.empty((M, N), dtype=F32, device=a3.device)
+    ops.gemm_tiles_tuned(a3, pw, bias, None, pre)
+    return X3Act(pre, epilogue)
+
+
+def gemm(a, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_NONE, out: Optional[torch.Tensor] = None):
+    """out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias) + residual, fp32 operands: on the exact f32 MFMA, or (GEMM_MODE "x3") as three 16-bit
+    partial products — then a call with an activation returns an X3Act that only the next gemm() may consume."""
+    if GEMM_MODE == "x3" and w.shape[0] >= X3_MIN_N and w.shape[1] % 4 == 0 and runtime.HALF == torch.bfloat16:
+        return _gemm_x3(a, w, bias, residual, epilogue, out)
+    if isinstance(a, X3Act):
+        a = a.materialize().contiguous()
     _chk(a, F32, "a", contiguous=False)
     _chk(w, F32, "w", contiguous=False)
     M, K = a.shape
