@@ -79,6 +79,42 @@ def test_vit_attention_f32():
     assert maxabs(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,S,heads,hd,causal,nz,past", [(2, 75, 2, 64, 0, 0, 0), (2, 75, 2, 64, 1, 5, 0), (3, 257, 16, 64, 0, 0, 0), (2, 75, 2, 128, 0, 0, 0),
+                                                       (2, 336, 4, 128, 1, 11, 0), (1, 16, 1, 128, 0, 3, 0), (2, 64, 2, 128, 1, 0, 0), (2, 40, 2, 128, 1, 7, 100)])
+def test_attention_f32_on_the_f32_mfma(B, S, heads, hd, causal, nz, past):
+    """vly_attention_f32 with 16 queries or more = the tiled kernel on v_mfma_f32_16x16x4_f32 (round 6): head dims 64 / 128, causal or not,
+    invalid leading keys (left padding), a past, query counts that are not multiples of the 64-query workgroup — against fp64 softmax
+    attention, and bit-identical from run to run (the wave-private P strip is fenced)."""
+    from valley_amd import lib as _lib
+    L = _lib.load()
+    ctx = 512
+    n_kv = past + S
+    q, k, v = rnd((B, S, heads, hd), 1).to(D), rnd((B, heads, ctx, hd), 2).to(D), rnd((B, heads, ctx, hd), 3).to(D)
+    valid = torch.ones((B, ctx), dtype=torch.uint8, device=D)
+    valid[0, :nz] = 0
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, S, heads, hd), float("nan"), device=D)
+        rc = L.vly_attention_f32(q.data_ptr(), S * heads * hd, heads * hd, k.data_ptr(), v.data_ptr(), heads * ctx * hd, ctx * hd, hd,
+                                 valid.data_ptr() if nz else None, ctx, out.data_ptr(), S * heads * hd, heads * hd, B, heads, S, n_kv, hd,
+                                 causal, past, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    s = (q.cpu().transpose(1, 2).double() @ k.cpu()[:, :, :n_kv].double().transpose(-1, -2)) * hd ** -0.5
+    allowed = torch.ones((B, 1, S, n_kv), dtype=torch.bool)
+    if causal:
+        allowed = allowed & (torch.arange(n_kv)[None, :] <= torch.arange(S)[:, None] + past)[None, None]
+    allowed = allowed & valid.cpu()[:, None, None, :n_kv].bool()
+    p = torch.softmax(torch.where(allowed, s, torch.tensor(-1e30, dtype=torch.float64)), -1)
+    ref = (p @ v.cpu()[:, :, :n_kv].double()).transpose(1, 2)
+    seen = allowed.any(-1).transpose(1, 2)[..., None]                    # fully masked query rows: zeros by contract
+    assert float((outs[0].double() * (~seen)).abs().max()) == 0.0
+    e = float(((outs[0].double() - ref).abs() * seen).max())
+    print(f"attention_f32 (MFMA) B{B} S{S} heads{heads} hd{hd} causal{causal} invalid{nz} past{past}: max err {e:.1e}")
+    assert e < 5e-6
+
+
 @pytest.mark.parametrize("B,S,past,heads,pad", [(2, 75, 0, 2, 9), (1, 130, 0, 3, 0), (2, 1, 130, 2, 5), (1, 40, 100, 2, 0)])
 def test_rope_and_llama_attention_f32(B, S, past, heads, pad):
     from valley_amd import ops_f32 as F

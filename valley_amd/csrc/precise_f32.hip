@@ -13,6 +13,8 @@
 //   vly_patchify_f32      im2col of the 14x14 patch conv                                              hf:clip 148-154
 //   vly_pool_tokens_f32   temporal mean / max / importance pooling + CLS pick                         valley_model.py:206-215,113-121
 //   vly_embed_splice_f32  embedding gather + visual-token splice by row map                           valley_model.py:160,195-247
+#include <cstdlib>
+#include <cstring>
 #include "common.hpp"
 #include "../../include/valley_hip.h"
 
@@ -144,6 +146,137 @@ __global__ void __launch_bounds__(64) attention_f32_kernel(const float* __restri
     float* o = O + b * o_bs + (size_t)qi * o_rs + h * HD;
     o[lane] = o0 * inv;
     if (HD > 64) o[lane + 64] = o1 * inv;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Attention on the exact f32-input MFMA (round 6: the one-wave-per-query kernel above was 48 % of a step of the split-operand
+// engine).  A workgroup = 64 queries of one (batch, head), 16 per wave; keys in tiles of 64 staged in LDS as fp32.
+//   S^T = K Q^T  (v_mfma_f32_16x16x4_f32: A = K[key r][k], B = Q^T[k][query r]) so that lane (g, r) ends up with the scores of ONE
+//   query r for keys 16 blk + 4 g + e: the softmax statistics of a query live in 4 lanes (xor 16, xor 32);
+//   O^T = V^T P^T (A = V^T[d r][key], B = P^T[key][query r]): the lane's accumulators again belong to query r — rescaling is per lane.
+// The contraction index is permuted so that a lane's operands are contiguous: in K step ks lane group g takes d = g HD/4 + ks (QK^T)
+// and key = 16 g + ks (PV); P goes through a per-wave LDS strip [query][key] to change owner.  Every product and sum is an fp32
+// fma (the MFMA is bit-for-bit an fmaf chain); the order of summation differs from the scalar kernel, nothing else.
+template <int HD>
+__global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __restrict__ Q, long q_bs, int q_rs, const float* __restrict__ Kp,
+                                                                 const float* __restrict__ Vp, long kv_bs, long kv_hs, int kv_rs,
+                                                                 const uint8_t* __restrict__ key_valid, int kv_valid_stride,
+                                                                 float* __restrict__ O, long o_bs, int o_rs, int n_q, int n_kv, int causal,
+                                                                 int past, float scale) {
+    constexpr int KS = HD / 4, LDK = HD + 4, LDP = 68;                   // K steps of QK^T; padded LDS rows (floats)
+    __shared__ __attribute__((aligned(16))) float sK[64 * LDK], sV[64 * LDK], sP[4][16 * LDP];
+    __shared__ __attribute__((aligned(16))) int sOk[64];                 // key k0 + row exists and is valid (branch-free masking below)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z, qb0 = blockIdx.x * 64, qi = qb0 + wave * 16 + r;
+    const bool q_ok = qi < n_q;
+    float q[KS];
+    {
+        const float* qp = Q + b * q_bs + (size_t)min(qi, n_q - 1) * q_rs + h * HD + g * KS;
+#pragma unroll
+        for (int k = 0; k < KS; k += 4) {
+            const f32x4 t = *(const f32x4*)(qp + k);
+            q[k] = t[0] * scale; q[k + 1] = t[1] * scale; q[k + 2] = t[2] * scale; q[k + 3] = t[3] * scale;
+        }
+    }
+    const float* kb = Kp + b * kv_bs + h * kv_hs;
+    const float* vb = Vp + b * kv_bs + h * kv_hs;
+    const uint8_t* valid = key_valid ? key_valid + (size_t)b * kv_valid_stride : nullptr;
+    const int my_last = causal ? min(n_kv - 1, qi + past) : n_kv - 1;                       // keys 0 .. my_last are visible to this query
+    const int blk_last = causal ? min(n_kv - 1, min(qb0 + 63, n_q - 1) + past) : n_kv - 1;  // ... to any query of the workgroup
+    f32x4 o[HD / 16];
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int k0 = 0; k0 <= blk_last; k0 += 64) {
+        __syncthreads();                                                  // the previous tile's readers are done
+        for (int s = tid; s < 64 * (HD / 4); s += 256) {                  // K and V rows k0 .. k0 + 63 (zeros past the end)
+            const int row = s / (HD / 4), c4 = (s % (HD / 4)) * 4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (k0 + row < n_kv) {
+                kv = *(const f32x4*)(kb + (size_t)(k0 + row) * kv_rs + c4);
+                vv = *(const f32x4*)(vb + (size_t)(k0 + row) * kv_rs + c4);
+            }
+            *(f32x4*)(sK + row * LDK + c4) = kv;
+            *(f32x4*)(sV + row * LDK + c4) = vv;
+        }
+        if (tid < 64) sOk[tid] = (k0 + tid < n_kv && (!valid || valid[min(k0 + tid, n_kv - 1)])) ? 1 : 0;
+        __syncthreads();
+        // ---- S^T: 4 key blocks x KS K steps
+        f32x4 sc[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            sc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* kr = sK + (blk * 16 + r) * LDK + g * KS;
+#pragma unroll
+            for (int k = 0; k < KS; k += 4) {
+                const f32x4 a = *(const f32x4*)(kr + k);
+                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], q[k], sc[blk], 0, 0, 0);
+                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], q[k + 1], sc[blk], 0, 0, 0);
+                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], q[k + 2], sc[blk], 0, 0, 0);
+                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], q[k + 3], sc[blk], 0, 0, 0);
+            }
+        }
+        // ---- mask, online softmax of query r (its 64 scores sit in 4 lanes x 16 registers)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int ok4[4] = {sOk[blk * 16 + 4 * g], sOk[blk * 16 + 4 * g + 1], sOk[blk * 16 + 4 * g + 2], sOk[blk * 16 + 4 * g + 3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + blk * 16 + 4 * g + e;
+                const int vis = (q_ok ? 1 : 0) & (key <= my_last ? 1 : 0) & ok4[e];
+                sc[blk][e] = vis ? sc[blk][e] : -INFINITY;
+                mx = fmaxf(mx, sc[blk][e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = (m_run == -INFINITY || m_new == -INFINITY) ? 0.f : expf(m_run - m_new);
+        float ps = 0.f;
+        float* pw = &sP[wave][r * LDP + 4 * g];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4 p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p[e] = sc[blk][e] == -INFINITY ? 0.f : expf(sc[blk][e] - m_new);
+                ps += p[e];
+            }
+            *(f32x4*)(pw + blk * 16) = p;                                 // P[query r][key 16 blk + 4 g + e]
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * corr + ps;
+        if (m_new != -INFINITY) m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) o[d] *= corr;
+        // ---- O^T += V^T P^T: K step ks of lane group g is key 16 g + ks
+        float pb[16];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // P: written and read by the same wave, other lanes
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const float* pr = &sP[wave][r * LDP + 16 * g];
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                const f32x4 t = *(const f32x4*)(pr + k);
+                pb[k] = t[0]; pb[k + 1] = t[1]; pb[k + 2] = t[2]; pb[k + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) {
+            const float* vr = sV + (16 * g) * LDK + d * 16 + r;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[k * LDK], pb[k], o[d], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;               // a fully masked (padded) query row yields zeros
+        float* op = O + b * o_bs + (size_t)qi * o_rs + h * HD + 4 * g;
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) *(f32x4*)(op + d * 16) = o[d] * inv;
+    }
 }
 
 // LayerNorm (beta != null) / RMSNorm (rms != 0): wave per row, fp32 statistics over the whole row.
@@ -356,8 +489,23 @@ extern "C" int vly_attention_f32(const float* q, long q_batch_stride, int q_row_
         return -22;
     }
     const float scale = 1.f / sqrtf((float)head_dim);
-    dim3 grid(n_q, heads, B), block(64);
     hipStream_t st = (hipStream_t)stream;
+    // 16 queries or more per (batch, head): the tiled kernel on the f32-input MFMA (VLY_ATTN_F32=scalar keeps the one-wave-per-query form)
+    static const bool scalar_only = getenv("VLY_ATTN_F32") && !strcmp(getenv("VLY_ATTN_F32"), "scalar");
+    if (n_q >= 16 && !scalar_only && q_row_stride % 4 == 0 && q_batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+        !((uintptr_t)q & 15) && !((uintptr_t)out & 15)) {
+        dim3 grid((n_q + 63) / 64, heads, B), block(256);
+        if (head_dim == 64)
+            hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+                               kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
+                               causal, past_len, scale);
+        else
+            hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+                               kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
+                               causal, past_len, scale);
+        return vly_check_launch("vly_attention_f32");
+    }
+    dim3 grid(n_q, heads, B), block(64);
     if (head_dim == 64)
         hipLaunchKernelGGL((attention_f32_kernel<64>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
                            kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
