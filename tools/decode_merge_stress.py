@@ -26,7 +26,7 @@ for mode in ("oproj", "attn"):
     cache.seq_len = 0
     ll.forward(x.clone(), B, S, cache)
     s = decode.DecodeSession(ll, cache, use_graph=True)
-    s.begin(torch.tensor([3, 7][:B], device="cuda"))
+    s.begin(torch.tensor([3, 7, 11, 13, 17, 19, 23, 29][:B], device="cuda"))
     sess.append(s)
 bad = 0
 for it in range(steps):

@@ -26,6 +26,12 @@ constexpr float NEG_BIG = -1.0e30f;
 // rescale (v_cmp + 2 v_cndmask + v_add + v_exp + v_ldexp: six instructions, 396 of the ViT kernel's 978 VALU
 // instructions per query tile); the bare instruction flushes results below 2^-126 to zero, which is exactly what a
 // softmax weight that small is worth (VLY_FAST_EXP2=0 restores the library call for A/B builds).
+#ifndef VLY_DECODE_MERGE_FENCE
+#define VLY_DECODE_MERGE_FENCE 0    // 1: release / acquire fences around the merged decode attention's ticket (see split_merge_if_last)
+#endif
+#ifndef VLY_VIT_STORE_LINES
+#define VLY_VIT_STORE_LINES 0       // 1: the ViT kernel's outputs leave as whole 128-byte lines (measured equal, bit-identical: profiles/r06/r06_vit_attn_store_lines.txt)
+#endif
 #ifndef VLY_FAST_EXP2
 #define VLY_FAST_EXP2 1
 #endif
@@ -237,11 +243,28 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
                     const auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
                     y[w][0] = q0[0]; y[w][1] = q1[0]; y[w][2] = q0[1]; y[w][3] = q1[1];
                 }
+#if VLY_VIT_STORE_LINES
+                // Whole 128-byte lines per store instruction (round 6): a lane's 32-byte run is two 16-byte pieces A (d = 16 g ..) and
+                // B (d = 16 g + 8 ..); B goes to the lane of row l15 ^ 8 (row_ror:8), and then instruction 1 writes rows 0-7 of the
+                // tile (lanes l15 < 8: their A; lanes l15 >= 8: the B of row l15 - 8) and instruction 2 rows 8-15 — 8 rows x 128 B
+                // each instead of 16 rows x 64 B twice.  Same bytes, same values.
+                const u32x4 pa = {y[0][0], y[1][0], y[0][1], y[1][1]}, pb = {y[0][2], y[1][2], y[0][3], y[1][3]};
+                u32x4 px;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) px[i] = __builtin_amdgcn_update_dpp(0u, pb[i], 0x128, 0xf, 0xf, false);     // row_ror:8
+                const bool lo8 = l15 < 8;
+                const int q1 = lo8 ? q : q - 8, q2 = lo8 ? q + 8 : q;
+                uint16_t* ob = out + (size_t)f * VN * 1024 + h * 64 + 16 * g;
+                if (q1 < VN) *(u32x4*)(ob + (size_t)q1 * 1024 + (lo8 ? 0 : 8)) = lo8 ? pa : px;
+                if (q2 < VN) *(u32x4*)(ob + (size_t)q2 * 1024 + (lo8 ? 8 : 0)) = lo8 ? px : pa;
+                (void)op;
+#else
                 if (q < VN) {
                     u32x4* dst = (u32x4*)(op + 16 * g);
                     dst[0] = u32x4{y[0][0], y[1][0], y[0][1], y[1][1]};
                     dst[1] = u32x4{y[0][2], y[1][2], y[0][3], y[1][3]};
                 }
+#endif
             }
         }
     }
@@ -690,9 +713,20 @@ VLY_DEVICE void split_merge_if_last(const float* __restrict__ partials, uint16_t
     __syncthreads();
     unsigned* ctr = arrivals + (size_t)b * heads + h;
     if (threadIdx.x == 0) {
+#if VLY_DECODE_MERGE_FENCE
+        // the memory-model form of the same hand-off (VERDICT r5 #8 / cdna_hip_programming Guideline 16): agent-scope release, the
+        // wait restated where hipcc cannot drop it, THEN the ticket; the merging workgroup acquires below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag_lds[0] = t == VLY_DECODE_SPLITS - 1 ? 1.f : 0.f;
-        if (t == VLY_DECODE_SPLITS - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == VLY_DECODE_SPLITS - 1) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if VLY_DECODE_MERGE_FENCE
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        }
     }
     __syncthreads();
     if (flag_lds[0] == 0.f || threadIdx.x >= 32) return;
@@ -745,7 +779,11 @@ __global__ void __launch_bounds__(256) decode_split_kernel(const uint16_t* __res
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float acc_s[16][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    // grid (heads, B, SPLITS): a head's splits are heads x B block ids apart — a multiple of 8 for every model of the path, i.e. on ONE
+    // XCD (block id % 8).  gridDim.x == SPLITS marks the stress order (VLY_DECODE_SPLIT_SPREAD=1: grid (SPLITS, heads, B)): the four
+    // splits of a head on four DIFFERENT XCDs, the placement the ticket hand-off must also survive (tools/decode_merge_stress.py)
+    const bool spread = gridDim.z != VLY_DECODE_SPLITS;
+    const int h = spread ? blockIdx.y : blockIdx.x, b = spread ? blockIdx.z : blockIdx.y, sp = spread ? blockIdx.x : blockIdx.z;
     const int Hq = heads * 128;
     if (past_dev) past = min(past_dev[(size_t)b * past_row_stride], ctx_max - 1);
     const int pos = past, kv_len = past + 1;
@@ -1114,7 +1152,10 @@ static int decode_split_launch(const char* name, const void* qkv, void* kcache, 
         vly_set_error("%s: key_valid_stride %d too short", name, key_valid_stride);
         return -22;
     }
-    hipLaunchKernelGGL(decode_split_kernel, dim3(heads, B, VLY_DECODE_SPLITS), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+    static const bool spread = getenv("VLY_DECODE_SPLIT_SPREAD") && atoi(getenv("VLY_DECODE_SPLIT_SPREAD")) != 0 && VLY_DECODE_SPLITS != 1;
+    // (the stress order needs B != SPLITS to be told apart by the kernel: B = 4 keeps the production order)
+    const dim3 grid = spread && B != VLY_DECODE_SPLITS ? dim3(VLY_DECODE_SPLITS, heads, B) : dim3(heads, B, VLY_DECODE_SPLITS);
+    hipLaunchKernelGGL(decode_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
                        (uint16_t*)kcache, (uint16_t*)vcache, cos_table, sin_table, key_valid, partials, heads, past_len, past_len_dev,
                        key_valid_stride, ctx_max, past_len_dev_stride, (uint16_t*)merged, arrivals);
     return vly_check_launch(name);
