@@ -28,8 +28,7 @@ def test_experimental_library_suite():
 def test_shipped_library_has_no_experimental_exports():
     import ctypes
     from valley_amd import build, lib
-    assert not lib.EXPERIMENTAL and not lib.experimental()
-    shipped = ctypes.CDLL(build.LIB)
+    shipped = ctypes.CDLL(build.LIB)                        # (whatever VALLEY_EXPERIMENTAL says about the library this process loaded)
     for name in lib._SIGS_EXPERIMENTAL:
         assert not hasattr(shipped, name), name
     exp = ctypes.CDLL(build.LIB_EXP)

@@ -15,3 +15,12 @@ def test_named_accumulators_are_never_touched_by_the_compiler():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "12 kernels with accumulators by name audited, 0 findings" in r.stdout, r.stdout[-2000:]
+
+
+def test_round6_kernels_with_named_accumulators_are_audited_too():
+    """gemm_p32_kernel / gemm_p16_kernel (round 6) own a0 .. a255 the same way; valley_amd.build audits every library it compiles
+    (valley_amd/agpr_audit.py) — this is the command-line form on both sources, bf16 and fp16 storage."""
+    for args, n in ((["--p16"], 4), (["--p16", "-DVLY_FP16=1"], 4), (["--p32"], 8)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "agpr_audit.py"), *args], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert f"{n} kernels with accumulators by name audited, 0 findings" in r.stdout, r.stdout[-2000:]

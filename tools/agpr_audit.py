@@ -1,88 +1,30 @@
 #!/usr/bin/env python3
-"""Audit of the kernels that own their accumulation registers BY NAME (gemm_p4_kernel's rolled instantiations, gemm_bf16.hip
-"accumulators by name"): in the ISA hipcc emits for them, no instruction OUTSIDE an inline-asm block may name an accumulation
-register — the compiler has no value there, and a spill or copy of its own into a0..a255 would silently corrupt a tile.  Also
-required: no scratch, no spilled registers.  Usage: agpr_audit.py [--p32 | --p16] [-Dflags ...]   (exit code 1 on any finding)"""
+"""Command-line form of valley_amd/agpr_audit.py (the build runs the same audit on every library it produces): compiles one of the
+by-name kernels' sources with the given flags and audits the ISA.
+Usage: agpr_audit.py [--p32 | --p16] [-Dflags ...]   (exit code 1 on any finding)"""
 import os
-import re
 import subprocess
 import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "valley_amd", "csrc", "gemm_bf16.hip")
+sys.path.insert(0, ROOT)
+from valley_amd.agpr_audit import AUDITED, audit_asm  # noqa: E402
 
 
 def main():
     flags = sys.argv[1:]
-    src, kern = SRC, "gemm_p4_kernel"
-    if "--p32" in flags:                                     # the 32x32x16 persistent kernel (gemm_p32.hip): every instantiation is by name
-        flags.remove("--p32")
-        src, kern = os.path.join(ROOT, "valley_amd", "csrc", "gemm_p32.hip"), "gemm_p32_kernel"
-    if "--p16" in flags:                                     # the 16x16x32 chains-of-two persistent kernel (gemm_p16.hip)
-        flags.remove("--p16")
-        src, kern = os.path.join(ROOT, "valley_amd", "csrc", "gemm_p16.hip"), "gemm_p16_kernel"
-    stem = os.path.basename(src)[:-4]
+    unit = "gemm_bf16.hip"
+    for opt, u in (("--p32", "gemm_p32.hip"), ("--p16", "gemm_p16.hip")):
+        if opt in flags:
+            flags.remove(opt)
+            unit = u
+    src = os.path.join(ROOT, "valley_amd", "csrc", unit)
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-save-temps", "-c", src,
                                "-o", os.path.join(td, "g.o")], cwd=td, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(td, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
-    bad = 0
-    kernels = 0
-    i = 0
-    areg = re.compile(r"\ba(\[(\d+|0x[0-9a-f]+)(:(\d+|0x[0-9a-f]+))?\]|\d+\b)")
-    while i < len(asm):
-        m = re.match(r"^(_ZN\S*" + kern + r"\S*):", asm[i])
-        if not m:
-            i += 1
-            continue
-        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        name = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].replace("void ", "")
-        j = i + 1
-        in_asm = False
-        lit = False                      # does this instantiation name accumulators literally?
-        outside, n_mfma, n_rd, n_mfma_compiler = [], 0, 0, 0
-        while j < len(asm) and "s_endpgm" not in asm[j]:
-            ln = asm[j]
-            if ";;#ASMSTART" in ln:
-                in_asm = True
-            elif ";;#ASMEND" in ln:
-                in_asm = False
-            else:
-                code = ln.split(";")[0]
-                if in_asm:
-                    if "v_mfma" in code:
-                        n_mfma += 1
-                    if "v_accvgpr_read" in code:
-                        n_rd += 1
-                elif areg.search(code) and not code.strip().startswith("."):
-                    outside.append((j - i, code.strip()))
-                    if "v_mfma" in code:
-                        n_mfma_compiler += 1
-                if "scratch_" in code:
-                    outside.append((j - i, code.strip()))
-            j += 1
-        # the kernel descriptor must allocate every accumulation register the asm names (it does so only because of the clobber list
-        # at the kernel's entry): next_free_vgpr - accum_offset >= highest named register + 1
-        named = [int(x, 0) for ln in asm[i:j] for x in re.findall(r"\ba\[(?:\d+|0x[0-9a-f]+):(\d+|0x[0-9a-f]+)\]", ln.split(";")[0])]
-        desc = "\n".join(asm[j:j + 120])
-        nf = re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", desc)
-        ao = re.search(r"\.amdhsa_accum_offset\s+(\d+)", desc)
-        lit = n_mfma > 0 and n_mfma_compiler == 0 and "v_mfma" not in "\n".join(c for _, c in outside)
-        if lit and named and nf and ao and int(nf.group(1)) - int(ao.group(1)) < max(named) + 1:
-            outside.append((0, f"descriptor allocates {int(nf.group(1)) - int(ao.group(1))} accumulation registers, the asm names a{max(named)}"))
-        if lit and not (nf and ao):
-            outside.append((0, "kernel descriptor not found behind the kernel"))
-        if n_mfma_compiler:              # the compiler manages this kernel's accumulators (builtin MFMAs): not audited
-            lit = False
-        if lit:
-            kernels += 1
-            status = "ok" if not outside else "FAIL"
-            print(f"{name:48s} mfma {n_mfma:4d}  acc reads {n_rd:4d}  compiler AGPR / scratch instructions: {len(outside)}  {status}")
-            for off, code in outside[:8]:
-                print(f"    +{off}: {code}")
-            bad += len(outside)
-        i = j
+        report, kernels, bad = audit_asm(os.path.join(td, unit[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s"), AUDITED[unit])
+    print("\n".join(report))
     print(f"{kernels} kernels with accumulators by name audited, {bad} findings")
     return 1 if bad or not kernels else 0
 

@@ -19,6 +19,9 @@ EXP_UNITS = ["decode_step.hip", "attention.hip", "gemm_bf16.hip", "gemv_bf16.hip
 SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_p32.hip", "gemm_p16.hip", "gemm_streamk.hip", "norm_elementwise.hip", "attention.hip", "temporal_delta.hip", "preprocess.hip", "gemv_bf16.hip", "precise_f32.hip", "gemm_skinny.hip", "decode_step.hip"]
 
 
+MAX_PARALLEL = max(2, min(8, (os.cpu_count() or 4)))     # hipcc processes at once (a clean build used to launch ~30: ADVICE r5)
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -48,7 +51,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     variants = [(LIB, LIBDIR, [], SOURCES), (LIB_F16, os.path.join(LIBDIR, "f16"), ["-DVLY_FP16=1"], SOURCES),
                 (LIB_EXP, os.path.join(LIBDIR, "exp"), ["-DVLY_EXPERIMENTAL=1"], EXP_UNITS),
                 (LIB_EXP_F16, os.path.join(LIBDIR, "exp_f16"), ["-DVLY_EXPERIMENTAL=1", "-DVLY_FP16=1"], EXP_UNITS)]
-    procs = []
+    try:
+        from .agpr_audit import AUDITED, audit_asm
+    except ImportError:                                                   # (run as a script: python valley_amd/build.py)
+        sys.path.insert(0, HERE)
+        from agpr_audit import AUDITED, audit_asm
+    jobs, audits = [], []
     # a translation unit is recompiled when its own source, a shared header (*.hpp, *.inc, valley_hip.h) or this recipe is newer than
     # its object — editing one kernel file costs one compile per library, not twenty-two
     shared = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip")] + \
@@ -59,16 +67,43 @@ def build(force: bool = False, verbose: bool = True) -> str:
             o = os.path.join(odir, s.replace(".hip", ".o"))
             if not force and os.path.exists(o) and os.path.getmtime(o) >= max(t_shared, os.path.getmtime(os.path.join(CSRC, s))):
                 continue
-            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c", os.path.join(CSRC, s), "-o", o]
+            # the units whose kernels hold accumulation registers by name keep their ISA (-save-temps=obj) for the audit below
+            temps = ["-save-temps=obj"] if s in AUDITED else []
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, *temps, "-c", os.path.join(CSRC, s), "-o", o]
+            jobs.append((s, cmd))
+            if s in AUDITED:
+                audits.append((s, odir, " ".join(flags) or "(default flags)"))
+    running = []
+    while jobs or running:
+        while jobs and len(running) < MAX_PARALLEL:
+            s, cmd = jobs.pop(0)
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for s, p in procs:
+            running.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        s, p = running.pop(0)
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
+    # every library that was (re)compiled: no compiler-made access to the accumulation registers the kernels own by name
+    for s, odir, what in audits:
+        stem = os.path.join(odir, s[:-4])
+        asm = stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"
+        report, kernels, bad = audit_asm(asm, AUDITED[s])
+        for ext in ("-hip-amdgcn-amd-amdhsa-gfx950.s", "-hip-amdgcn-amd-amdhsa-gfx950.bc", "-hip-amdgcn-amd-amdhsa-gfx950.hipi",
+                    "-hip-amdgcn-amd-amdhsa-gfx950.o", "-hip-amdgcn-amd-amdhsa-gfx950.out", "-hip-amdgcn-amd-amdhsa-gfx950.out.resolution.txt",
+                    "-host-x86_64-unknown-linux-gnu.bc", "-host-x86_64-unknown-linux-gnu.hipi", "-host-x86_64-unknown-linux-gnu.s",
+                    ".hip-hip-amdgcn-amd-amdhsa.hipfb"):
+            try:
+                os.remove(stem + ext)
+            except OSError:
+                pass
+        if verbose:
+            print(f"agpr audit {s} [{what}]: {kernels} kernels by name, {bad} findings")
+        if bad or not kernels:
+            os.remove(os.path.join(odir, s.replace(".hip", ".o")))         # (never link, never ship, recompile next time)
+            raise RuntimeError(f"accumulation-register audit failed for {s} [{what}]:\n" + "\n".join(report))
     for lib, odir, _flags, units in variants:
         base = os.path.join(LIBDIR, "f16") if "-DVLY_FP16=1" in _flags else LIBDIR      # the units a variant does not recompile
         objs = [os.path.join(odir if s in units else base, s.replace(".hip", ".o")) for s in SOURCES]

@@ -342,6 +342,9 @@ __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __r
     };
     // fragment reads: row l15, chunk (4 step + g) ^ (l15 & 7)
     const int rd0 = l15 * 128 + (((0 + g) ^ (l15 & 7)) << 4), rd1 = l15 * 128 + (((4 + g) ^ (l15 & 7)) << 4);
+    // the activation piece holds 8 rows unless FOUR_K stages two: columns m >= 8 of the MFMA read row m & 7 again (their results are
+    // dropped below) instead of running 1 KB past the slot
+    const int ra0 = two_a ? rd0 : (l15 & 7) * 128 + (((0 + g) ^ (l15 & 7)) << 4), ra1 = two_a ? rd1 : (l15 & 7) * 128 + (((4 + g) ^ (l15 & 7)) << 4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int P = K >> KSH;
     const int n = (P - wave + NW - 1) / NW;                          // pairs of this wave: p = wave + NW i
@@ -352,6 +355,9 @@ __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __r
     for (int i = 0; i < n; ++i) {
         const int ahead = i + NSLOT - 1;
         if (ahead < n) {
+            // the slot being refilled was read in the PREVIOUS iteration: its ds_reads must have returned before the DMA may land there
+            // (only the order of issue separated them — hipcc is free to sink the MFMAs and their lgkmcnt wait below this asm)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue(wave + NW * ahead, (slot + NSLOT - 1) % NSLOT);
             // pair i has landed when at most the (NSLOT - 1) younger pairs' instructions are outstanding
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NSLOT - 1) * (two_a ? 4 : 3)) : "memory");
@@ -360,7 +366,7 @@ __global__ void __launch_bounds__(NW * 64) gemv_mfma2_kernel(const uint16_t* __r
         }
         const char* s = my + slot * SLOT;
         const bf16x8 w0 = *(const bf16x8*)(s + rd0), w1 = *(const bf16x8*)(s + rd1);
-        const bf16x8 a0 = *(const bf16x8*)(s + 2048 + rd0), a1 = *(const bf16x8*)(s + 2048 + rd1);
+        const bf16x8 a0 = *(const bf16x8*)(s + 2048 + ra0), a1 = *(const bf16x8*)(s + 2048 + ra1);
         acc = mfma16(w0, a0, acc);
         acc = mfma16(w1, a1, acc);
         slot = (slot + 1) % NSLOT;
@@ -416,7 +422,8 @@ int launch_mfma_rows(const void* A, const void* W, const float* bias, const floa
     if (form != 1) {
         // eight-row blocks (HALF8) where sixteen-row blocks leave the CUs unevenly loaded: fewer than three blocks per CU, M <= 8
         static const int half_pin = [] { const char* e = getenv("VLY_GEMV_HALF8"); return e ? atoi(e) : -1; }();     // (A/B runs)
-        const bool half8 = M <= 8 && K % 128 == 0 && (half_pin >= 0 ? half_pin != 0 : (N + 15) / 16 < 3 * cu_count());
+        const bool half8 = M <= 8 && K % 128 == 0 && (half_pin >= 0 ? half_pin != 0 : (N + 15) / 16 < 3 * 256);     // (by SHAPE only, not by the device's CU count:
+                                                                                                                   // the same request sums in the same order on every partition of the GPU — ADVICE r5)
         dim3 g2(half8 ? (N + 7) / 8 : (N + 15) / 16), b2(256);
         // (eight waves per workgroup — one workgroup per CU — measured 3-5 % behind four on the narrow shapes: r05_gemv_rows_v2.txt)
 #define VLY_GEMV_M2(E, O)                                                                                                              \
