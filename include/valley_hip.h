@@ -33,7 +33,7 @@ extern "C" {
 #define VLY_ABI_VERSION 7   /* 2: + the fp32 "precise" entry points (vly_*_f32); 3: + vly_storage_dtype; 4: + vly_gemv_rmsnorm_bf16,
                                vly_decode_attention_split, vly_gemv_attnmerge_bf16; 5: + vly_decode_layers(_supported),
                                vly_decode_attention_merged; 6: vly_decode_layers(_supported) and tile hint 297 moved to the
-                               EXPERIMENTAL library (libvalley_hip_exp.so, section at the end), vly_gemv_bf16 takes M <= 16; 7: + vly_split3_f32,
+                               EXPERIMENTAL library (libvalley_hip_exp.so, section at the end), vly_gemv_bf16 takes M <= 16; 7: + vly_split3_f32, vly_norm_split3_f32,
                                tile hints 397 / 398 / 497 of vly_gemm_bf16 */
 
 /* epilogues of vly_gemm_bf16 */
@@ -401,6 +401,12 @@ int vly_attention_f32(const float *q, long q_batch_stride, int q_row_stride, con
  *   [M,D] -> fp32 [M,D]; y may alias x.  hf:clip/modeling_clip.py:605,642; hf:llama/modeling_llama.py:51-67. */
 int vly_norm_f32(const float *x, const float *gamma, const float *beta, float *y, int M, int D, float eps, int rms,
                  void *stream);
+
+/* vly_norm_f32 fused with vly_split3_f32 (order 0, no activation): out3[M, 3 Kp] = [hi | hi | lo] of LayerNorm / RMSNorm(x) — the GEMM
+ *   operand of the split-operand engine without the fp32 round trip through memory.  hf:clip/modeling_clip.py:605,642;
+ *   hf:llama/modeling_llama.py:51-67. */
+int vly_norm_split3_f32(const float *x, const float *gamma, const float *beta, void *out3_half, int M, int D, int Kp, float eps, int rms,
+                        void *stream);
 
 /* vly_rope_kv with fp32 q|k|v rows [B*S, 3*heads*128] and fp32 caches [B,heads,ctx_max,128] (hf:llama 127-157). */
 int vly_rope_kv_f32(float *qkv, float *kcache, float *vcache, const float *cos_table, const float *sin_table,

@@ -134,6 +134,9 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 #ifndef VLY_P4_LIT
 #define VLY_P4_LIT 1                // 0: accumulators as C++ values everywhere (the round-4 kernel)
 #endif
+#ifndef VLY_P4_LATE
+#define VLY_P4_LATE 0               // 1: barrier B and the next K tile's first fragment reads late in phase 2 (see ktile)
+#endif
 #ifndef VLY_P4_DROPSTORE
 #define VLY_P4_DROPSTORE 0
 #endif
@@ -1159,7 +1162,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         const char* cur = smem + buf * STAGE;
         const char* nxt = smem + (buf ^ 1) * STAGE;
         // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago (VLY_P4_LATE: >= 11)
         if (wave_live)
             phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE, LIT ? (FIRST ? 3 : 2) : 0>(
                 acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
@@ -1168,6 +1171,30 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
             for (int q = 0; q < N1; ++q) piece(buf, q);
         }
+#if VLY_P4_LATE
+        // Round 6: barrier B (the next K tile has landed everywhere) moves from the phase boundary INTO phase 2, and the reads of the next
+        // K tile's first fragments behind it.  A buffer's fragments are then read in [B2_AT of the tile before, 16 of its own] — 0.35 of
+        // a K tile instead of 0.75 — and its refill (from barrier A) has 1.6 K tiles to land instead of 1.3: the K loop's period was the
+        // staging round trip (~2390 cycles: latency + 64 KB at ~36 B/clk per CU, profiles/r06/r06_p32_ablation_*.txt), not the MFMAs.
+        constexpr int B2_AT = T - (MI + NI) - 12;
+        constexpr int NB2 = B2_AT <= GL2_START ? 0 : (B2_AT - GL2_START + GL_STRIDE - 1) / GL_STRIDE < N2 ? (B2_AT - GL2_START + GL_STRIDE - 1) / GL_STRIDE : N2;
+        static_assert(B2_AT > 0 && B2_AT + 1 + MI + NI <= T, "late barrier");
+        auto bar_b = [&](int) {
+            if (ROLL && relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1 + MI * NST_ + NB2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1 + NB2) : "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        if (wave_live)
+            phase_4w4<MI, NI, MI + NI, B2_AT + 1, 1, N2, GL2_START, GL_STRIDE, 1, B2_AT, 1, N2, GL2_START - P4_M0_LEAD, GL_STRIDE, LIT ? 2 : 0>(
+                acc, a1, w1, rd_step0(nxt), [&](int q) { piece_ld(N1 + q); }, bar_b, [&](int q) { piece_m0(buf, N1 + q); });
+        else {
+#pragma unroll
+            for (int q = 0; q < NB2; ++q) piece(buf, N1 + q);
+            bar_b(0);
+#pragma unroll
+            for (int q = NB2; q < N2; ++q) piece(buf, N1 + q);
+        }
+#else
         if (ROLL && relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1 + MI * NST_) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N1) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -1178,6 +1205,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
             for (int q = 0; q < N2; ++q) piece(buf, N1 + q);
         }
+#endif
         advance_load();
         buf ^= 1;
     };

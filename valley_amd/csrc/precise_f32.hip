@@ -302,6 +302,38 @@ __global__ void __launch_bounds__(256) norm_f32_kernel(const float* __restrict__
     }
 }
 
+// The same norm writing the split-operand image [hi | hi | lo] of its result straight away (x3 GEMMs, round 6): the fp32 result never
+// goes to memory — 4 B read + 6 B written per element instead of 4 + 4 (norm) and 4 + 6 (vly_split3_f32).  Same arithmetic as
+// norm_f32_kernel + split3_kernel<NONE>, value for value.
+__global__ void __launch_bounds__(256) norm_split3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, uint16_t* __restrict__ out, int M, int D, int Kp,
+                                                          float eps, int rms) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d];
+    const float mean = rms ? 0.f : wave_sum(s) / D;
+    float v = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float c = xr[d] - mean;
+        v = fmaf(c, c, v);
+    }
+    const float rstd = rsqrtf(wave_sum(v) / D + eps);
+    uint16_t* orow = out + (size_t)row * (3 * Kp);
+    for (int d = lane; d < Kp; d += 64) {
+        float y = 0.f;
+        if (d < D) {
+            const float n = (xr[d] - mean) * rstd;
+            y = rms ? gamma[d] * n : fmaf(n, gamma[d], beta[d]);
+        }
+        const uint16_t hi = f2h(y), lo = f2h(y - h2f(hi));
+        orow[d] = hi;
+        orow[Kp + d] = hi;
+        orow[2 * Kp + d] = lo;
+    }
+}
+
 // rotate-half RoPE of q (in place) and k (into the cache) + v append; one thread per (token, head, d < 64)
 __global__ void __launch_bounds__(256) rope_kv_f32_kernel(float* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc,
                                                           const float* __restrict__ cs, const float* __restrict__ sn, int B, int S,
@@ -522,6 +554,13 @@ extern "C" int vly_norm_f32(const float* x, const float* gamma, const float* bet
     if (M <= 0 || D <= 0 || !gamma || (!rms && !beta)) { vly_set_error("vly_norm_f32: bad args M=%d D=%d", M, D); return -22; }
     hipLaunchKernelGGL(norm_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, M, D, eps, rms);
     return vly_check_launch("vly_norm_f32");
+}
+
+extern "C" int vly_norm_split3_f32(const float* x, const float* gamma, const float* beta, void* out3, int M, int D, int Kp, float eps, int rms,
+                                   void* stream) {
+    if (M <= 0 || D <= 0 || Kp < D || !gamma || (!rms && !beta) || !out3) { vly_set_error("vly_norm_split3_f32: bad args M=%d D=%d Kp=%d", M, D, Kp); return -22; }
+    hipLaunchKernelGGL(norm_split3_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)out3, M, D, Kp, eps, rms);
+    return vly_check_launch("vly_norm_split3_f32");
 }
 
 extern "C" int vly_rope_kv_f32(float* qkv, float* kcache, float* vcache, const float* cos_table, const float* sin_table, int B,

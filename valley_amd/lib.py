@@ -64,6 +64,7 @@ _SIGS = {
                                        c_int, _P]),
     "vly_gemm_skinny_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     # fp32 "precise" path
+    "vly_norm_split3_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "vly_split3_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_gemm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vly_attention_f32": (c_int, [_P, c_long, c_int, _P, _P, c_long, c_long, c_int, _P, c_int, _P, c_long, c_int, c_int, c_int,

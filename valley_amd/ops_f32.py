@@ -50,6 +50,14 @@ class X3Act:
         return torch.relu(x) if self.epilogue == 3 else x / (1 + torch.exp(-1.702 * x))
 
 
+class X3Split:
+    """An activation that exists only as its split-operand image [hi | hi | lo] (norm_for_gemm in x3 mode): gemm() alone consumes it."""
+
+    def __init__(self, a3: torch.Tensor, K: int):
+        self.a3, self.K = a3, K
+        self.shape = (a3.shape[0], K)
+
+
 _X3_WEIGHTS = {}        # id(fp32 weight tensor) -> (weakref to it, its version, its [hi | lo | hi] image in the tile kernels' block layout)
 
 
@@ -80,7 +88,10 @@ def _x3_weight(w: torch.Tensor):
 def _gemm_x3(a, w, bias, residual, epilogue, out):
     from . import ops
     K = w.shape[1]
-    if isinstance(a, X3Act):
+    if isinstance(a, X3Split):
+        assert a.K == K
+        a3 = a.a3
+    elif isinstance(a, X3Act):
         a3 = _split3(a.pre, K, a.epilogue, 0)
     else:
         a3 = _split3(a, K, EPI_NONE, 0)
@@ -105,6 +116,8 @@ def gemm(a, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Opti
         return _gemm_x3(a, w, bias, residual, epilogue, out)
     if isinstance(a, X3Act):
         a = a.materialize().contiguous()
+    if isinstance(a, X3Split):
+        raise TypeError("an X3Split operand reached the exact GEMM: norm_for_gemm() and gemm() must run under the same GEMM_MODE")
     _chk(a, F32, "a", contiguous=False)
     _chk(w, F32, "w", contiguous=False)
     M, K = a.shape
@@ -136,6 +149,21 @@ def norm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps
                                   _stream())
     _lib.check(rc, "vly_norm_f32")
     return y
+
+
+def norm_for_gemm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float, n_out: int):
+    """norm() whose ONLY consumer is the next gemm() (n_out = that GEMM's output width): a tensor in the exact mode; in x3 mode the
+    split-operand image written by the norm kernel itself (vly_norm_split3_f32) — the fp32 result never goes to memory."""
+    if not (GEMM_MODE == "x3" and n_out >= X3_MIN_N and x.shape[1] % 4 == 0 and runtime.HALF == torch.bfloat16):
+        return norm(x, gamma, beta, eps)
+    _chk(x, F32, "x")
+    M, D = x.shape
+    Kp = (D + 63) // 64 * 64
+    out = torch.empty((M, 3 * Kp), dtype=runtime.HALF, device=x.device)
+    rc = _lib.load().vly_norm_split3_f32(x.data_ptr(), gamma.data_ptr(), _ptr(beta), out.data_ptr(), M, D, Kp, eps, 0 if beta is not None else 1,
+                                         _stream())
+    _lib.check(rc, "vly_norm_split3_f32")
+    return X3Split(out, D)
 
 
 def vit_attention(qkv: torch.Tensor, F: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -121,10 +121,10 @@ class PreciseCLIPVisionTower:
                 if keep_all:
                     states[0].append(h.clone())
                 for li, L in enumerate(self.layers[:nl]):
-                    x = F.norm(h, L["ln1_g"], L["ln1_b"], eps)
+                    x = F.norm_for_gemm(h, L["ln1_g"], L["ln1_b"], eps, 3072)
                     att = F.vit_attention(F.gemm(x, L["w_qkv"], L["b_qkv"]), Fn)
                     F.gemm(att, L["w_o"], L["b_o"], residual=h, out=h)
-                    x = F.norm(h, L["ln2_g"], L["ln2_b"], eps)
+                    x = F.norm_for_gemm(h, L["ln2_g"], L["ln2_b"], eps, L["w_fc1"].shape[0])
                     mid = F.gemm(x, L["w_fc1"], L["b_fc1"], epilogue=ops.EPI_QUICK_GELU)
                     F.gemm(mid, L["w_fc2"], L["b_fc2"], residual=h, out=h)
                     if keep_all:
@@ -267,14 +267,14 @@ class PreciseLlama:
                 collect.append(h.clone())
             for li in range(nl):
                 L = self.layers[li]
-                qkv = F.gemm(F.norm(h, L["ln1"], None, self.eps), L["w_qkv"])
+                qkv = F.gemm(F.norm_for_gemm(h, L["ln1"], None, self.eps, 3 * self.H), L["w_qkv"])
                 F.rope_kv(qkv, cache.k[li], cache.v[li], self.cos, self.sin, B, S, self.heads, past)
                 att = F.llama_attention(qkv, cache.k[li], cache.v[li], cache.key_valid, B, S, self.heads, past)
                 if attn is not None:                        # output_attentions (as HipLlama.forward): rotated q, rotated K cache
                     from . import ops as _ops
                     attn.append(_ops.attention_probs(qkv, cache.k[li], cache.key_valid, B, S, self.heads, past))
                 F.gemm(att, L["w_o"], residual=h, out=h)
-                mid = F.gemm(F.norm(h, L["ln2"], None, self.eps), L["w_gu"], epilogue=ops.EPI_SWIGLU)
+                mid = F.gemm(F.norm_for_gemm(h, L["ln2"], None, self.eps, 2 * self.I), L["w_gu"], epilogue=ops.EPI_SWIGLU)
                 F.gemm(mid, L["w_down"], residual=h, out=h)
                 if collect is not None and li + 1 < nl:
                     collect.append(h.clone())
