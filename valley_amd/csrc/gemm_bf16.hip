@@ -134,6 +134,9 @@ constexpr int P4_M0_LEAD = 2;       // the M0 write of a piece sits this many MF
 #ifndef VLY_P4_LIT
 #define VLY_P4_LIT 1                // 0: accumulators as C++ values everywhere (the round-4 kernel)
 #endif
+#ifndef VLY_P4_CHAIN
+#define VLY_P4_CHAIN 0              // 1: the by-name instantiations issue the two K steps of a block BACK TO BACK (see `CHAIN` in gemm_p4_kernel)
+#endif
 #ifndef VLY_P4_LATE
 #define VLY_P4_LATE 0               // 1: barrier B and the next K tile's first fragment reads late in phase 2 (see ktile)
 #endif
@@ -240,6 +243,42 @@ VLY_DEVICE void phase_4w4(ACC& acc, const bf16x8 (&af)[MI], const bf16x8 (&wf)[N
             if (k < N4 && S4 + k * D4 >= MI * NI) f4(k);
             f2(k);
         }
+    __builtin_amdgcn_sched_barrier(0);
+}
+// T MFMAs issued by mf(t) with the same four hook lists as phase_4w4 (order behind MFMA t: f1, f3, f4, f2) — the chain-order phases
+template <int T, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, int N4, int S4, int D4, typename MF, typename F1, typename F2,
+          typename F3, typename F4>
+VLY_DEVICE void phase_seq(MF&& mf, F1&& f1, F2&& f2, F3&& f3, F4&& f4) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N4; ++k)
+        if (S4 + k * D4 < 0) f4(k);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        mf(t);
+        if (N1 > 0 && t >= S1 && (t - S1) % D1 == 0 && (t - S1) / D1 < N1) {
+            __builtin_amdgcn_sched_barrier(0);
+            f1((t - S1) / D1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (N3 > 0 && t >= S3 && (t - S3) % D3 == 0 && (t - S3) / D3 < N3) {
+            __builtin_amdgcn_sched_barrier(0);
+            f3((t - S3) / D3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (N4 > 0 && t >= S4 && (t - S4) % D4 == 0 && (t - S4) / D4 < N4) {
+            __builtin_amdgcn_sched_barrier(0);
+            f4((t - S4) / D4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (N2 > 0 && t >= S2 && (t - S2) % D2 == 0 && (t - S2) / D2 < N2) {
+            __builtin_amdgcn_sched_barrier(0);
+            f2((t - S2) / D2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    static_assert((N1 == 0 || S1 + (N1 - 1) * D1 < T) && (N2 == 0 || S2 + (N2 - 1) * D2 < T) && (N3 == 0 || S3 + (N3 - 1) * D3 < T) &&
+                  (N4 == 0 || S4 + (N4 - 1) * D4 < T), "every hook inside the phase");
     __builtin_amdgcn_sched_barrier(0);
 }
 template <int MI, int NI, int N1, int S1, int D1, int N2, int S2, int D2, int N3, int S3, int D3, typename F1, typename F2, typename F3, typename ACC>
@@ -1125,6 +1164,33 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         __builtin_amdgcn_s_barrier();
     };
 
+    // ---- CHAIN (round 6, -DVLY_P4_CHAIN=1; the by-name instantiations): the two K steps of a block are issued BACK TO BACK on its
+    // accumulator instead of 64 MFMAs apart.  tools/probes/mfma_order.hip: 2.37 against 2.23 PFLOP/s sustained with nothing but MFMAs —
+    // the chip is power-limited and the chained form is the cheaper one (the second MFMA takes the first one's result as forwarded C).
+    // Per block the products are added in the same order as before (K step 0, then 1, K tile by K tile): bit-identical results.
+    // A K tile = phase 1: block rows 0 .. CH-1, row by row (all W fragments of the tile + the A fragments of those rows resident; the
+    // A fragments of rows CH .. MI-1 are read meanwhile); phase 2: rows CH .. MI-1 COLUMN by column, so that a column's two W fragments
+    // are free when its chains are through and take the next K tile's at once, while the first rows' A fragments are re-read too.
+    // Same 32 fragment reads, barriers and pieces per K tile; no rolling boundary (it is built around the phase order).
+    constexpr bool CHAIN = VLY_P4_CHAIN != 0 && VLY_P4_LIT != 0 && !SK && OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE;
+    constexpr int CH = MI / 2, CT1 = CH * NI * 2, CT2 = (MI - CH) * NI * 2;                      // rows and MFMAs of the two phases
+    constexpr int CR1 = 2 * (MI - CH), CBAR = CR1 + P8_BAR_GAP, CGL1 = CBAR + 2;                 // phase 1: reads, barrier A, first piece
+    constexpr int CGLS = (CT1 + CT2 - CGL1) / NS, CN1 = (CT1 - CGL1 + CGLS - 1) / CGLS, CN2 = NS - CN1, CGL2 = CGL1 + CN1 * CGLS - CT1;
+    static_assert(!CHAIN || (CGL1 < CT1 && CGLS >= 1 && CN2 >= 0 && CGL2 >= 0 && CGL2 + (CN2 - 1) * CGLS < CT2 && 1 + 2 * (2 * CH - 1) < CT2),
+                  "chain piece schedule");
+    auto chain_preload = [&](const char* st) {                       // what a K tile's phase 1 starts from: every W fragment, A rows 0 .. CH-1
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            w0[j] = *(const bf16x8*)(st + rdW + j * 2048 + sw0);
+            w1[j] = *(const bf16x8*)(st + rdW + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            a0[i] = *(const bf16x8*)(st + rdA + i * 2048 + sw0);
+            a1[i] = *(const bf16x8*)(st + rdA + i * 2048 + sw1);
+        }
+    };
+
     // ---- prologue: the first two K tiles of the stream
 #pragma unroll
     for (int q = 0; q < NS; ++q) piece(0, q);
@@ -1134,7 +1200,8 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     advance_load();
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");
     __builtin_amdgcn_s_barrier();
-    {
+    if constexpr (CHAIN) chain_preload(smem);
+    else {
         auto r0 = rd_step0(smem);
 #pragma unroll
         for (int k = 0; k < MI + NI; ++k) r0(k);
@@ -1147,7 +1214,7 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (uint32_t)M * (uint32_t)ldc * (OUT == VLY_OUT_BF16 ? 2u : 4u), 0x00020000);
     int buf = 0;                                                     // buffer of the K tile being computed
     constexpr bool LIT = VLY_P4_LIT != 0 && !SK && OUT == VLY_OUT_BF16 && EPI != VLY_EPI_QKV_ROPE;     // the accumulators by name (mfma16_lit)
-    constexpr bool ROLL = VLY_P4_ROLL != 0 && LIT && ((VLY_P4_ROLL_MASK >> EPI) & 1) != 0;
+    constexpr bool ROLL = VLY_P4_ROLL != 0 && LIT && !CHAIN && ((VLY_P4_ROLL_MASK >> EPI) & 1) != 0;
     constexpr int NST_ = EPI == VLY_EPI_SWIGLU ? NI / 4 : NI / 2;    // 16-byte stores per fragment row of the bf16 epilogue
     static_assert(!ROLL || N1 + MI * NST_ <= 63, "vmcnt is a 6-bit count");
     if constexpr (LIT) asm volatile("" ::: VLY_ALL_AGPRS);           // the kernel owns a0 .. a255 (this is what makes the descriptor allocate them)
@@ -1163,6 +1230,59 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         const char* nxt = smem + (buf ^ 1) * STAGE;
         // (a dead wave's fragment registers are never used; its reads are skipped with its MFMAs)
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // the fragments of this phase: read >= 33 MFMAs ago (VLY_P4_LATE: >= 11)
+        if constexpr (CHAIN) {
+            if (wave_live) {
+                // phase 1: rows 0 .. CH-1, row-major pairs; reads: a0 / a1 of rows CH .. MI-1 (the last reads of this buffer)
+                phase_seq<CT1, CR1, 0, 1, CN1, CGL1, CGLS, 1, CBAR, 1, CN1, CGL1 - P4_M0_LEAD, CGLS>(
+                    [&](int t) {
+                        const int i = t / (2 * NI), j = (t % (2 * NI)) >> 1, st = t & 1;
+                        if (FIRST && st == 0) mfma16_lit_zero(i * NI + j, w0[j], a0[i]);
+                        else if (st == 0) mfma16_lit(i * NI + j, w0[j], a0[i]);
+                        else mfma16_lit(i * NI + j, w1[j], a1[i]);
+                    },
+                    [&](int k) {
+                        const int i = CH + (k >> 1);
+                        if (k & 1) a1[i < MI ? i : 0] = *(const bf16x8*)(cur + rdA + i * 2048 + sw1);
+                        else a0[i < MI ? i : 0] = *(const bf16x8*)(cur + rdA + i * 2048 + sw0);
+                    },
+                    [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
+            } else {
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int q = 0; q < CN1; ++q) piece(buf, q);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CN1) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave_live) {
+                // phase 2: rows CH .. MI-1, column-major pairs; reads from the NEXT K tile: a0 / a1 of rows 0 .. CH-1 (one per two MFMAs), and
+                // a column's w0 / w1 the moment its last chain is through
+                constexpr int CW = 2 * (MI - CH);                    // MFMAs per column
+                phase_seq<CT2, 2 * CH, 1, 2, CN2, CGL2, CGLS, NI, CW - 1, CW, CN2, CGL2 - P4_M0_LEAD, CGLS>(
+                    [&](int t) {
+                        const int j = t / CW, i = CH + ((t % CW) >> 1), st = t & 1;
+                        if (FIRST && st == 0) mfma16_lit_zero(i * NI + j, w0[j], a0[i]);
+                        else if (st == 0) mfma16_lit(i * NI + j, w0[j], a0[i]);
+                        else mfma16_lit(i * NI + j, w1[j], a1[i]);
+                    },
+                    [&](int k) {
+                        const int i = k >> 1;
+                        if (k & 1) a1[i < MI ? i : 0] = *(const bf16x8*)(nxt + rdA + i * 2048 + sw1);
+                        else a0[i < MI ? i : 0] = *(const bf16x8*)(nxt + rdA + i * 2048 + sw0);
+                    },
+                    [&](int q) { piece_ld(CN1 + q); },
+                    [&](int j) {
+                        w0[j < NI ? j : 0] = *(const bf16x8*)(nxt + rdW + j * 2048 + sw0);
+                        w1[j < NI ? j : 0] = *(const bf16x8*)(nxt + rdW + j * 2048 + sw1);
+                    },
+                    [&](int q) { piece_m0(buf, CN1 + q); });
+            } else {
+#pragma unroll
+                for (int q = 0; q < CN2; ++q) piece(buf, CN1 + q);
+            }
+            advance_load();
+            buf ^= 1;
+            return;
+        }
         if (wave_live)
             phase_4w4<MI, NI, MI + NI, 0, 1, N1, GL1_START, GL_STRIDE, 1, BAR_AT, 1, N1, GL1_START - P4_M0_LEAD, GL_STRIDE, LIT ? (FIRST ? 3 : 2) : 0>(
                 acc, a0, w0, rd_step1(cur), [&](int q) { piece_ld(q); }, bar_a, [&](int q) { piece_m0(buf, q); });
@@ -1740,7 +1860,8 @@ gemm_p4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             ct += G;
         }
         tile_origin(ct, cm0, cn0);
-        {   // K step 0 of the next tile's first K tile: it landed before the last barrier B (same buffer rotation)
+        if constexpr (CHAIN) chain_preload(smem + buf * STAGE);
+        else {   // K step 0 of the next tile's first K tile: it landed before the last barrier B (same buffer rotation)
             auto r0 = rd_step0(smem + buf * STAGE);
 #pragma unroll
             for (int k = 0; k < MI + NI; ++k) r0(k);
