@@ -29,6 +29,12 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef VLY_DECODE_MERGE_FENCE
 #define VLY_DECODE_MERGE_FENCE 0    // 1: release / acquire fences around the merged decode attention's ticket (see split_merge_if_last)
 #endif
+#ifndef VLY_VIT_PRIO
+#define VLY_VIT_PRIO 0              // 1: s_setprio 1 around the MFMA runs of the ViT kernel (QK^T, PV), 0 in the softmax
+#endif
+#ifndef VLY_VIT_STAGGER
+#define VLY_VIT_STAGGER 0           // N > 0: waves 4-7 of a workgroup start their query tiles N x 64 clocks late (the two waves of a SIMD out of phase)
+#endif
 #ifndef VLY_VIT_STORE_LINES
 #define VLY_VIT_STORE_LINES 0       // 1: the ViT kernel's outputs leave as whole 128-byte lines (measured equal, bit-identical: profiles/r06/r06_vit_attn_store_lines.txt)
 #endif
@@ -153,6 +159,9 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
         qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
     }
+#if VLY_VIT_STAGGER
+    if (wave >= 4) __builtin_amdgcn_s_sleep(VLY_VIT_STAGGER);
+#endif
     for (int qt = wave; qt < VNT; qt += VNW) {
         const int q = qt * 16 + l15;
         bf16x8 qf[2] = {qn[0], qn[1]};
@@ -165,6 +174,9 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         // (scale, then max / exp2(s - m).  Folding the scale into the exponent's FMA with a max3 chain — fewer VALU instructions —
         // measured 4 % SLOWER: 113.4 vs 109.0 us at 128 frames, round 2.)
         f32x4 s[VNT];
+#if VLY_VIT_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int t = 0; t < VNT; ++t) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -176,6 +188,9 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             s[t] = acc * sc;
             if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
         }
+#if VLY_VIT_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // keys 257..271 are padding: only (g == 0, r == 0) of the last tile is real
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -203,6 +218,9 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if VLY_VIT_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int c = 0; c < VNC; ++c) {
             u32x4 pk;
@@ -227,6 +245,9 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             }
             asm volatile("" ::: "memory");
         }
+#if VLY_VIT_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         {   // (every lane takes part in the lane swaps; rows past token 256 write to the clamped row's twin and are masked)
             const float inv = 1.f / l;
             uint16_t* op = out + ((size_t)f * VN + min(q, VN - 1)) * 1024 + h * 64;
