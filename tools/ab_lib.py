@@ -151,7 +151,7 @@ def run_attn(names, shapes, reps=60):
         print(json.dumps({"attn": sh, **{n: round(statistics.median(t), 1) for n, t in zip(names, times)}, "unit": "us"}), flush=True)
 
 
-def run_vit_attn(names, frames, reps=40):
+def run_vit_attn(names, frames, reps=int(os.environ.get("AB_REPS", "40"))):
     """ViT attention (vly_vit_attention) A/B: one arm per library, F frames per launch."""
     import random
     import torch

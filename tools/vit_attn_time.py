@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """vly_vit_attention: time per launch at F frames and the error against an fp32 torch evaluation of the same bf16 inputs.
-VLY_VIT_ATTN=1 selects the round-2 kernel (read once per process): run once per setting.  One JSON line."""
+VLY_VIT_ATTN=1 / 4 forces the workgroup-per-head / the persistent kernel (read once per process; default: by frame count): run once per
+setting.  One JSON line."""
 import json
 import os
 import statistics
@@ -42,7 +43,7 @@ def main():
         torch.cuda.synchronize()
         if i >= 3:
             ts.append(e0.elapsed_time(e1) * 1e3)
-    print(json.dumps({"vit_attn_frames": F, "kernel": os.environ.get("VLY_VIT_ATTN", "1 (default)"), "median_us": round(statistics.median(ts), 1),
+    print(json.dumps({"vit_attn_frames": F, "kernel": os.environ.get("VLY_VIT_ATTN", "default"), "median_us": round(statistics.median(ts), 1),
                       "min_us": round(min(ts), 1), "rel_l2_vs_fp32": round(rel, 5), "max_abs": round(mx, 4)}), flush=True)
 
 

@@ -35,6 +35,18 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef VLY_VIT_STAGGER
 #define VLY_VIT_STAGGER 0           // N > 0: waves 4-7 of a workgroup start their query tiles N x 64 clocks late (the two waves of a SIMD out of phase)
 #endif
+#ifndef VLY_VIT_TIMING
+#define VLY_VIT_TIMING 0            // anatomy builds (tools/vit_attn_times.py): every wave of every workgroup stamps s_memtime at the seams of its query tiles
+#endif
+#ifndef VLY_VIT_STAGE2
+#define VLY_VIT_STAGE2 1            // 1: all of a workgroup's start-up loads in flight at once (0: round 2's load / wait / store loops)
+#endif
+#ifndef VLY_VIT_ROT
+#define VLY_VIT_ROT 0               // 1: the 17th query tile of a head goes to a wave picked from the workgroup index (not always wave 0 = SIMD 0)
+#endif
+#ifndef VLY_VIT_FOLD
+#define VLY_VIT_FOLD 0              // 1: softmax on the raw scores — max by v_max3, the 64^-0.5 scale inside the exponent's FMA (one VALU op per score fewer; not bit-identical)
+#endif
 #ifndef VLY_VIT_STORE_LINES
 #define VLY_VIT_STORE_LINES 0       // 1: the ViT kernel's outputs leave as whole 128-byte lines (measured equal, bit-identical: profiles/r06/r06_vit_attn_store_lines.txt)
 #endif
@@ -101,7 +113,19 @@ constexpr int VK_BYTES = VNT * 16 * 128;
 constexpr int VNW = 8;             // waves per workgroup: 2 workgroups x 8 waves = 4 waves per SIMD hide the LDS / MFMA
                                    // latency chains of a 16-query block (4 waves: 31.5 us per layer at 32 frames)
 
-__global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+#if VLY_VIT_TIMING
+constexpr int VTS_WG = 4096, VTS_N = 24;                    // stamped workgroups (the first 4096), stamps per wave
+__device__ unsigned long long vit_ts[VTS_WG * VNW * VTS_N];
+#define VLY_VSTAMP()                                                                                     \
+    do {                                                                                                  \
+        if (ts_row && lane == 0 && tsn < VTS_N) ts_row[tsn] = __builtin_readcyclecounter();                \
+        ++tsn;                                                                                            \
+    } while (0)
+#else
+#define VLY_VSTAMP() do {} while (0)
+#endif
+
+__global__ void __launch_bounds__(VNW * 64, 4) vit_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[VK_BYTES + 64 * VT_STRIDE * 2];
     char* sK = smem;
     uint16_t* sVt = (uint16_t*)(smem + VK_BYTES);
@@ -110,12 +134,77 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
     const int l15 = lane & 15, g = lane >> 4;
     [[maybe_unused]] const int hi16 = opaque_i32(16);          // see opaque_i32
     const int h = blockIdx.x & 15;
+#if VLY_VIT_TIMING
+    int tsn = 0;
+    unsigned long long* ts_row = blockIdx.x < VTS_WG ? vit_ts + ((size_t)blockIdx.x * VNW + wave) * VTS_N : nullptr;
+    VLY_VSTAMP();                                                    // 0: start
+    if (ts_row && lane == 0) {                                       // 1: HW_ID (which XCD / CU / SIMD this wave sits on)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ts_row[tsn] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+    ++tsn;
+#endif
     // (Timing variants of this kernel — staging only, no LDS reads, no stores, L2-resident inputs, no HBM traffic, no exp2, no
     // softmax arithmetic — were compile-time switches here while profiles/history/r03/r03_vit_attn_timing_variants{,2}.jsonl were
     // measured; they and the old 8-byte store pattern left with commit 49dfb3f's successor.)
     const int f = blockIdx.x >> 4;
     const uint16_t* base = qkv + (size_t)f * VN * VLD + h * 64;
 
+#if VLY_VIT_STAGE2
+    // ---- staging, round 6: EVERY global load of the workgroup's start is issued before the first LDS store — the K slots (five per
+    //      thread), the V rows (two key pairs per thread) and the first query tile's fragments — so the start costs one memory round trip
+    //      plus the transfer.  (The loops below this block — one load, s_waitcnt vmcnt(0), one store per trip — cost five round trips
+    //      in series: 12.7 k of a workgroup's 35 k cycles, profiles/r06/r06_vit_attn_anatomy.txt.)
+    //      Loads are unconditional on clamped addresses (a load under a lane mask has to be merged with the masked lanes' value, which
+    //      costs a vmcnt(0) on the spot); the padding is zeroed where the LDS words are formed.
+    const int dq = wave & 3;
+    u32x4 kr[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int sl = tid + i * VNW * 64, row = min(sl >> 3, VN - 1), c = sl & 7;
+        kr[i] = *(const u32x4*)(base + (size_t)row * VLD + 1024 + c * 8);
+    }
+    u32x4 vr[2][4];                                        // [pass][a0, a1, b0, b1]: pass 0 = key-pair group wave >> 2, pass 1 = group 2 (waves 0-3)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int pg = ps == 0 ? (wave >> 2) : 2, kv0 = 2 * (pg * 64 + lane), kv1 = kv0 + 1;
+        if (ps == 0 || wave < 4) {                         // (wave-uniform)
+            const uint16_t* r0 = base + (size_t)min(kv0, VN - 1) * VLD + 2048 + dq * 16;
+            const uint16_t* r1 = base + (size_t)min(kv1, VN - 1) * VLD + 2048 + dq * 16;
+            vr[ps][0] = *(const u32x4*)r0;
+            vr[ps][1] = *(const u32x4*)(r0 + 8);
+            vr[ps][2] = *(const u32x4*)r1;
+            vr[ps][3] = *(const u32x4*)(r1 + 8);
+        }
+    }
+    bf16x8 qn[2];
+    {
+        const int qc0 = min(wave * 16 + l15, VN - 1);
+        qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
+        qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
+    }
+    // K: [272][64] bf16, 128-byte rows, chunk ^= row & 7
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int sl = tid + i * VNW * 64, row = sl >> 3, c = sl & 7;
+        if (sl < VNT * 16 * 8) *(u32x4*)(sK + row * 128 + ((c ^ (row & 7)) << 4)) = row < VN ? kr[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+    // V^T: [64 d][288 kv]; wave w transposes d = 16 (w & 3) .. + 15, lane <-> key pair
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int pg = ps == 0 ? (wave >> 2) : 2, kv0 = 2 * (pg * 64 + lane);
+        if (ps == 0 || (wave < 4 && lane < VNC * 16 - 128)) {
+            const uint32_t m0 = kv0 < VN ? 0xffffu : 0u, m1 = kv0 + 1 < VN ? 0xffff0000u : 0u;
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const uint32_t w = (sel16(vr[ps][0], vr[ps][1], dd) & m0) | ((sel16(vr[ps][2], vr[ps][3], dd) << 16) & m1);
+                *(uint32_t*)(sVt + (dq * 16 + dd) * VT_STRIDE + kv0) = w;
+            }
+        }
+    }
+#else
     // ---- K: [272][64] bf16, 128-byte rows, chunk ^= row & 7 ------------------------------------
     for (int s = tid; s < VNT * 16 * 8; s += VNW * 64) {
         const int row = s >> 3, c = s & 7;
@@ -148,25 +237,37 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
             }
         }
     }
+#endif
+    VLY_VSTAMP();                                          // 2: staging stores issued
     __syncthreads();
+    VLY_VSTAMP();                                          // 3: barrier passed
 
     const float sc = 0.125f * LOG2E;                       // 64^-0.5, folded with log2(e) for exp2
     // the Q fragments come straight from global memory: the next query tile's are requested before this tile's math
     // (a wave handles 2-3 query tiles; an exposed global round trip per tile was ~1/4 of the kernel)
+#if !VLY_VIT_STAGE2
     bf16x8 qn[2];
     {
         const int qc0 = min(wave * 16 + l15, VN - 1);
         qn[0] = *(const bf16x8*)(base + (size_t)qc0 * VLD + g * 8);
         qn[1] = *(const bf16x8*)(base + (size_t)qc0 * VLD + 32 + g * 8);
     }
+#endif
 #if VLY_VIT_STAGGER
     if (wave >= 4) __builtin_amdgcn_s_sleep(VLY_VIT_STAGGER);
 #endif
-    for (int qt = wave; qt < VNT; qt += VNW) {
+#if VLY_VIT_ROT
+    const int rot = (blockIdx.x ^ (blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & (VNW - 1);
+#else
+    const int rot = 0;
+#endif
+    // wave w takes query tiles w, w + 8 and — one wave of the workgroup — tile 16 (the 257th query)
+    const auto next_tile = [&](int qt) { return qt + VNW < 16 ? qt + VNW : (qt < 16 && wave == rot ? 16 : VNT); };
+    for (int qt = wave; qt < VNT; qt = next_tile(qt)) {
         const int q = qt * 16 + l15;
         bf16x8 qf[2] = {qn[0], qn[1]};
-        if (qt + VNW < VNT) {
-            const int qc1 = min((qt + VNW) * 16 + l15, VN - 1);
+        if (next_tile(qt) < VNT) {
+            const int qc1 = min(next_tile(qt) * 16 + l15, VN - 1);
             qn[0] = *(const bf16x8*)(base + (size_t)qc1 * VLD + g * 8);
             qn[1] = *(const bf16x8*)(base + (size_t)qc1 * VLD + 32 + g * 8);
         }
@@ -185,7 +286,11 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
                 const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + l15) * 128 + (((kk * 4 + g) ^ (l15 & 7)) << 4));
                 acc = mfma16(kf, qf[kk], acc);
             }
+#if VLY_VIT_FOLD
+            s[t] = acc;
+#else
             s[t] = acc * sc;
+#endif
             if ((t & 3) == 3) asm volatile("" ::: "memory");     // cap the K-fragment reads in flight (VGPR budget: 2 blocks/CU)
         }
 #if VLY_VIT_PRIO
@@ -195,9 +300,35 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (g != 0 || r != 0) s[VNT - 1][r] = NEG_BIG;
+#if VLY_VIT_TIMING
+        asm volatile("" : "+v"(s[VNT - 1][0]));                // (the stamp after the first product: all of it issued; s_memtime does not wait for the MFMAs)
+        VLY_VSTAMP();                                        // 4 + 4 i: QK^T issued
+#endif
 
         float m = NEG_BIG;
         float l = 0.f;
+#if VLY_VIT_FOLD
+#pragma unroll
+        for (int t = 0; t < VNT; ++t) {
+            m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][0]), s[t][1]);        // v_max3_f32
+            m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][2]), s[t][3]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        {
+            const float nm = -m * sc;
+            float l2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < VNT; ++t) {
+                const float p0 = sm_exp2(__builtin_fmaf(s[t][0], sc, nm)), p1 = sm_exp2(__builtin_fmaf(s[t][1], sc, nm));
+                const float p2 = sm_exp2(__builtin_fmaf(s[t][2], sc, nm)), p3 = sm_exp2(__builtin_fmaf(s[t][3], sc, nm));
+                s[t] = f32x4{p0, p1, p2, p3};
+                l += p0 + p1;
+                l2 += p2 + p3;
+            }
+            l += l2;
+        }
+#else
 #pragma unroll
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
@@ -212,9 +343,14 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
                 s[t][r] = p;
                 l += p;
             }
+#endif
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
 
+#if VLY_VIT_TIMING
+        asm volatile("" : "+v"(l));
+        VLY_VSTAMP();                                        // 5 + 4 i: softmax done
+#endif
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -247,6 +383,10 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
         }
 #if VLY_VIT_PRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
+#if VLY_VIT_TIMING
+        asm volatile("" : "+v"(o[3][3]));
+        VLY_VSTAMP();                                        // 6 + 4 i: PV issued
 #endif
         {   // (every lane takes part in the lane swaps; rows past token 256 write to the clamped row's twin and are masked)
             const float inv = 1.f / l;
@@ -288,10 +428,16 @@ __global__ void __launch_bounds__(VNW * 64, 2) vit_attn_kernel(const uint16_t* _
 #endif
             }
         }
+        VLY_VSTAMP();                                        // 7 + 4 i: stores issued
     }
+#if VLY_VIT_TIMING
+    if (ts_row && lane == 0 && tsn < VTS_N) ts_row[VTS_N - 1] = (unsigned long long)tsn;
+#endif
 }
+#undef VLY_VSTAMP
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+#include "attention_vit_persist.inc"
 // ---------------------------------------------------------------------------------------------
 // Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
 // grid = (heads, B, ceil(S/(16*LNW))), last query block first; LNW waves x 16 query rows.
@@ -309,7 +455,7 @@ constexpr int LNW = VLY_LNW;
 // barriers per 64-key tile because its tiles pass through registers (K) and a register transpose (V).  Here a tile is 16 + 16
 // one-KB LDS-DMA pieces (asm buffer_load ... lds, M0 = destination: no registers, no VALU), K swizzled on the SOURCE address
 // (chunk ^= row & 15, the layout the S^T fragment reads expect), V ROW-major with its 32-byte chunk pairs XORed by row & 7 and
-// read as the second product's A operand by the hardware transpose read (vit_attn4_kernel's scheme at 256-byte rows: the 8
+// read as the second product's A operand by the hardware transpose read (vit_attn_persist_kernel's scheme at 256-byte rows: the 8
 // rows of a half wave land in 8 distinct 32-byte slots of the 256-byte bank window).  Two buffers: tile t + 1 flies under
 // tile t, ONE barrier per tile.  No staging registers -> <= 128 per lane -> two workgroups per CU: one workgroup's start-up
 // (Q fragments, first tile) hides under the other's tiles.  Same arithmetic, same order as llama_attn_kernel: bit-identical.
@@ -1020,9 +1166,8 @@ __global__ void __launch_bounds__(256) attn_probs_kernel(const T* __restrict__ q
     for (int j = tid; j < kv_len; j += 256) o[j] = pr_sc[j] * inv;
 }
 
-// the two kernels that are NOT the default of their op (A/B runs and each other's bit-identity witness: VLY_VIT_ATTN=4 ->
-// vit_attn4_kernel, VLY_LLAMA_ATTN=1 -> llama_attn_kernel) live in the EXPERIMENTAL library only (libvalley_hip_exp.so,
-// -DVLY_EXPERIMENTAL=1, valley_amd/build.py): the shipped libraries carry one kernel per op
+// the kernel that is NOT the default of its op (A/B runs and the default's bit-identity witness: VLY_LLAMA_ATTN=1 -> llama_attn_kernel)
+// lives in the EXPERIMENTAL library only (libvalley_hip_exp.so, -DVLY_EXPERIMENTAL=1, valley_amd/build.py)
 #ifndef VLY_EXPERIMENTAL
 #define VLY_EXPERIMENTAL 0
 #endif
@@ -1032,13 +1177,25 @@ __global__ void __launch_bounds__(256) attn_probs_kernel(const T* __restrict__ q
 
 }  // namespace
 
+#if VLY_VIT_TIMING
+extern "C" int vlydbg_vit_timing_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vit_ts), sizeof(unsigned long long) * VTS_WG * VNW * VTS_N); }
+#endif
+
+// The persistent kernel (one 16-wave workgroup per CU walking its heads, the next head's K / V in flight by LDS-DMA: attention_vit_persist.inc)
+// at every frame count: one kernel per op keeps the encode bit-identical however many frames share a launch (tests/test_scale_gpu.py::
+// test_c4_shape_tower_chunk_invariance).  Against one workgroup per (frame, head) (vit_attn_kernel, rounds 2-5's default), A/B, 100
+// repetitions, same box (profiles/r06/r06_vit_attn_persist_ab.txt, r06_vit_attn_persist_small.txt): 4 frames 12.4 -> 11.2 us, 32 frames
+// 23.2 -> 21.7, 64 frames 46.7 -> 43.7, 128 frames 88.2 -> 72.5, 256 frames 169.1 -> 131.2.  VLY_VIT_ATTN=1 runs vit_attn_kernel (A/B runs,
+// its tests); -DVLY_VIT_PERSIST_MIN=n builds a library that uses it below n frames.
+#ifndef VLY_VIT_PERSIST_MIN
+#define VLY_VIT_PERSIST_MIN 1
+#endif
+constexpr int VIT_PERSIST_MIN_FRAMES = VLY_VIT_PERSIST_MIN;
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
     // (out: the kernels store 16 bytes per lane since round 3)
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) { vly_set_error("vly_vit_attention: bad args F=%d (qkv and out 16-byte aligned)", F); return -22; }
-    // VLY_VIT_ATTN=4 launches vit_attn4_kernel (persistent, LDS-DMA staged; measured 2 % faster at >= 128 frames, equal at 32)
-#if VLY_EXPERIMENTAL
-    static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 1;
-    if (ver == 4) {
+    static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 0;
+    if (ver == 4 || (ver != 1 && F >= VIT_PERSIST_MIN_FRAMES)) {
         static const int cus = [] {
             int dev = 0, n = 0;
             (void)hipGetDevice(&dev);
@@ -1046,11 +1203,11 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
             return n > 0 ? n : 256;
         }();
         const int nheads = F * 16;
-        hipLaunchKernelGGL(vit_attn4_kernel, dim3(nheads < cus ? nheads : cus), dim3(V4W * 64), 0, (hipStream_t)stream,
+        if ((size_t)F * VN * VLD * 2 >= ((size_t)1 << 32)) { vly_set_error("vly_vit_attention: F=%d exceeds the 4 GB buffer descriptor", F); return -22; }
+        hipLaunchKernelGGL(vit_attn_persist_kernel, dim3(nheads < cus ? nheads : cus), dim3(VPW * 64), 0, (hipStream_t)stream,
                            (const uint16_t*)qkv, (uint16_t*)out, nheads);
         return vly_check_launch("vly_vit_attention");
     }
-#endif
     hipLaunchKernelGGL(vit_attn_kernel, dim3(F * 16), dim3(VNW * 64), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out);
     return vly_check_launch("vly_vit_attention");
 }
