@@ -324,6 +324,27 @@ def test_vit_attention_persistent_default(F):
     assert worst < 2.5e-2 and worst_last < 2.5e-2, (worst, worst_last)
 
 
+@pytest.mark.parametrize("F", [5, 40, 130])
+def test_vit_attention_three_kernels_agree(F, monkeypatch):
+    """The persistent default, the two-workgroups-per-CU form (VLY_VIT_ATTN=5, attention_vit_pp.inc) and rounds 2-5's workgroup-per-head
+    kernel (VLY_VIT_ATTN=1) on the same inputs (the switch is read per call): the 256 full-tile queries of every head are bit-identical between
+    the two persistent kernels (same arithmetic, same order); the 257th query (its partials associate differently) and the workgroup-per-head
+    kernel (scale outside the exponent's FMA) agree to the storage type's rounding."""
+    from valley_amd import ops
+    d = dev()
+    qkv = rnd((F * 257, 3072), 300 + F, 1.0, dtype=HALF).to(d)
+    monkeypatch.delenv("VLY_VIT_ATTN", raising=False)
+    a = ops.vit_attention(qkv, F).view(F, 257, 1024)
+    monkeypatch.setenv("VLY_VIT_ATTN", "5")
+    b = ops.vit_attention(qkv, F).view(F, 257, 1024)
+    monkeypatch.setenv("VLY_VIT_ATTN", "1")
+    c = ops.vit_attention(qkv, F).view(F, 257, 1024)
+    monkeypatch.delenv("VLY_VIT_ATTN", raising=False)
+    assert torch.equal(a[:, :256], b[:, :256])
+    assert relerr(b[:, 256].float(), a[:, 256].float()) < 3e-3 and relerr(c.float(), a.float()) < 3e-3
+    assert torch.equal(a, ops.vit_attention(qkv, F).view(F, 257, 1024))          # (and run to run)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_pool_tokens(mode):
     from valley_amd import ops

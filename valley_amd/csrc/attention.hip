@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(VNW * 64, 4) vit_attn_kernel(const uint16_t* _
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #include "attention_vit_persist.inc"
+#include "attention_vit_pp.inc"
 // ---------------------------------------------------------------------------------------------
 // Llama attention over the KV cache (head_dim 128, causal + key-validity mask, online softmax)
 // grid = (heads, B, ceil(S/(16*LNW))), last query block first; LNW waves x 16 query rows.
@@ -1186,16 +1187,21 @@ extern "C" int vlydbg_vit_timing_read(unsigned long long* host) { return (int)hi
 // test_c4_shape_tower_chunk_invariance).  Against one workgroup per (frame, head) (vit_attn_kernel, rounds 2-5's default), A/B, 100
 // repetitions, same box (profiles/r06/r06_vit_attn_persist_ab.txt, r06_vit_attn_persist_small.txt): 4 frames 12.4 -> 11.2 us, 32 frames
 // 23.2 -> 21.7, 64 frames 46.7 -> 43.7, 128 frames 88.2 -> 72.5, 256 frames 169.1 -> 131.2.  VLY_VIT_ATTN=1 runs vit_attn_kernel (A/B runs,
-// its tests); -DVLY_VIT_PERSIST_MIN=n builds a library that uses it below n frames.
+// its tests), VLY_VIT_ATTN=5 the two-workgroups-per-CU form (attention_vit_pp.inc: bit-identical, measured 6 % behind); -DVLY_VIT_PERSIST_MIN=n
+// builds a library that uses vit_attn_kernel below n frames.
 #ifndef VLY_VIT_PERSIST_MIN
 #define VLY_VIT_PERSIST_MIN 1
+#endif
+#ifndef VLY_VIT_PP
+#define VLY_VIT_PP 0                // 1: vit_attn_pp_kernel instead of vit_attn_persist_kernel (A/B builds)
 #endif
 constexpr int VIT_PERSIST_MIN_FRAMES = VLY_VIT_PERSIST_MIN;
 extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream) {
     // (out: the kernels store 16 bytes per lane since round 3)
     if (F <= 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) { vly_set_error("vly_vit_attention: bad args F=%d (qkv and out 16-byte aligned)", F); return -22; }
-    static const int ver = getenv("VLY_VIT_ATTN") ? atoi(getenv("VLY_VIT_ATTN")) : 0;
-    if (ver == 4 || (ver != 1 && F >= VIT_PERSIST_MIN_FRAMES)) {
+    const char* sel = getenv("VLY_VIT_ATTN");           // (read per call: the tests compare the kernels inside one process)
+    const int ver = sel ? atoi(sel) : 0;
+    if (ver == 4 || ver == 5 || (ver != 1 && F >= VIT_PERSIST_MIN_FRAMES)) {
         static const int cus = [] {
             int dev = 0, n = 0;
             (void)hipGetDevice(&dev);
@@ -1204,6 +1210,11 @@ extern "C" int vly_vit_attention(const void* qkv, void* out, int F, void* stream
         }();
         const int nheads = F * 16;
         if ((size_t)F * VN * VLD * 2 >= ((size_t)1 << 32)) { vly_set_error("vly_vit_attention: F=%d exceeds the 4 GB buffer descriptor", F); return -22; }
+        if (ver == 5 || VLY_VIT_PP) {                    // two persistent 8-wave workgroups per CU (attention_vit_pp.inc)
+            hipLaunchKernelGGL(vit_attn_pp_kernel, dim3(nheads < 2 * cus ? nheads : 2 * cus), dim3(PPW * 64), 0, (hipStream_t)stream,
+                               (const uint16_t*)qkv, (uint16_t*)out, nheads);
+            return vly_check_launch("vly_vit_attention");
+        }
         hipLaunchKernelGGL(vit_attn_persist_kernel, dim3(nheads < cus ? nheads : cus), dim3(VPW * 64), 0, (hipStream_t)stream,
                            (const uint16_t*)qkv, (uint16_t*)out, nheads);
         return vly_check_launch("vly_vit_attention");
