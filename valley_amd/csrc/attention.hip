@@ -100,6 +100,25 @@ VLY_DEVICE void store_tile_rows(uint16_t* row_ptr, const f32x4 (&o)[4], float in
     dst[1] = u32x4{y[0][2], y[1][2], y[0][3], y[1][3]};
 }
 
+// v (op)= v[lane ^ 16], then v[lane ^ 32]: the four lane groups of a query column, by the two gfx950 lane swaps instead of __shfl_xor's
+// ds_bpermute round trips (same partners, same order: bit-identical; see wave_reduce in common.hpp)
+template <typename OP>
+VLY_DEVICE float rows4_reduce(float v, OP op) {
+    {
+        const uint32_t x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);     // rows {0, 0, 2, 2} and {1, 1, 3, 3}
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        const uint32_t x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);     // {lo, lo} and {hi, hi}
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
+VLY_DEVICE float rows4_max(float v) { return rows4_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+VLY_DEVICE float rows4_sum(float v) { return rows4_reduce(v, [](float a, float b) { return a + b; }); }
+
 // ---------------------------------------------------------------------------------------------
 // ViT attention
 // ---------------------------------------------------------------------------------------------
@@ -313,8 +332,7 @@ __global__ void __launch_bounds__(VNW * 64, 4) vit_attn_kernel(const uint16_t* _
             m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][0]), s[t][1]);        // v_max3_f32
             m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][2]), s[t][3]);
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         {
             const float nm = -m * sc;
             float l2 = 0.f;
@@ -333,8 +351,7 @@ __global__ void __launch_bounds__(VNW * 64, 4) vit_attn_kernel(const uint16_t* _
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
 #pragma unroll
         for (int t = 0; t < VNT; ++t)
 #pragma unroll
@@ -344,8 +361,7 @@ __global__ void __launch_bounds__(VNW * 64, 4) vit_attn_kernel(const uint16_t* _
                 l += p;
             }
 #endif
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = rows4_sum(l);
 
 #if VLY_VIT_TIMING
         asm volatile("" : "+v"(l));
@@ -578,8 +594,7 @@ __global__ void __launch_bounds__(LNW * 64, 4) llama_attn2_kernel(const uint16_t
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) rm = fmaxf(rm, s[t][r]);
-        rm = fmaxf(rm, __shfl_xor(rm, 16, 64));
-        rm = fmaxf(rm, __shfl_xor(rm, 32, 64));
+        rm = rows4_max(rm);
         const float mn = fmaxf(m, rm);
         const float alpha = sm_exp2(m - mn);
         m = mn;
@@ -609,8 +624,7 @@ __global__ void __launch_bounds__(LNW * 64, 4) llama_attn2_kernel(const uint16_t
                 o[dt] = mfma16(vt_frag256(sK + vbase + ((dt << 5) ^ vx) + c * 8192), pf, o[dt]);
         }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = rows4_sum(l);
     if (q < S) {
         const float inv = 1.f / l;
         uint16_t* op = out + ((size_t)b * S + q) * Hq + h * 128 + 4 * g;
