@@ -13,6 +13,7 @@
 //   vly_patchify_f32      im2col of the 14x14 patch conv                                              hf:clip 148-154
 //   vly_pool_tokens_f32   temporal mean / max / importance pooling + CLS pick                         valley_model.py:206-215,113-121
 //   vly_embed_splice_f32  embedding gather + visual-token splice by row map                           valley_model.py:160,195-247
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 #include "common.hpp"
@@ -183,6 +184,11 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
     const uint8_t* valid = key_valid ? key_valid + (size_t)b * kv_valid_stride : nullptr;
     const int my_last = causal ? min(n_kv - 1, qi + past) : n_kv - 1;                       // keys 0 .. my_last are visible to this query
     const int blk_last = causal ? min(n_kv - 1, min(qb0 + 63, n_q - 1) + past) : n_kv - 1;  // ... to any query of the workgroup
+    // ... to any query of this WAVE, and whether it has a query at all: 16-key blocks (first product) and key quadruples (second product)
+    // past it carry probabilities that are exactly zero — their MFMAs are skipped, wave-uniformly (ViT: 257 = 4 x 64 + 1 keys and queries, so
+    // the fifth tile is one key and the fifth query block one row: 17 % + 15 % of the kernel's MFMAs; causal: the diagonal tile's upper half)
+    const bool wave_active = qb0 + wave * 16 < n_q;
+    const int wave_last = causal ? min(n_kv - 1, min(qb0 + wave * 16 + 15, n_q - 1) + past) : n_kv - 1;
     f32x4 o[HD / 16];
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -201,75 +207,85 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
         }
         if (tid < 64) sOk[tid] = (k0 + tid < n_kv && (!valid || valid[min(k0 + tid, n_kv - 1)])) ? 1 : 0;
         __syncthreads();
-        // ---- S^T: 4 key blocks x KS K steps
-        f32x4 sc[4];
+        if (!wave_active || k0 > wave_last) continue;                     // (the loads and the barriers above are the whole workgroup's)
+        // a tile this wave sees whole runs the branch-free body; only a tile cut by wave_last tests its blocks / key quadruples
+        const auto tile_body = [&](auto part_c) {
+            constexpr bool PART = decltype(part_c)::value;
+            // ---- S^T: 4 key blocks x KS K steps
+            f32x4 sc[4];
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            sc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* kr = sK + (blk * 16 + r) * LDK + g * KS;
+            for (int blk = 0; blk < 4; ++blk) {
+                sc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PART && k0 + blk * 16 > wave_last) continue;              // every score of the block is masked below
+                const float* kr = sK + (blk * 16 + r) * LDK + g * KS;
 #pragma unroll
-            for (int k = 0; k < KS; k += 4) {
-                const f32x4 a = *(const f32x4*)(kr + k);
-                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], q[k], sc[blk], 0, 0, 0);
-                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], q[k + 1], sc[blk], 0, 0, 0);
-                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], q[k + 2], sc[blk], 0, 0, 0);
-                sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], q[k + 3], sc[blk], 0, 0, 0);
+                for (int k = 0; k < KS; k += 4) {
+                    const f32x4 a = *(const f32x4*)(kr + k);
+                    sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], q[k], sc[blk], 0, 0, 0);
+                    sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], q[k + 1], sc[blk], 0, 0, 0);
+                    sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], q[k + 2], sc[blk], 0, 0, 0);
+                    sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], q[k + 3], sc[blk], 0, 0, 0);
+                }
             }
-        }
-        // ---- mask, online softmax of query r (its 64 scores sit in 4 lanes x 16 registers)
-        float mx = -INFINITY;
+            // ---- mask, online softmax of query r (its 64 scores sit in 4 lanes x 16 registers)
+            float mx = -INFINITY;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const int ok4[4] = {sOk[blk * 16 + 4 * g], sOk[blk * 16 + 4 * g + 1], sOk[blk * 16 + 4 * g + 2], sOk[blk * 16 + 4 * g + 3]};
+            for (int blk = 0; blk < 4; ++blk) {
+                const int ok4[4] = {sOk[blk * 16 + 4 * g], sOk[blk * 16 + 4 * g + 1], sOk[blk * 16 + 4 * g + 2], sOk[blk * 16 + 4 * g + 3]};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = k0 + blk * 16 + 4 * g + e;
-                const int vis = (q_ok ? 1 : 0) & (key <= my_last ? 1 : 0) & ok4[e];
-                sc[blk][e] = vis ? sc[blk][e] : -INFINITY;
-                mx = fmaxf(mx, sc[blk][e]);
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + blk * 16 + 4 * g + e;
+                    const int vis = (q_ok ? 1 : 0) & (key <= my_last ? 1 : 0) & ok4[e];
+                    sc[blk][e] = vis ? sc[blk][e] : -INFINITY;
+                    mx = fmaxf(mx, sc[blk][e]);
+                }
             }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float corr = (m_run == -INFINITY || m_new == -INFINITY) ? 0.f : expf(m_run - m_new);
-        float ps = 0.f;
-        float* pw = &sP[wave][r * LDP + 4 * g];
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float corr = (m_run == -INFINITY || m_new == -INFINITY) ? 0.f : expf(m_run - m_new);
+            float ps = 0.f;
+            float* pw = &sP[wave][r * LDP + 4 * g];
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            f32x4 p;
+            for (int blk = 0; blk < 4; ++blk) {
+                f32x4 p;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                p[e] = sc[blk][e] == -INFINITY ? 0.f : expf(sc[blk][e] - m_new);
-                ps += p[e];
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = sc[blk][e] == -INFINITY ? 0.f : expf(sc[blk][e] - m_new);
+                    ps += p[e];
+                }
+                *(f32x4*)(pw + blk * 16) = p;                                 // P[query r][key 16 blk + 4 g + e]
             }
-            *(f32x4*)(pw + blk * 16) = p;                                 // P[query r][key 16 blk + 4 g + e]
-        }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        l_run = l_run * corr + ps;
-        if (m_new != -INFINITY) m_run = m_new;
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l_run = l_run * corr + ps;
+            if (m_new != -INFINITY) m_run = m_new;
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) o[d] *= corr;
-        // ---- O^T += V^T P^T: K step ks of lane group g is key 16 g + ks
-        float pb[16];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // P: written and read by the same wave, other lanes
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            const float* pr = &sP[wave][r * LDP + 16 * g];
+            for (int d = 0; d < HD / 16; ++d) o[d] *= corr;
+            // ---- O^T += V^T P^T: K step ks of lane group g is key 16 g + ks
+            float pb[16];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // P: written and read by the same wave, other lanes
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const float* pr = &sP[wave][r * LDP + 16 * g];
 #pragma unroll
-            for (int k = 0; k < 16; k += 4) {
-                const f32x4 t = *(const f32x4*)(pr + k);
-                pb[k] = t[0]; pb[k + 1] = t[1]; pb[k + 2] = t[2]; pb[k + 3] = t[3];
+                for (int k = 0; k < 16; k += 4) {
+                    const f32x4 t = *(const f32x4*)(pr + k);
+                    pb[k] = t[0]; pb[k + 1] = t[1]; pb[k + 2] = t[2]; pb[k + 3] = t[3];
+                }
             }
-        }
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) {
-            const float* vr = sV + (16 * g) * LDK + d * 16 + r;
+            for (int d = 0; d < HD / 16; ++d) {
+                const float* vr = sV + (16 * g) * LDK + d * 16 + r;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[k * LDK], pb[k], o[d], 0, 0, 0);
-        }
+                for (int k = 0; k < 16; ++k)
+                    if (!PART || k0 + k <= wave_last) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[k * LDK], pb[k], o[d], 0, 0, 0);   // keys k, 16 + k, 32 + k, 48 + k
+            }
+    
+        };
+        if (k0 + 63 <= wave_last) tile_body(std::false_type{});
+        else tile_body(std::true_type{});
     }
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;               // a fully masked (padded) query row yields zeros
