@@ -318,6 +318,83 @@ __global__ void __launch_bounds__(256) norm_f32_kernel(const float* __restrict__
     }
 }
 
+// ---- the two norms, four elements per lane (round 6; D % 4 == 0 and 16-byte aligned rows — the scalar kernels around them serve the rest).
+// norm_split3_kernel moved 337 MB per ViT call in 103 us (3.3 TB/s): 4-byte loads, three 2-byte stores per element.  Here a lane reads 16
+// bytes and writes three 8-byte pieces: the statistics are ONE routine for both kernels (lane l sums the float4 l, l + 64, ... in order,
+// (a0 + a1) + (a2 + a3) each; the butterfly of wave_sum after), so norm_split3 stays value for value norm + split3
+// (tests/test_r6_gpu.py::test_norm_split3_equals_norm_then_split).
+VLY_DEVICE void norm_row_stats4(const float* __restrict__ xr, int D, int lane, int rms, float eps, float& mean, float& rstd) {
+    const int nv = D >> 2;
+    float s = 0.f;
+    if (!rms)
+        for (int v = lane; v < nv; v += 64) {
+            const f32x4 a = *(const f32x4*)(xr + 4 * v);
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+    mean = rms ? 0.f : wave_sum(s) / D;
+    float q = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        const f32x4 a = *(const f32x4*)(xr + 4 * v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float c = a[r] - mean;
+            q = fmaf(c, c, q);
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+}
+VLY_DEVICE f32x4 norm_apply4(const f32x4& a, const f32x4& gm, const f32x4& bt, float mean, float rstd, int rms) {
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float n = (a[r] - mean) * rstd;
+        y[r] = rms ? gm[r] * n : fmaf(n, gm[r], bt[r]);
+    }
+    return y;
+}
+__global__ void __launch_bounds__(256) norm_f32_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y, int M, int D, float eps,
+                                                           int rms) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float mean, rstd;
+    norm_row_stats4(xr, D, lane, rms, eps, mean, rstd);
+    float* yr = y + (size_t)row * D;
+    for (int v = lane; v < (D >> 2); v += 64) {
+        const f32x4 bt = rms ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(beta + 4 * v);
+        *(f32x4*)(yr + 4 * v) = norm_apply4(*(const f32x4*)(xr + 4 * v), *(const f32x4*)(gamma + 4 * v), bt, mean, rstd, rms);
+    }
+}
+__global__ void __launch_bounds__(256) norm_split3_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, uint16_t* __restrict__ out, int M, int D, int Kp,
+                                                              float eps, int rms) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float mean, rstd;
+    norm_row_stats4(xr, D, lane, rms, eps, mean, rstd);
+    uint16_t* orow = out + (size_t)row * (3 * Kp);
+    for (int v = lane; v < (Kp >> 2); v += 64) {
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+        if (4 * v < D) {
+            const f32x4 bt = rms ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(beta + 4 * v);
+            yv = norm_apply4(*(const f32x4*)(xr + 4 * v), *(const f32x4*)(gamma + 4 * v), bt, mean, rstd, rms);
+        }
+        uint16_t hi[4], lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hi[r] = f2h(yv[r]);
+            lo[r] = f2h(yv[r] - h2f(hi[r]));
+        }
+        const u32x2 H = {(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+        const u32x2 L = {(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+        *(u32x2*)(orow + 4 * v) = H;
+        *(u32x2*)(orow + Kp + 4 * v) = H;
+        *(u32x2*)(orow + 2 * Kp + 4 * v) = L;
+    }
+}
+
 // The same norm writing the split-operand image [hi | hi | lo] of its result straight away (x3 GEMMs, round 6): the fp32 result never
 // goes to memory — 4 B read + 6 B written per element instead of 4 + 4 (norm) and 4 + 6 (vly_split3_f32).  Same arithmetic as
 // norm_f32_kernel + split3_kernel<NONE>, value for value.
@@ -568,14 +645,19 @@ extern "C" int vly_attention_f32(const float* q, long q_batch_stride, int q_row_
 extern "C" int vly_norm_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int D, float eps, int rms,
                             void* stream) {
     if (M <= 0 || D <= 0 || !gamma || (!rms && !beta)) { vly_set_error("vly_norm_f32: bad args M=%d D=%d", M, D); return -22; }
-    hipLaunchKernelGGL(norm_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, M, D, eps, rms);
+    const bool vec = D % 4 == 0 && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15);
+    if (vec) hipLaunchKernelGGL(norm_f32_vec_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, M, D, eps, rms);
+    else hipLaunchKernelGGL(norm_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, M, D, eps, rms);
     return vly_check_launch("vly_norm_f32");
 }
 
 extern "C" int vly_norm_split3_f32(const float* x, const float* gamma, const float* beta, void* out3, int M, int D, int Kp, float eps, int rms,
                                    void* stream) {
     if (M <= 0 || D <= 0 || Kp < D || !gamma || (!rms && !beta) || !out3) { vly_set_error("vly_norm_split3_f32: bad args M=%d D=%d Kp=%d", M, D, Kp); return -22; }
-    hipLaunchKernelGGL(norm_split3_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)out3, M, D, Kp, eps, rms);
+    // (the same predicate as vly_norm_f32's: the pair norm + split3 and this kernel then take the same statistics routine)
+    const bool vec = D % 4 == 0 && Kp % 4 == 0 && !(((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) && !((uintptr_t)out3 & 7);
+    if (vec) hipLaunchKernelGGL(norm_split3_vec_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)out3, M, D, Kp, eps, rms);
+    else hipLaunchKernelGGL(norm_split3_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)out3, M, D, Kp, eps, rms);
     return vly_check_launch("vly_norm_split3_f32");
 }
 
