@@ -158,15 +158,18 @@ __global__ void __launch_bounds__(64) attention_f32_kernel(const float* __restri
 // The contraction index is permuted so that a lane's operands are contiguous: in K step ks lane group g takes d = g HD/4 + ks (QK^T)
 // and key = 16 g + ks (PV); P goes through a per-wave LDS strip [query][key] to change owner.  Every product and sum is an fp32
 // fma (the MFMA is bit-for-bit an fmaf chain); the order of summation differs from the scalar kernel, nothing else.
-template <int HD>
+// KT keys per LDS tile: 64 at head_dim 64 (52 KB: three workgroups per CU); 32 at head_dim 128, where 64 made 85 KB — ONE workgroup per
+// CU, one wave per SIMD, every tile's memory round trip and both barriers exposed (0.35 ms per 13B layer for 68 us of MFMA).
+template <int HD, int KT>
 __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __restrict__ Q, long q_bs, int q_rs, const float* __restrict__ Kp,
                                                                  const float* __restrict__ Vp, long kv_bs, long kv_hs, int kv_rs,
                                                                  const uint8_t* __restrict__ key_valid, int kv_valid_stride,
                                                                  float* __restrict__ O, long o_bs, int o_rs, int n_q, int n_kv, int causal,
                                                                  int past, float scale) {
-    constexpr int KS = HD / 4, LDK = HD + 4, LDP = 68;                   // K steps of QK^T; padded LDS rows (floats)
-    __shared__ __attribute__((aligned(16))) float sK[64 * LDK], sV[64 * LDK], sP[4][16 * LDP];
-    __shared__ __attribute__((aligned(16))) int sOk[64];                 // key k0 + row exists and is valid (branch-free masking below)
+    constexpr int KS = HD / 4, LDK = HD + 4, LDP = KT + 4;               // K steps of QK^T; padded LDS rows (floats)
+    constexpr int NB = KT / 16, GS = KT / 4;                             // 16-key blocks per tile; keys per lane group in the second product
+    __shared__ __attribute__((aligned(16))) float sK[KT * LDK], sV[KT * LDK], sP[4][16 * LDP];
+    __shared__ __attribute__((aligned(16))) int sOk[KT];                 // key k0 + row exists and is valid (branch-free masking below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z, qb0 = blockIdx.x * 64, qi = qb0 + wave * 16 + r;
     const bool q_ok = qi < n_q;
@@ -193,9 +196,9 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    for (int k0 = 0; k0 <= blk_last; k0 += 64) {
+    for (int k0 = 0; k0 <= blk_last; k0 += KT) {
         __syncthreads();                                                  // the previous tile's readers are done
-        for (int s = tid; s < 64 * (HD / 4); s += 256) {                  // K and V rows k0 .. k0 + 63 (zeros past the end)
+        for (int s = tid; s < KT * (HD / 4); s += 256) {                  // K and V rows k0 .. k0 + KT - 1 (zeros past the end)
             const int row = s / (HD / 4), c4 = (s % (HD / 4)) * 4;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
             if (k0 + row < n_kv) {
@@ -205,16 +208,16 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
             *(f32x4*)(sK + row * LDK + c4) = kv;
             *(f32x4*)(sV + row * LDK + c4) = vv;
         }
-        if (tid < 64) sOk[tid] = (k0 + tid < n_kv && (!valid || valid[min(k0 + tid, n_kv - 1)])) ? 1 : 0;
+        if (tid < KT) sOk[tid] = (k0 + tid < n_kv && (!valid || valid[min(k0 + tid, n_kv - 1)])) ? 1 : 0;
         __syncthreads();
         if (!wave_active || k0 > wave_last) continue;                     // (the loads and the barriers above are the whole workgroup's)
         // a tile this wave sees whole runs the branch-free body; only a tile cut by wave_last tests its blocks / key quadruples
         const auto tile_body = [&](auto part_c) {
             constexpr bool PART = decltype(part_c)::value;
-            // ---- S^T: 4 key blocks x KS K steps
-            f32x4 sc[4];
+            // ---- S^T: NB key blocks x KS K steps
+            f32x4 sc[NB];
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
+            for (int blk = 0; blk < NB; ++blk) {
                 sc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (PART && k0 + blk * 16 > wave_last) continue;              // every score of the block is masked below
                 const float* kr = sK + (blk * 16 + r) * LDK + g * KS;
@@ -227,10 +230,10 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
                     sc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], q[k + 3], sc[blk], 0, 0, 0);
                 }
             }
-            // ---- mask, online softmax of query r (its 64 scores sit in 4 lanes x 16 registers)
+            // ---- mask, online softmax of query r (its KT scores sit in 4 lanes x KT / 4 registers)
             float mx = -INFINITY;
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
+            for (int blk = 0; blk < NB; ++blk) {
                 const int ok4[4] = {sOk[blk * 16 + 4 * g], sOk[blk * 16 + 4 * g + 1], sOk[blk * 16 + 4 * g + 2], sOk[blk * 16 + 4 * g + 3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
             float ps = 0.f;
             float* pw = &sP[wave][r * LDP + 4 * g];
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
+            for (int blk = 0; blk < NB; ++blk) {
                 f32x4 p;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -262,29 +265,29 @@ __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __
             if (m_new != -INFINITY) m_run = m_new;
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d) o[d] *= corr;
-            // ---- O^T += V^T P^T: K step ks of lane group g is key 16 g + ks
-            float pb[16];
+            // ---- O^T += V^T P^T: K step ks of lane group g is key GS g + ks
+            float pb[GS];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // P: written and read by the same wave, other lanes
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             {
-                const float* pr = &sP[wave][r * LDP + 16 * g];
+                const float* pr = &sP[wave][r * LDP + GS * g];
 #pragma unroll
-                for (int k = 0; k < 16; k += 4) {
+                for (int k = 0; k < GS; k += 4) {
                     const f32x4 t = *(const f32x4*)(pr + k);
                     pb[k] = t[0]; pb[k + 1] = t[1]; pb[k + 2] = t[2]; pb[k + 3] = t[3];
                 }
             }
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d) {
-                const float* vr = sV + (16 * g) * LDK + d * 16 + r;
+                const float* vr = sV + (GS * g) * LDK + d * 16 + r;
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (!PART || k0 + k <= wave_last) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[k * LDK], pb[k], o[d], 0, 0, 0);   // keys k, 16 + k, 32 + k, 48 + k
+                for (int k = 0; k < GS; ++k)
+                    if (!PART || k0 + k <= wave_last) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[k * LDK], pb[k], o[d], 0, 0, 0);   // keys k, GS + k, 2 GS + k, 3 GS + k
             }
     
         };
-        if (k0 + 63 <= wave_last) tile_body(std::false_type{});
+        if (k0 + KT - 1 <= wave_last) tile_body(std::false_type{});
         else tile_body(std::true_type{});
     }
     if (q_ok) {
@@ -621,11 +624,11 @@ extern "C" int vly_attention_f32(const float* q, long q_batch_stride, int q_row_
         !((uintptr_t)q & 15) && !((uintptr_t)out & 15)) {
         dim3 grid((n_q + 63) / 64, heads, B), block(256);
         if (head_dim == 64)
-            hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+            hipLaunchKernelGGL((attention_f32_mfma_kernel<64, 64>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
                                kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
                                causal, past_len, scale);
         else
-            hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+            hipLaunchKernelGGL((attention_f32_mfma_kernel<128, 32>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
                                kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
                                causal, past_len, scale);
         return vly_check_launch("vly_attention_f32");
