@@ -158,8 +158,10 @@ __global__ void __launch_bounds__(64) attention_f32_kernel(const float* __restri
 // The contraction index is permuted so that a lane's operands are contiguous: in K step ks lane group g takes d = g HD/4 + ks (QK^T)
 // and key = 16 g + ks (PV); P goes through a per-wave LDS strip [query][key] to change owner.  Every product and sum is an fp32
 // fma (the MFMA is bit-for-bit an fmaf chain); the order of summation differs from the scalar kernel, nothing else.
-// KT keys per LDS tile: 64 at head_dim 64 (52 KB: three workgroups per CU); 32 at head_dim 128, where 64 made 85 KB — ONE workgroup per
-// CU, one wave per SIMD, every tile's memory round trip and both barriers exposed (0.35 ms per 13B layer for 68 us of MFMA).
+// KT keys per LDS tile: 32 (round 6).  With 64, head_dim 128 needed 85 KB — ONE workgroup per CU, one wave per SIMD, every tile's memory
+// round trip and both barriers exposed (0.35 ms per 13B layer for 68 us of MFMA; 43 KB and 164 registers now: three per CU, prefill on the
+// split-operand engine 173 -> 166.6 ms) — and head_dim 64 52 KB / 152 registers (three per CU; 27 KB / 112 now: four, and 257 keys pad to 288
+// instead of 320: ViT pass 74.2 -> 71.7 ms).  profiles/r06/r06_x3_attn_kt32_ab.txt, r06_x3_attn_kt32_hd64_ab.txt.
 template <int HD, int KT>
 __global__ void __launch_bounds__(256) attention_f32_mfma_kernel(const float* __restrict__ Q, long q_bs, int q_rs, const float* __restrict__ Kp,
                                                                  const float* __restrict__ Vp, long kv_bs, long kv_hs, int kv_rs,
@@ -624,7 +626,7 @@ extern "C" int vly_attention_f32(const float* q, long q_batch_stride, int q_row_
         !((uintptr_t)q & 15) && !((uintptr_t)out & 15)) {
         dim3 grid((n_q + 63) / 64, heads, B), block(256);
         if (head_dim == 64)
-            hipLaunchKernelGGL((attention_f32_mfma_kernel<64, 64>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
+            hipLaunchKernelGGL((attention_f32_mfma_kernel<64, 32>), grid, block, 0, st, q, q_batch_stride, q_row_stride, k, v, kv_batch_stride,
                                kv_head_stride, kv_row_stride, key_valid, key_valid_stride, out, out_batch_stride, out_row_stride, n_q, n_kv,
                                causal, past_len, scale);
         else
